@@ -1,0 +1,141 @@
+/*
+ * mcg.h -- C ABI of the MI355X rollout engine for the MyCobotGym step()/reset() hot path.
+ *
+ * The reference has no FFI of its own: its hot path is MuJoCo driven from Python through the
+ * Gymnasium Env protocol.  Each entry point below replaces one reference interface, batched over
+ * N environments (citations relative to /root/reference):
+ *
+ *   mcg_create          MyCobotEnv.__init__ + _env_setup         mycobotgym/envs/mycobot.py:30-115, 450-481
+ *                       (MuJoCo model compile is replaced by the precompiled mcg_model block)
+ *   mcg_reset           MyCobotEnv.reset / reset_model / _sample_goal   mycobot.py:506-514, 207-243
+ *   mcg_step            MyCobotEnv.step (controller branch -> mujoco.mj_step x frame_skip -> _get_obs ->
+ *                       _is_success / compute_reward / compute_terminated / compute_truncated)
+ *                       mycobot.py:132-205, 245-298, 342-400; IKController mycobotgym/utils.py:499-556;
+ *                       TimeLimit(50) from the registration mycobotgym/__init__.py:34; auto-reset as in
+ *                       gymnasium.vector (info["final_observation"]) / SB3 VecEnv used by scripts/train.py:80-85
+ *   mcg_compute_reward  MyCobotEnv.compute_reward on batched goals (HER)   mycobot.py:289-298, utils.py:24-26
+ *   mcg_get_state / mcg_set_state   direct access to data.qpos/qvel/ctrl/qacc_warmstart (set_joint_qpos etc.)
+ *
+ * Conventions: every pointer in the step/reset/state calls is DEVICE memory owned by the caller;
+ * the engine owns its struct-of-arrays state.  Calls enqueue work on `stream` (a hipStream_t passed
+ * as void*, NULL = default stream) and return without synchronising.  Return 0 = OK, otherwise an
+ * MCG_ERR_* code with text in mcg_last_error().  A handle is bound to one device and is not
+ * thread-safe; distinct handles are independent.  There is no CPU fallback: without a HIP device
+ * mcg_create fails.
+ */
+#ifndef MCG_H
+#define MCG_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MCG_ABI_VERSION 1
+
+enum { MCG_OK = 0, MCG_ERR_ARG = 1, MCG_ERR_HIP = 2, MCG_ERR_UNSUPPORTED = 3 };
+enum { MCG_CTRL_JOINT = 0, MCG_CTRL_IK = 1 };                 /* controller_type "joint" | "IK" */
+enum { MCG_REWARD_SPARSE = 0, MCG_REWARD_DENSE = 1, MCG_REWARD_SHAPING = 2 };
+
+/* Numeric model block (produced by mycobotgym_amd/model/specialize.py from the compiled MJCF).
+   13 bodies: link1..6, right gear/finger, left gear/finger, right/left hinge, cube. */
+typedef struct mcg_model {
+  double timestep;
+  double base_pos[3], base_mat[9], gravity_base[3];
+  double r[13][3];                  /* body origin in its parent's frame */
+  double mass[13], mc[13][3];       /* mass, mass * centre of mass (body frame, about the origin) */
+  double inertia[13][6];            /* xx yy zz xy xz yz about the body origin */
+  double armature[18], damping[18];
+  double jnt_range[12][2];
+  double limit_par[12][7];          /* K B d0 dmax width midpoint power (refsafe applied) */
+  double limit_diag[12];            /* dof_invweight0 */
+  double eq_anchor1[2][3], eq_anchor2[2][3];
+  double eq_par[3][7], eq_diag[3];  /* connect right, connect left, joint coupling */
+  double act_gain[7], act_bias[7][3], act_ctrlrange[7][2], act_forcerange[7][2], tendon_coef[2];
+  double site_eef[3];               /* EEF site in the link6 frame */
+  /* PickAndPlace only */
+  double cube_half[3], table_pos[3], table_half[3], pad_box[2][6];
+  double contact_par[3][12];        /* table-cube, right pad-cube, left pad-cube: K B d0 dmax width mid power | friction[5] */
+  double contact_diag[3][2];        /* summed body_invweight0 (translational, rotational) */
+} mcg_model;
+
+typedef struct mcg_config {
+  int32_t n_envs;
+  int32_t has_object;          /* 0 = Reach, 1 = PickAndPlace                       (mycobot.py:33) */
+  int32_t controller;          /* MCG_CTRL_*                                       (mycobot.py:36) */
+  int32_t fetch_env;           /*                                                  (mycobot.py:41) */
+  int32_t reward_type;         /* MCG_REWARD_*                                     (mycobot.py:42) */
+  int32_t frame_skip;          /* 20                                               (mycobot.py:43) */
+  int32_t control_steps;       /* 5, IK only                                       (mycobot.py:35) */
+  int32_t max_episode_steps;   /* 50, TimeLimit                                    (__init__.py:34) */
+  int32_t target_in_the_air;   /*                                                  (mycobot.py:38) */
+  int32_t auto_reset;          /* reset finished envs inside mcg_step */
+  int32_t dr_enable;           /* per-reset domain randomisation (build-defined) */
+  int32_t reserved0;
+  double distance_threshold;   /* 0.01                                             (mycobot.py:39) */
+  double height_offset;        /* z of site object0 at the initial state           (mycobot.py:470-472) */
+  double initial_gripper_xpos[3];   /* EEF site at the initial state               (mycobot.py:464-466) */
+  double init_qpos[19], init_qvel[18], init_ctrl[7];   /* snapshot restored by reset (mycobot.py:80-82) */
+  double dr_mass_range[2], dr_friction_range[2];
+  uint64_t seed;
+  int64_t env_id_offset;       /* global id of env 0 of this handle: RNG streams are keyed by global id */
+} mcg_config;
+
+/* Output block of mcg_step / mcg_reset; all device pointers, any may be NULL to skip.  D = mcg_obs_dim. */
+typedef struct mcg_step_out {
+  double* obs;            /* [N, D]  "observation" (after auto-reset where done) */
+  double* achieved_goal;  /* [N, 3] */
+  double* desired_goal;   /* [N, 3] */
+  double* reward;         /* [N]     dense: -d (f64); sparse: -(d > thr) as in the reference's float32 */
+  uint8_t* terminated;    /* [N] */
+  uint8_t* truncated;     /* [N]     is_success | elapsed >= max_episode_steps */
+  uint8_t* is_success;    /* [N] */
+  double* final_obs;      /* [N, D]  pre-reset observation, valid where terminated|truncated */
+  double* final_achieved; /* [N, 3] */
+  double* final_desired;  /* [N, 3] */
+  double* ep_return;      /* [N]     running episode return (Monitor's "r" where done) */
+  int32_t* ep_length;     /* [N]     running episode length (Monitor's "l" where done) */
+} mcg_step_out;
+
+/* State arrays are struct-of-arrays [dim, N] (N fastest), the engine's native layout. */
+typedef struct mcg_state {
+  double* qpos;      /* [nq, N]   nq = 12 (Reach) | 19 (PickAndPlace) */
+  double* qvel;      /* [nv, N]   nv = 12 | 18 */
+  double* ctrl;      /* [7, N] */
+  double* warm;      /* [nv, N]   qacc_warmstart */
+  double* qpos_lag;  /* [nq, N]   qpos of the last forward pass: observations lag one sub-step (SURVEY D-1) */
+  double* goal;      /* [3, N] */
+  int32_t* elapsed;  /* [N] */
+  int32_t* episode;  /* [N]       per-env episode counter (RNG stream position) */
+} mcg_state;
+
+typedef struct mcg_env mcg_env;
+
+int mcg_abi_version(void);
+const char* mcg_last_error(void);
+/* built-in model blocks: 0 = legacy mesh inertia (default), 1 = exact mesh inertia */
+int mcg_default_model(int variant, mcg_model* out);
+
+int mcg_create(const mcg_config* cfg, const mcg_model* model /* NULL = variant 0 */, int device, mcg_env** out);
+void mcg_destroy(mcg_env* env);
+int mcg_obs_dim(const mcg_env* env);
+int mcg_action_dim(const mcg_env* env);
+int mcg_nq(const mcg_env* env);
+int mcg_nv(const mcg_env* env);
+
+int mcg_reset(mcg_env* env, const uint8_t* mask /* [N] device or NULL = all */, int reseed, uint64_t seed,
+              const mcg_step_out* out, void* stream);
+int mcg_step(mcg_env* env, const float* actions /* [N, A] row-major, device */, const mcg_step_out* out, void* stream);
+int mcg_get_state(mcg_env* env, const mcg_state* dst, void* stream);
+int mcg_set_state(mcg_env* env, const mcg_state* src, void* stream);
+int mcg_compute_reward(const double* achieved /* [n,3] device */, const double* desired, int n, int reward_type,
+                       double threshold, double* out, void* stream);
+
+/* Live timing of the step kernel on its own stream with HIP events (used by bench.py's roofline leg). */
+int mcg_time_steps(mcg_env* env, const float* actions, const mcg_step_out* out, int steps, void* stream, float* ms_total);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

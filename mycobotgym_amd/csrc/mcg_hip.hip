@@ -1,0 +1,372 @@
+// mcg_hip.hip -- kernels and C ABI of the MI355X rollout engine (see include/mcg.h for the boundary).
+//
+// One environment per lane, 64-lane workgroups, struct-of-arrays state in HBM ([field][N], N fastest, so every
+// state load/store of a wave is one contiguous 512-byte row).  A whole env.step() -- controller, all physics
+// sub-steps, observation, reward, termination, TimeLimit, auto-reset with Philox sampling -- is ONE launch: state
+// is read once and written once per env-step (B = 2*S + A + O bytes per env-step).
+// gfx950 only; no CPU fallback exists on purpose.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "mcg.h"
+#include "mcg_dynamics.hpp"
+#include "model_gen.h"
+
+using namespace mcg;
+
+namespace {
+
+thread_local char g_err[512] = "";
+int fail(int code, const char* fmt, const char* a = "") { snprintf(g_err, sizeof(g_err), fmt, a); return code; }
+#define HIP_OK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(MCG_ERR_HIP, #expr ": %s", hipGetErrorString(e_)); } while (0)
+
+// ------------------------------------------------------------------------------------------- device-side views
+struct Cfg {
+  int n, has_object, controller, fetch, reward_type, frame_skip, control_steps, max_episode_steps;
+  int target_in_the_air, auto_reset, nq, nv, obs_dim, act_dim;
+  double distance_threshold, height_offset, igx[3], dt, grip_center, grip_range;
+  double init_qpos[19], init_qvel[18], init_ctrl[7];
+  unsigned long long seed;
+  long long env_id_offset;
+};
+
+struct View {           // SoA state: field f of env i at d[f * n + i]
+  double* d; int32_t* i32; int n, nq, nv;
+  __device__ double& qpos(int k, int i) const { return d[(size_t)k * n + i]; }
+  __device__ double& qvel(int k, int i) const { return d[(size_t)(nq + k) * n + i]; }
+  __device__ double& ctrl(int k, int i) const { return d[(size_t)(nq + nv + k) * n + i]; }
+  __device__ double& warm(int k, int i) const { return d[(size_t)(nq + nv + 7 + k) * n + i]; }
+  __device__ double& qlag(int k, int i) const { return d[(size_t)(nq + 2 * nv + 7 + k) * n + i]; }
+  __device__ double& goal(int k, int i) const { return d[(size_t)(2 * nq + 2 * nv + 7 + k) * n + i]; }
+  __device__ double& epret(int i) const { return d[(size_t)(2 * nq + 2 * nv + 10) * n + i]; }
+  __device__ int32_t& elapsed(int i) const { return i32[i]; }
+  __device__ int32_t& episode(int i) const { return i32[n + i]; }
+  __device__ int32_t& eplen(int i) const { return i32[2 * n + i]; }
+};
+inline int state_doubles(int nq, int nv) { return 2 * nq + 2 * nv + 11; }
+
+struct Env {            // one lane's working set
+  Robot R;
+  real qlag6[6], goal[3], epret;
+  int32_t elapsed, episode, eplen;
+  uint32_t draw;
+};
+
+// ------------------------------------------------------------------------------------------------- sampling
+__device__ void rng_pair(const Cfg& C, int i, Env& E, uint32_t stream, real& u0, real& u1) {
+  unsigned long long gid = (unsigned long long)(C.env_id_offset + i);
+  uint32_t r[4];
+  philox4x32_10((uint32_t)gid, (uint32_t)E.episode, E.draw++, stream ^ ((uint32_t)(gid >> 32) << 8),
+                (uint32_t)C.seed, (uint32_t)(C.seed >> 32), r);
+  u0 = (real)((((unsigned long long)r[0] << 32) | r[1]) >> 11) * (1.0 / 9007199254740992.0);
+  u1 = (real)((((unsigned long long)r[2] << 32) | r[3]) >> 11) * (1.0 / 9007199254740992.0);
+}
+
+// _sample_goal (mycobot.py:238-243) with generate_random_point_inside_rectangle (utils.py:14-21)
+__device__ void sample_goal(const Cfg& C, int i, Env& E, real* g) {
+  real ux, uy, uc, uz;
+  rng_pair(C, i, E, 0, ux, uy);
+  rng_pair(C, i, E, 0, uc, uz);
+  g[0] = -0.12 + (0.12 - -0.12) * ux;
+  g[1] = -0.06 + (0.06 - -0.06) * uy;
+  g[2] = C.height_offset;
+  if (C.target_in_the_air && uc < 0.5) g[2] += 0.0 + (0.1 - 0.0) * uz;
+}
+
+// reset_model (mycobot.py:207-236), Reach: the object position stays the initial gripper xy
+__device__ void reset_env(const Cfg& C, int i, Env& E) {
+  E.draw = 0;
+  for (int k = 0; k < NB; k++) { E.R.q[k] = C.init_qpos[k]; E.R.qd[k] = C.init_qvel[k]; }
+  for (int k = 0; k < 7; k++) E.R.ctrl[k] = C.init_ctrl[k];
+  real ox = C.igx[0], oy = C.igx[1];
+  int tries = 0;
+  sample_goal(C, i, E, E.goal);
+  while (sqrt((E.goal[0] - ox) * (E.goal[0] - ox) + (E.goal[1] - oy) * (E.goal[1] - oy)) < 0.1 && tries++ < 1000)
+    sample_goal(C, i, E, E.goal);
+  for (int k = 0; k < 6; k++) E.qlag6[k] = E.R.q[k];
+  E.elapsed = 0; E.epret = 0; E.eplen = 0;
+  E.episode++;
+}
+
+// _get_obs / generate_mujoco_observations for Reach (mycobot.py:245-283, 342-388): 10 numbers
+__device__ void observe_reach(const Cfg& C, const mcg_model* __restrict__ P, const Env& E, real* obs, real* ag) {
+  EefPose X;
+  eef_forward(P, E.qlag6, X, true);
+  for (int k = 0; k < 3; k++) {
+    real v = 0;
+    for (int j = 0; j < 6; j++) v += X.jacp[k][j] * E.R.qd[j];
+    obs[k] = X.pos[k]; obs[5 + k] = v * C.dt; ag[k] = X.pos[k];
+  }
+  obs[3] = E.R.q[6]; obs[4] = E.R.q[8];
+  obs[8] = E.R.qd[6] * C.dt; obs[9] = E.R.qd[8] * C.dt;
+}
+
+__device__ void load_env(const View& V, int i, Env& E) {
+  for (int k = 0; k < NB; k++) { E.R.q[k] = V.qpos(k, i); E.R.qd[k] = V.qvel(k, i); E.R.warm[k] = V.warm(k, i); }
+  for (int k = 0; k < 7; k++) E.R.ctrl[k] = V.ctrl(k, i);
+  for (int k = 0; k < 6; k++) E.qlag6[k] = V.qlag(k, i);
+  for (int k = 0; k < 3; k++) E.goal[k] = V.goal(k, i);
+  E.epret = V.epret(i); E.elapsed = V.elapsed(i); E.episode = V.episode(i); E.eplen = V.eplen(i);
+  E.draw = 0;
+}
+__device__ void store_env(const View& V, int i, const Env& E) {
+  for (int k = 0; k < NB; k++) { V.qpos(k, i) = E.R.q[k]; V.qvel(k, i) = E.R.qd[k]; V.warm(k, i) = E.R.warm[k]; }
+  for (int k = 0; k < 7; k++) V.ctrl(k, i) = E.R.ctrl[k];
+  for (int k = 0; k < 6; k++) V.qlag(k, i) = E.qlag6[k];
+  for (int k = 0; k < 3; k++) V.goal(k, i) = E.goal[k];
+  V.epret(i) = E.epret; V.elapsed(i) = E.elapsed; V.episode(i) = E.episode; V.eplen(i) = E.eplen;
+}
+
+__device__ void write_obs(const mcg_step_out& O, int i, int D, const real* obs, const real* ag, const real* goal) {
+  if (O.obs) for (int k = 0; k < D; k++) O.obs[(size_t)i * D + k] = obs[k];
+  if (O.achieved_goal) for (int k = 0; k < 3; k++) O.achieved_goal[(size_t)i * 3 + k] = ag[k];
+  if (O.desired_goal) for (int k = 0; k < 3; k++) O.desired_goal[(size_t)i * 3 + k] = goal[k];
+}
+
+// ------------------------------------------------------------------------------------------------ step kernel
+// MyCobotEnv.step (mycobot.py:132-205) for Reach, controller = joint | IK.
+template <int CONTROLLER>
+__global__ __launch_bounds__(64) void step_reach_kernel(Cfg C, View V, const mcg_model* __restrict__ P,
+                                                        const float* __restrict__ actions, mcg_step_out O) {
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= C.n) return;
+  Env E;
+  load_env(V, i, E);
+  float act[7];
+  for (int k = 0; k < C.act_dim; k++) { float x = actions[(size_t)i * C.act_dim + k]; act[k] = fminf(fmaxf(x, -1.f), 1.f); }
+
+  if constexpr (CONTROLLER == MCG_CTRL_IK) {
+    EefPose X;
+    eef_forward(P, E.qlag6, X, true);
+    real tpos[3], tquat[4];
+    for (int k = 0; k < 3; k++) tpos[k] = X.pos[k] + (real)(act[k] * 0.2f);      // f32 product, as numpy computes it
+    if (C.fetch) { tquat[0] = 0; tquat[1] = -0.707; tquat[2] = 0; tquat[3] = 0.707; }
+    else {
+      real e[3], qr[4], cur[4];
+      for (int k = 0; k < 3; k++) e[k] = (real)(act[3 + k] * 0.5f);
+      euler2quat(e, qr); mat2quat(X.mat, cur); mulquat(qr, cur, tquat);
+    }
+    const real grip = C.grip_center + (real)act[C.act_dim - 1] * C.grip_range;
+    for (int c = 0; c < C.control_steps; c++) {
+      if (c > 0) eef_forward(P, E.qlag6, X, true);
+      real dq[6];
+      ik_delta(X, tpos, tquat, dq);
+      for (int k = 0; k < 6; k++) E.R.ctrl[k] += dq[k];
+      E.R.ctrl[6] = grip;
+      for (int s = 0; s < C.frame_skip; s++) robot_substep(P, E.R, E.qlag6);
+    }
+  } else {
+    for (int k = 0; k < 7; k++) E.R.ctrl[k] = (real)act[k];
+    for (int s = 0; s < C.frame_skip; s++) robot_substep(P, E.R, E.qlag6);
+  }
+
+  real obs[10], ag[3];
+  observe_reach(C, P, E, obs, ag);
+  real dx = ag[0] - E.goal[0], dy = ag[1] - E.goal[1], dz = ag[2] - E.goal[2];
+  const real dist = sqrt(dx * dx + dy * dy + dz * dz);                       // goal_distance, utils.py:24-26
+  const bool succ = dist < C.distance_threshold;                            // _is_success, mycobot.py:285-287
+  const real rew = C.reward_type == MCG_REWARD_SPARSE ? -(real)(float)(dist > C.distance_threshold) : -dist;
+  E.elapsed++; E.eplen++; E.epret += rew;
+  const bool term = succ;                                                   // compute_terminated, :390-394
+  const bool trunc = succ || (E.elapsed >= C.max_episode_steps);            // compute_truncated :396-400 | TimeLimit
+  if (O.reward) O.reward[i] = rew;
+  if (O.terminated) O.terminated[i] = term;
+  if (O.truncated) O.truncated[i] = trunc;
+  if (O.is_success) O.is_success[i] = succ;
+  if (O.ep_return) O.ep_return[i] = E.epret;
+  if (O.ep_length) O.ep_length[i] = E.eplen;
+  if ((term || trunc) && C.auto_reset) {
+    if (O.final_obs) for (int k = 0; k < 10; k++) O.final_obs[(size_t)i * 10 + k] = obs[k];
+    if (O.final_achieved) for (int k = 0; k < 3; k++) O.final_achieved[(size_t)i * 3 + k] = ag[k];
+    if (O.final_desired) for (int k = 0; k < 3; k++) O.final_desired[(size_t)i * 3 + k] = E.goal[k];
+    reset_env(C, i, E);
+    observe_reach(C, P, E, obs, ag);
+  }
+  write_obs(O, i, 10, obs, ag, E.goal);
+  store_env(V, i, E);
+}
+
+__global__ __launch_bounds__(64) void reset_reach_kernel(Cfg C, View V, const mcg_model* __restrict__ P,
+                                                         const uint8_t* __restrict__ mask, int reseed, mcg_step_out O) {
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= C.n) return;
+  Env E;
+  load_env(V, i, E);
+  if (!mask || mask[i]) {
+    if (reseed) E.episode = 0;
+    reset_env(C, i, E);
+    store_env(V, i, E);
+  }
+  real obs[10], ag[3];
+  observe_reach(C, P, E, obs, ag);
+  write_obs(O, i, 10, obs, ag, E.goal);
+}
+
+// compute_reward on batched goals (mycobot.py:289-298) -- the HER entry point
+__global__ void reward_kernel(const double* __restrict__ ag, const double* __restrict__ dg, int n, int reward_type,
+                              double thr, double* __restrict__ out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double dx = ag[3 * i] - dg[3 * i], dy = ag[3 * i + 1] - dg[3 * i + 1], dz = ag[3 * i + 2] - dg[3 * i + 2];
+  double d = sqrt(dx * dx + dy * dy + dz * dz);
+  out[i] = reward_type == MCG_REWARD_SPARSE ? -(double)(float)(d > thr) : -d;
+}
+
+// state <-> caller arrays (both SoA [dim, N])
+__global__ void copy_state_kernel(View V, mcg_state S, int to_engine) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= V.n) return;
+  const int n = V.n;
+#define CP(ptr, acc, cnt) if (S.ptr) for (int k = 0; k < cnt; k++) { if (to_engine) V.acc(k, i) = S.ptr[(size_t)k * n + i]; else S.ptr[(size_t)k * n + i] = V.acc(k, i); }
+  CP(qpos, qpos, V.nq) CP(qvel, qvel, V.nv) CP(ctrl, ctrl, 7) CP(warm, warm, V.nv) CP(qpos_lag, qlag, V.nq) CP(goal, goal, 3)
+#undef CP
+  if (S.elapsed) { if (to_engine) V.elapsed(i) = S.elapsed[i]; else S.elapsed[i] = V.elapsed(i); }
+  if (S.episode) { if (to_engine) V.episode(i) = S.episode[i]; else S.episode[i] = V.episode(i); }
+}
+
+}  // namespace
+
+// ================================================================================================== host ABI
+struct mcg_env {
+  Cfg cfg;
+  View view;
+  mcg_model* d_model;
+  int device;
+};
+
+extern "C" {
+
+int mcg_abi_version(void) { return MCG_ABI_VERSION; }
+const char* mcg_last_error(void) { return g_err; }
+
+int mcg_default_model(int variant, mcg_model* out) {
+  if (!out || variant < 0 || variant >= MCG_NUM_MODEL_VARIANTS) return fail(MCG_ERR_ARG, "mcg_default_model: bad variant%s");
+  memcpy(out, &kDefaultModels[variant], sizeof(mcg_model));
+  return MCG_OK;
+}
+
+int mcg_create(const mcg_config* c, const mcg_model* model, int device, mcg_env** out) {
+  if (!c || !out) return fail(MCG_ERR_ARG, "mcg_create: null argument%s");
+  if (c->n_envs <= 0) return fail(MCG_ERR_ARG, "mcg_create: n_envs must be positive%s");
+  if (c->has_object) return fail(MCG_ERR_UNSUPPORTED, "mcg_create: PickAndPlace (has_object) is not built yet%s");
+  if (c->controller != MCG_CTRL_JOINT && c->controller != MCG_CTRL_IK) return fail(MCG_ERR_ARG, "mcg_create: controller must be joint or IK%s");
+  if (c->controller == MCG_CTRL_JOINT && c->fetch_env) return fail(MCG_ERR_ARG, "Joint controller not supported for Fetch env%s");  // mycobot.py:96
+  if (c->reward_type == MCG_REWARD_SHAPING) return fail(MCG_ERR_UNSUPPORTED, "mcg_create: reward_shaping needs the contact stage (not built yet)%s");
+  if (c->reward_type != MCG_REWARD_SPARSE && c->reward_type != MCG_REWARD_DENSE) return fail(MCG_ERR_ARG, "mcg_create: bad reward_type%s");
+  if (c->frame_skip <= 0 || c->control_steps <= 0 || c->max_episode_steps <= 0) return fail(MCG_ERR_ARG, "mcg_create: frame_skip, control_steps, max_episode_steps must be positive%s");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(MCG_ERR_HIP, "mcg_create: no HIP device (this engine has no CPU path)%s");
+  if (device < 0 || device >= ndev) return fail(MCG_ERR_ARG, "mcg_create: bad device index%s");
+  HIP_OK(hipSetDevice(device));
+  mcg_env* e = new (std::nothrow) mcg_env();
+  if (!e) return fail(MCG_ERR_ARG, "mcg_create: out of host memory%s");
+  const mcg_model* m = model ? model : &kDefaultModels[0];
+  Cfg& C = e->cfg;
+  C.n = c->n_envs; C.has_object = c->has_object; C.controller = c->controller; C.fetch = c->fetch_env;
+  C.reward_type = c->reward_type; C.frame_skip = c->frame_skip; C.control_steps = c->control_steps;
+  C.max_episode_steps = c->max_episode_steps; C.target_in_the_air = c->target_in_the_air; C.auto_reset = c->auto_reset;
+  C.nq = c->has_object ? 19 : 12; C.nv = c->has_object ? 18 : 12;
+  C.obs_dim = c->has_object ? 25 : 10;
+  C.act_dim = (c->controller == MCG_CTRL_IK && c->fetch_env) ? 4 : 7;                 // mycobot.py:84-103
+  C.distance_threshold = c->distance_threshold; C.height_offset = c->height_offset;
+  for (int k = 0; k < 3; k++) C.igx[k] = c->initial_gripper_xpos[k];
+  C.dt = c->frame_skip * m->timestep;                                                // mycobot.py:346
+  C.grip_range = (m->act_ctrlrange[6][1] - m->act_ctrlrange[6][0]) / 2.0;            // mycobot.py:113-115
+  C.grip_center = (m->act_ctrlrange[6][1] + m->act_ctrlrange[6][0]) / 2.0;
+  memcpy(C.init_qpos, c->init_qpos, sizeof(C.init_qpos));
+  memcpy(C.init_qvel, c->init_qvel, sizeof(C.init_qvel));
+  memcpy(C.init_ctrl, c->init_ctrl, sizeof(C.init_ctrl));
+  C.seed = c->seed; C.env_id_offset = c->env_id_offset;
+  e->device = device;
+  e->view.n = C.n; e->view.nq = C.nq; e->view.nv = C.nv;
+  size_t nd = (size_t)state_doubles(C.nq, C.nv) * C.n;
+  hipError_t err = hipMalloc(&e->view.d, nd * sizeof(double));
+  if (err == hipSuccess) err = hipMalloc(&e->view.i32, (size_t)3 * C.n * sizeof(int32_t));
+  if (err == hipSuccess) err = hipMalloc(&e->d_model, sizeof(mcg_model));
+  if (err == hipSuccess) err = hipMemset(e->view.d, 0, nd * sizeof(double));
+  if (err == hipSuccess) err = hipMemset(e->view.i32, 0, (size_t)3 * C.n * sizeof(int32_t));
+  if (err == hipSuccess) err = hipMemcpy(e->d_model, m, sizeof(mcg_model), hipMemcpyHostToDevice);
+  if (err != hipSuccess) { mcg_destroy(e); return fail(MCG_ERR_HIP, "mcg_create: %s", hipGetErrorString(err)); }
+  *out = e;
+  return MCG_OK;
+}
+
+void mcg_destroy(mcg_env* e) {
+  if (!e) return;
+  (void)hipSetDevice(e->device);
+  if (e->view.d) (void)hipFree(e->view.d);
+  if (e->view.i32) (void)hipFree(e->view.i32);
+  if (e->d_model) (void)hipFree(e->d_model);
+  delete e;
+}
+
+int mcg_obs_dim(const mcg_env* e) { return e ? e->cfg.obs_dim : -1; }
+int mcg_action_dim(const mcg_env* e) { return e ? e->cfg.act_dim : -1; }
+int mcg_nq(const mcg_env* e) { return e ? e->cfg.nq : -1; }
+int mcg_nv(const mcg_env* e) { return e ? e->cfg.nv : -1; }
+
+static mcg_step_out out_or_empty(const mcg_step_out* o) { mcg_step_out z; memset(&z, 0, sizeof(z)); return o ? *o : z; }
+
+int mcg_reset(mcg_env* e, const uint8_t* mask, int reseed, uint64_t seed, const mcg_step_out* out, void* stream) {
+  if (!e) return fail(MCG_ERR_ARG, "mcg_reset: null handle%s");
+  if (reseed) e->cfg.seed = seed;
+  dim3 grid((e->cfg.n + 63) / 64), block(64);
+  hipLaunchKernelGGL(reset_reach_kernel, grid, block, 0, (hipStream_t)stream, e->cfg, e->view, e->d_model, mask, reseed, out_or_empty(out));
+  HIP_OK(hipGetLastError());
+  return MCG_OK;
+}
+
+static int launch_step(mcg_env* e, const float* actions, const mcg_step_out& o, hipStream_t s) {
+  dim3 grid((e->cfg.n + 63) / 64), block(64);
+  if (e->cfg.controller == MCG_CTRL_IK)
+    hipLaunchKernelGGL(step_reach_kernel<MCG_CTRL_IK>, grid, block, 0, s, e->cfg, e->view, e->d_model, actions, o);
+  else
+    hipLaunchKernelGGL(step_reach_kernel<MCG_CTRL_JOINT>, grid, block, 0, s, e->cfg, e->view, e->d_model, actions, o);
+  return hipGetLastError() == hipSuccess ? MCG_OK : MCG_ERR_HIP;
+}
+
+int mcg_step(mcg_env* e, const float* actions, const mcg_step_out* out, void* stream) {
+  if (!e || !actions) return fail(MCG_ERR_ARG, "mcg_step: null argument%s");
+  if (launch_step(e, actions, out_or_empty(out), (hipStream_t)stream) != MCG_OK) return fail(MCG_ERR_HIP, "mcg_step: launch failed: %s", hipGetErrorString(hipGetLastError()));
+  return MCG_OK;
+}
+
+int mcg_time_steps(mcg_env* e, const float* actions, const mcg_step_out* out, int steps, void* stream, float* ms_total) {
+  if (!e || !actions || !ms_total || steps <= 0) return fail(MCG_ERR_ARG, "mcg_time_steps: bad argument%s");
+  hipStream_t s = (hipStream_t)stream;
+  hipEvent_t t0, t1;
+  HIP_OK(hipEventCreate(&t0)); HIP_OK(hipEventCreate(&t1));
+  mcg_step_out o = out_or_empty(out);
+  HIP_OK(hipEventRecord(t0, s));
+  for (int k = 0; k < steps; k++) if (launch_step(e, actions, o, s) != MCG_OK) return fail(MCG_ERR_HIP, "mcg_time_steps: launch failed%s");
+  HIP_OK(hipEventRecord(t1, s));
+  HIP_OK(hipEventSynchronize(t1));
+  HIP_OK(hipEventElapsedTime(ms_total, t0, t1));
+  (void)hipEventDestroy(t0); (void)hipEventDestroy(t1);
+  return MCG_OK;
+}
+
+static int copy_state(mcg_env* e, const mcg_state* s, int to_engine, void* stream) {
+  if (!e || !s) return fail(MCG_ERR_ARG, "mcg_get/set_state: null argument%s");
+  dim3 grid((e->cfg.n + 255) / 256), block(256);
+  hipLaunchKernelGGL(copy_state_kernel, grid, block, 0, (hipStream_t)stream, e->view, *s, to_engine);
+  HIP_OK(hipGetLastError());
+  return MCG_OK;
+}
+int mcg_get_state(mcg_env* e, const mcg_state* dst, void* stream) { return copy_state(e, dst, 0, stream); }
+int mcg_set_state(mcg_env* e, const mcg_state* src, void* stream) { return copy_state(e, src, 1, stream); }
+
+int mcg_compute_reward(const double* achieved, const double* desired, int n, int reward_type, double threshold,
+                       double* out, void* stream) {
+  if (!achieved || !desired || !out || n < 0) return fail(MCG_ERR_ARG, "mcg_compute_reward: bad argument%s");
+  if (reward_type != MCG_REWARD_SPARSE && reward_type != MCG_REWARD_DENSE) return fail(MCG_ERR_UNSUPPORTED, "mcg_compute_reward: reward_shaping needs simulator state%s");
+  if (n == 0) return MCG_OK;
+  hipLaunchKernelGGL(reward_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, achieved, desired, n, reward_type, threshold, out);
+  HIP_OK(hipGetLastError());
+  return MCG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,206 @@
+"""Compiled-model table -> the numeric parameter block the HIP kernels consume (``mcg_model``).
+
+The kernels hard-code the *structure* of the MyCobot-280 scene (a 6-hinge arm whose joint axes
+are coordinate axes, a planar 6-hinge gripper hanging off link6 with two loop closures and one
+joint coupling, optionally one free cube) and read every *number* from this block, so model
+variants (legacy / exact mesh inertia, fetch keyframe, domain-randomised cube) share one binary.
+
+Joint-less bodies are welded into their nearest jointed ancestor (flange, camera frames,
+gripper_base, gripper_tcp -> link6; finger layers -> fingers), giving 12 moving bodies + cube:
+
+    0..5  link1..link6      6 right_gear   7 right_finger   8 left_gear   9 left_finger
+    10 right_hinge  11 left_hinge   (12 object0)
+
+All inertial data are expressed in the body's own frame about the body origin (= joint anchor):
+``mass``, ``mc`` = mass * com, ``inertia`` = (xx, yy, zz, xy, xz, yz) about the origin.
+The structural assumptions are asserted here so that a model that violates them fails loudly.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .mjcf import quat_to_mat
+from .refdyn import invweight0
+
+NB_ARM = 6
+NB_ROBOT = 12
+MOVING = ["link1", "link2", "link3", "link4", "link5", "link6", "right_gear_link", "right_finger_link",
+          "left_gear_link", "left_finger_link", "right_hinge_link", "left_hinge_link"]
+PARENT = [-1, 0, 1, 2, 3, 4, 5, 6, 5, 8, 5, 5]
+MINIMP, MAXIMP, MINVAL = 1e-4, 0.9999, 1e-15
+
+
+def _axis_code(ax):
+    k = int(np.argmax(np.abs(ax)))
+    assert abs(abs(ax[k]) - 1.0) < 1e-12, f"joint axis {ax} is not a coordinate axis"
+    return k, float(np.sign(ax[k]))
+
+
+def _solparams(solref, solimp, timestep):
+    """(K, B, d0, dmax, width, midpoint, power) with refsafe and the solimp clamps applied."""
+    tc, damp = float(solref[0]), float(solref[1])
+    d0, dmax, width, mid, power = [float(x) for x in solimp]
+    d0 = min(max(d0, MINIMP), MAXIMP); dmax = min(max(dmax, MINIMP), MAXIMP)
+    width = max(width, 0.0); mid = min(max(mid, MINIMP), MAXIMP); power = max(power, 1.0)
+    if tc > 0:
+        tc = max(tc, 2 * timestep)
+        K = 1.0 / max(MINVAL, dmax * dmax * tc * tc * damp * damp)
+        B = 2.0 / max(MINVAL, dmax * tc)
+    else:
+        K = -tc / max(MINVAL, dmax * dmax)
+        B = -damp / max(MINVAL, dmax)
+    return [K, B, d0, dmax, width, mid, power]
+
+
+def mix_contact(m, g1, g2):
+    """[RECALL mj_contactParam] pair parameters of two geoms with equal priority and solmix."""
+    condim = max(m["geom_condim"][g1], m["geom_condim"][g2])
+    f = np.maximum(np.asarray(m["geom_friction"][g1]), np.asarray(m["geom_friction"][g2]))
+    r1, r2 = np.asarray(m["geom_solref"][g1]), np.asarray(m["geom_solref"][g2])
+    solref = 0.5 * (r1 + r2) if (r1[0] > 0 and r2[0] > 0) else np.minimum(r1, r2)
+    solimp = 0.5 * (np.asarray(m["geom_solimp"][g1]) + np.asarray(m["geom_solimp"][g2]))
+    return condim, [f[0], f[0], f[1], f[2], f[2]], solref, solimp
+
+
+def specialize(m: dict) -> dict:
+    """m: table from ``load_model`` (full scene; the cube may have been dropped)."""
+    name2id = {n: i for i, n in enumerate(m["body_name"])}
+    has_cube = "object0" in name2id
+    ids = [name2id[n] for n in MOVING] + ([name2id["object0"]] if has_cube else [])
+    nb = len(ids)
+    h = m["opt"]["timestep"]
+    out = {"has_cube": has_cube, "timestep": h}
+
+    # --- base (static) frame
+    base = name2id["mycobot"]
+    assert m["body_parent"][base] == 0 and m["body_dofnum"][base] == 0
+    Rb = quat_to_mat(np.asarray(m["body_quat"][base]))
+    out["base_pos"] = np.asarray(m["body_pos"][base], dtype=float)
+    out["base_mat"] = Rb
+    out["gravity_base"] = Rb.T @ (-np.asarray(m["opt"]["gravity"], dtype=float))
+
+    # --- weld joint-less descendants into each moving body
+    def fixed_children(b):
+        return [c for c in range(m["nbody"]) if m["body_parent"][c] == b and m["body_dofnum"][c] == 0]
+
+    r = np.zeros((13, 3)); mass = np.zeros(13); mc = np.zeros((13, 3)); inertia = np.zeros((13, 6))
+    axis_k = []; axis_s = []
+    weld_frames = {}   # body id -> (root index, R, p) of every body welded into a moving body
+    for i, b in enumerate(ids):
+        free = m["body_dofnum"][b] == 6
+        if not free:
+            j = [jj for jj in range(m["njnt"]) if m["jnt_body"][jj] == b]
+            assert len(j) == 1 and np.allclose(m["jnt_pos"][j[0]], 0), "hinge anchored at the body origin expected"
+            k, s = _axis_code(np.asarray(m["jnt_axis"][j[0]])); axis_k.append(k); axis_s.append(s)
+            assert np.allclose(m["body_quat"][b], [1, 0, 0, 0]), "moving bodies are expected to have identity quat"
+        # origin in the parent moving body's frame (walk up through joint-less bodies)
+        p = m["body_parent"][b]; off = np.asarray(m["body_pos"][b], dtype=float)
+        while p != 0 and m["body_dofnum"][p] == 0 and p != base:
+            assert np.allclose(m["body_quat"][p], [1, 0, 0, 0])
+            off = off + np.asarray(m["body_pos"][p]); p = m["body_parent"][p]
+        if i < NB_ROBOT:
+            expect = base if PARENT[i] < 0 else ids[PARENT[i]]
+            assert p == expect, f"{m['body_name'][b]}: unexpected tree structure"
+        r[i] = off
+        # composite of b and its welded descendants
+        stack = [(b, np.eye(3), np.zeros(3))]
+        I = np.zeros((3, 3))
+        while stack:
+            k_, R, pos = stack.pop()
+            weld_frames[k_] = (i, R, pos)
+            mk = m["body_mass"][k_]
+            if mk > 0:
+                c = pos + R @ np.asarray(m["body_ipos"][k_])
+                Rc = R @ quat_to_mat(np.asarray(m["body_iquat"][k_]))
+                Ic = Rc @ np.diag(np.asarray(m["body_inertia"][k_])) @ Rc.T
+                mass[i] += mk; mc[i] += mk * c
+                I += Ic + mk * (c @ c * np.eye(3) - np.outer(c, c))
+            for ch in fixed_children(k_):
+                Rch = R @ quat_to_mat(np.asarray(m["body_quat"][ch]))
+                stack.append((ch, Rch, pos + R @ np.asarray(m["body_pos"][ch])))
+        inertia[i] = [I[0, 0], I[1, 1], I[2, 2], I[0, 1], I[0, 2], I[1, 2]]
+    out.update(r=r, mass=mass, mc=mc, inertia=inertia, axis_k=axis_k, axis_s=axis_s)
+    # structural facts the kernels rely on
+    assert [axis_k[i] for i in range(6, 12)] == [1] * 6, "gripper joints must all turn about local y"
+
+    # --- dofs
+    nv = m["nv"]
+    arm = np.zeros(18); damp = np.zeros(18)
+    arm[:nv] = m["dof_armature"]; damp[:nv] = m["dof_damping"]
+    out["armature"] = arm; out["damping"] = damp
+    rng = np.zeros((12, 2)); limited = []
+    lim_par = np.zeros((12, 7))
+    for i in range(12):
+        j = [jj for jj in range(m["njnt"]) if m["jnt_body"][jj] == ids[i]][0]
+        assert m["jnt_dofadr"][j] == i and m["jnt_qposadr"][j] == i
+        limited.append(bool(m["jnt_limited"][j])); rng[i] = m["jnt_range"][j]
+        lim_par[i] = _solparams(m["jnt_solref"][j], m["jnt_solimp"][j], h)
+    assert limited == [True] * 10 + [False] * 2, "joints 0-9 limited, the two couplers unlimited"
+    out["jnt_range"] = rng; out["limit_par"] = lim_par
+
+    # --- inverse weights at qpos0 (constraint regularisation)
+    biw, diw = invweight0(m)
+    out["limit_diag"] = np.concatenate([diw[:12]])
+
+    # --- equalities: connect(right_finger, right_hinge), connect(left_finger, left_hinge), joint(gear R = gear L)
+    eq = m["eq"]
+    assert [e["type"] for e in eq[:3]] == [0, 0, 2]
+    assert (eq[0]["obj1"], eq[0]["obj2"]) == (ids[7], ids[10]) and (eq[1]["obj1"], eq[1]["obj2"]) == (ids[9], ids[11])
+    assert (eq[2]["obj1"], eq[2]["obj2"]) == (6, 8) and np.allclose(eq[2]["data"][:5], [0, 1, 0, 0, 0])
+    out["eq_anchor1"] = np.array([eq[0]["data"][0:3], eq[1]["data"][0:3]])
+    out["eq_anchor2"] = np.array([eq[0]["data"][3:6], eq[1]["data"][3:6]])
+    out["eq_par"] = np.array([_solparams(e["solref"], e["solimp"], h) for e in eq[:3]])
+    out["eq_diag"] = np.array([biw[ids[7], 0] + biw[ids[10], 0], biw[ids[9], 0] + biw[ids[11], 0], diw[6] + diw[8]])
+
+    # --- actuators: 6 joint servos + tendon servo over (gear R, gear L)
+    acts = m["actuators"]
+    assert len(acts) == 7 and [a["trntype"] for a in acts] == ["joint"] * 6 + ["tendon"]
+    assert [a["trnid"] for a in acts[:6]] == list(range(6)) and all(a["gear"] == 1 for a in acts)
+    ten = m["tendons"][acts[6]["trnid"]]
+    assert ten["joints"] == [6, 8]
+    out["act_gain"] = np.array([a["gainprm"][0] for a in acts])
+    out["act_bias"] = np.array([a["biasprm"] for a in acts])
+    assert all(a["ctrllimited"] and a["forcelimited"] for a in acts)
+    out["act_ctrlrange"] = np.array([a["ctrlrange"] for a in acts])
+    out["act_forcerange"] = np.array([a["forcerange"] for a in acts])
+    out["tendon_coef"] = np.array(ten["coefs"])
+
+    # --- sites
+    s = m["site_name"].index("EEF")
+    i6, R, p = weld_frames[m["site_body"][s]]
+    assert i6 == 5 and np.allclose(R, np.eye(3)) and np.allclose(m["site_quat"][s], [1, 0, 0, 0])
+    out["site_eef"] = p + np.asarray(m["site_pos"][s])
+
+    # --- contact geometry of the PickAndPlace scene: cube, table top, finger pads
+    if has_cube:
+        gname = {n: i for i, n in enumerate(m["geom_name"]) if n}
+        gc, gr, gl = gname["object0"], gname["right_finger_layer"], gname["left_finger_layer"]
+        gt = [g for g in range(m["ngeom"]) if m["body_name"][m["geom_body"][g]] == "table"][0]
+        out["cube_half"] = np.asarray(m["geom_size"][gc], dtype=float)
+        tb = m["geom_body"][gt]
+        out["table_pos"] = np.asarray(m["body_pos"][tb]) + np.asarray(m["geom_pos"][gt])
+        out["table_half"] = np.asarray(m["geom_size"][gt], dtype=float)
+        pads = []
+        for g, fing in ((gr, 7), (gl, 9)):
+            root, R, p = weld_frames[m["geom_body"][g]]
+            assert root == fing and np.allclose(R, np.eye(3)) and np.allclose(m["geom_quat"][g], [1, 0, 0, 0])
+            pads.append(np.concatenate([p + np.asarray(m["geom_pos"][g]), np.asarray(m["geom_size"][g])]))
+        out["pad_box"] = np.array(pads)      # centre (finger frame) | half sizes
+        cp = []
+        for (ga, gb) in ((gt, gc), (gr, gc), (gl, gc)):
+            condim, fri, solref, solimp = mix_contact(m, ga, gb)
+            assert condim == 4
+            cp.append(np.concatenate([_solparams(solref, solimp, h), fri]))
+        out["contact_par"] = np.array(cp)    # rows: table-cube, right pad-cube, left pad-cube
+        bt = lambda g: biw[m["geom_body"][g]]
+        out["contact_diag"] = np.array([[bt(ga)[0] + bt(gc)[0], bt(ga)[1] + bt(gc)[1]] for ga in (gt, gr, gl)])
+        out["cube_invweight"] = np.array([diw[12], diw[15]])
+        out["geom_ids"] = {"table": gt, "cube": gc, "pad_r": gr, "pad_l": gl}
+    return out
+
+
+def initial_gripper_xpos(m: dict, qpos) -> np.ndarray:
+    """EEF site position at ``qpos`` (reference ``_env_setup``, mycobot.py:464-466)."""
+    from .refdyn import kinematics
+    kin = kinematics(m, qpos)
+    return kin["site_xpos"][m["site_name"].index("EEF")].copy()

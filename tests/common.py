@@ -1,0 +1,84 @@
+"""Shared helpers of the parity tests: build the HIP env and the CPU oracle with one configuration."""
+from __future__ import annotations
+
+import json
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ASSETS = os.path.join(ROOT, "mycobotgym_amd", "assets")
+
+
+def table_name(has_object=False, mesh_inertia="legacy"):
+    return "mycobot280" + ("" if has_object else "_reach") + ("_exactmesh" if mesh_inertia == "exact" else "")
+
+
+def load_json(name):
+    with open(os.path.join(ASSETS, name + ".json")) as f:
+        return json.load(f)
+
+
+def make_oracle(n, has_object=False, controller_type="joint", fetch_env=False, reward_type="dense", seed=0,
+                env_id_offset=0, mesh_inertia="legacy", frame_skip=20, control_steps=5, max_episode_steps=50,
+                target_in_the_air=True, distance_threshold=0.01, auto_reset=True, n_threads=None):
+    from oracle import pyoracle as po
+    from mycobotgym_amd.vec_env import initial_state
+    tab = load_json(table_name(has_object, mesh_inertia))
+    model = po.OracleModel(tab, enable_contact=has_object)
+    qpos, qvel, ctrl, igx, height = initial_state(has_object, fetch_env, mesh_inertia)
+    cfg = po.EnvConfig()
+    cfg.n_envs = n; cfg.has_object = int(has_object)
+    cfg.controller = {"joint": 0, "IK": 1}[controller_type]; cfg.fetch_env = int(fetch_env)
+    cfg.reward_type = {"sparse": 0, "dense": 1, "reward_shaping": 2}[reward_type]
+    cfg.frame_skip = frame_skip; cfg.control_steps = control_steps; cfg.max_episode_steps = max_episode_steps
+    cfg.target_in_the_air = int(target_in_the_air); cfg.auto_reset = int(auto_reset)
+    cfg.eef_site = tab["site_name"].index("EEF")
+    cfg.obj_site = tab["site_name"].index("object0") if has_object else -1
+    cfg.obj_jnt = tab["jnt_name"].index("object0:joint") if has_object else -1
+    cfg.grip_jnt[0] = tab["jnt_name"].index("robot0:right_gear_joint")
+    cfg.grip_jnt[1] = tab["jnt_name"].index("robot0:left_gear_joint")
+    cfg.n_threads = n_threads or min(os.cpu_count() or 1, 16)
+    cfg.pad_geom[0] = cfg.pad_geom[1] = cfg.obj_geom = -1
+    cfg.distance_threshold = distance_threshold; cfg.height_offset = height
+    for k, v in enumerate(qpos): cfg.init_qpos[k] = v
+    for k, v in enumerate(qvel): cfg.init_qvel[k] = v
+    for k, v in enumerate(ctrl): cfg.init_ctrl[k] = v
+    cfg.seed = seed; cfg.env_id_offset = env_id_offset
+    return po.OracleEnvs(model, cfg)
+
+
+def make_pair(n, device="cuda:0", **kw):
+    from mycobotgym_amd import MyCobotVecEnv
+    okw = dict(kw)
+    envs = MyCobotVecEnv(n, device=device, has_object=kw.pop("has_object", False), **kw)
+    ora = make_oracle(n, **okw)
+    return envs, ora
+
+
+def sync_oracle_to(envs, ora):
+    """Copy the oracle's state into the HIP engine (both then continue from identical state)."""
+    s = ora.get_state()
+    envs.set_state(qpos=s["qpos"].T.copy(), qvel=s["qvel"].T.copy(), ctrl=s["ctrl"].T.copy(), warm=s["warm"].T.copy(),
+                   qpos_lag=s["qpos_lag"].T.copy(), goal=s["goal"].T.copy(), elapsed=s["elapsed"], episode=s["episode"])
+
+
+def compare_step(envs, ora, actions, keys=("obs", "achieved", "desired", "reward")):
+    """Step both with the same float32 actions; return the max abs error over obs / goals / reward and assert
+    that the integer outputs agree exactly."""
+    import torch
+    obs, rew, term, trunc, info = envs.step(torch.as_tensor(actions))
+    o = ora.step(actions)
+    got = {"obs": obs["observation"], "achieved": obs["achieved_goal"], "desired": obs["desired_goal"], "reward": rew}
+    err = 0.0
+    for k in keys:
+        err = max(err, float(np.abs(got[k].cpu().numpy() - o[k]).max()))
+    assert np.array_equal(term.cpu().numpy(), o["terminated"].astype(bool))
+    assert np.array_equal(trunc.cpu().numpy(), o["truncated"].astype(bool))
+    assert np.array_equal(info["is_success"].cpu().numpy(), o["is_success"].astype(bool))
+    done = o["terminated"].astype(bool) | o["truncated"].astype(bool)
+    if done.any():
+        f = info["final_observation"]
+        err = max(err, float(np.abs(f["observation"].cpu().numpy()[done] - o["final_obs"][done]).max()))
+        assert np.array_equal(info["episode"]["l"].cpu().numpy()[done], o["ep_length"][done])
+    return err
