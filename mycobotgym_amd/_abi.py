@@ -50,7 +50,7 @@ class McgModel(C.Structure):
                 continue                       # cube fields of a Reach-only table stay zero
             v = np.ascontiguousarray(np.asarray(spec[name], dtype=np.float64))
             if ctype is d:
-                setattr(m, name, float(v))
+                setattr(m, name, float(v.reshape(-1)[0]))
             else:
                 dst = np.ctypeslib.as_array(getattr(m, name))
                 dst[...] = v.reshape(dst.shape)

@@ -70,10 +70,11 @@ __device__ void sample_goal(const Cfg& C, int i, Env& E, real* g) {
   real ux, uy, uc, uz;
   rng_pair(C, i, E, 0, ux, uy);
   rng_pair(C, i, E, 0, uc, uz);
-  g[0] = -0.12 + (0.12 - -0.12) * ux;
-  g[1] = -0.06 + (0.06 - -0.06) * uy;
+  // a + (b - a) * u as one explicit fma: rounds identically on the CPU oracle and here
+  g[0] = fma(0.12 - -0.12, ux, -0.12);
+  g[1] = fma(0.06 - -0.06, uy, -0.06);
   g[2] = C.height_offset;
-  if (C.target_in_the_air && uc < 0.5) g[2] += 0.0 + (0.1 - 0.0) * uz;
+  if (C.target_in_the_air && uc < 0.5) g[2] = fma(0.1 - 0.0, uz, C.height_offset);
 }
 
 // reset_model (mycobot.py:207-236), Reach: the object position stays the initial gripper xy

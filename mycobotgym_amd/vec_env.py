@@ -65,7 +65,7 @@ class MyCobotVecEnv:
                  frame_skip: int = 20, max_episode_steps: int = MAX_EPISODE_STEPS, device="cuda:0", seed: int = 0,
                  env_id_offset: int = 0, auto_reset: bool = True, mesh_inertia: str = "legacy",
                  domain_randomization: Optional[dict] = None, model_path: Optional[str] = None,
-                 image_obs: bool = False, **unused):
+                 image_obs: bool = False, model: Optional["_abi.McgModel"] = None, **unused):
         if image_obs:
             raise NotImplementedError("image observations (-v1 ids, MyCobotImgEnv) need a rasteriser: out of scope")
         if controller_type == "mocap":
@@ -113,8 +113,9 @@ class MyCobotVecEnv:
             cfg.dr_friction_range[0], cfg.dr_friction_range[1] = domain_randomization.get("friction", (1.0, 1.0))
         cfg.seed = int(seed) & (2 ** 64 - 1); cfg.env_id_offset = int(env_id_offset)
         self._cfg = cfg
-        model = _abi.McgModel()
-        _abi.check(self._lib.mcg_default_model(1 if mesh_inertia == "exact" else 0, C.byref(model)), "mcg_default_model")
+        if model is None:     # built-in block; a caller-supplied mcg_model (tests, custom robots) overrides it
+            model = _abi.McgModel()
+            _abi.check(self._lib.mcg_default_model(1 if mesh_inertia == "exact" else 0, C.byref(model)), "mcg_default_model")
         self._model = model
         self._h = C.c_void_p()
         dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()

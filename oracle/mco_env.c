@@ -79,10 +79,12 @@ static void sample_goal(const mco_envs* e, int i, env_t* v, double g[3]) {     /
   double ux, uy, uc, uz;
   rng_pair(e, i, v, 0, &ux, &uy);
   rng_pair(e, i, v, 0, &uc, &uz);
-  g[0] = -0.12 + (0.12 - -0.12) * ux;          /* random.uniform(a, b) = a + (b - a) * random() */
-  g[1] = -0.06 + (0.06 - -0.06) * uy;
+  /* random.uniform(a, b) = a + (b - a) * random(); written as one fused multiply-add so that the CPU oracle and
+     the GPU kernel round identically (the reference's own draws are not reproducible anyway, Appendix D-6) */
+  g[0] = fma(0.12 - -0.12, ux, -0.12);
+  g[1] = fma(0.06 - -0.06, uy, -0.06);
   g[2] = e->cfg.height_offset;
-  if (e->cfg.target_in_the_air && uc < 0.5) g[2] += 0.0 + (0.1 - 0.0) * uz;
+  if (e->cfg.target_in_the_air && uc < 0.5) g[2] = fma(0.1 - 0.0, uz, e->cfg.height_offset);
 }
 
 static void domain_randomise(mco_envs* e, int i, env_t* v);

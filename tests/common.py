@@ -19,12 +19,21 @@ def load_json(name):
         return json.load(f)
 
 
+def soften_gains(tab, scale=0.1):
+    """A contractive variant of the model: actuator velocity gains scaled so that h*kv/M < 1 (the reference's own
+    gains make explicit Euler an unstable map, see DESIGN.md 'Parity and chaos').  Test-only."""
+    tab = json.loads(json.dumps(tab))
+    for a in tab["actuators"]:
+        a["biasprm"][2] *= scale
+    return tab
+
+
 def make_oracle(n, has_object=False, controller_type="joint", fetch_env=False, reward_type="dense", seed=0,
                 env_id_offset=0, mesh_inertia="legacy", frame_skip=20, control_steps=5, max_episode_steps=50,
-                target_in_the_air=True, distance_threshold=0.01, auto_reset=True, n_threads=None):
+                target_in_the_air=True, distance_threshold=0.01, auto_reset=True, n_threads=None, table=None):
     from oracle import pyoracle as po
     from mycobotgym_amd.vec_env import initial_state
-    tab = load_json(table_name(has_object, mesh_inertia))
+    tab = table if table is not None else load_json(table_name(has_object, mesh_inertia))
     model = po.OracleModel(tab, enable_contact=has_object)
     qpos, qvel, ctrl, igx, height = initial_state(has_object, fetch_env, mesh_inertia)
     cfg = po.EnvConfig()
@@ -48,12 +57,32 @@ def make_oracle(n, has_object=False, controller_type="joint", fetch_env=False, r
     return po.OracleEnvs(model, cfg)
 
 
-def make_pair(n, device="cuda:0", **kw):
+def make_pair(n, device="cuda:0", table=None, **kw):
+    """HIP engine + CPU oracle with one configuration.  `table`: optional modified model table for both."""
     from mycobotgym_amd import MyCobotVecEnv
     okw = dict(kw)
-    envs = MyCobotVecEnv(n, device=device, has_object=kw.pop("has_object", False), **kw)
-    ora = make_oracle(n, **okw)
+    model = None
+    if table is not None:
+        from mycobotgym_amd._abi import McgModel
+        from mycobotgym_amd.model.mjcf import _np_model
+        from mycobotgym_amd.model.specialize import specialize
+        model = McgModel.from_spec(specialize(_np_model(table)))
+    envs = MyCobotVecEnv(n, device=device, has_object=kw.pop("has_object", False), model=model, **kw)
+    ora = make_oracle(n, table=table, **okw)
     return envs, ora
+
+
+def step_errors(envs, ora, actions):
+    """Step both; per-env max abs error over observation / achieved goal / reward, plus the oracle outputs."""
+    import torch
+    obs, rew, term, trunc, info = envs.step(torch.as_tensor(actions))
+    o = ora.step(actions)
+    e = np.abs(obs["observation"].cpu().numpy() - o["obs"]).max(axis=1)
+    e = np.maximum(e, np.abs(obs["achieved_goal"].cpu().numpy() - o["achieved"]).max(axis=1))
+    e = np.maximum(e, np.abs(rew.cpu().numpy() - o["reward"]))
+    flags_equal = (np.array_equal(term.cpu().numpy(), o["terminated"].astype(bool))
+                   and np.array_equal(trunc.cpu().numpy(), o["truncated"].astype(bool)))
+    return e, flags_equal, o
 
 
 def sync_oracle_to(envs, ora):
