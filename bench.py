@@ -1,0 +1,161 @@
+#!/usr/bin/env python3
+"""bench.py -- env-steps/sec of the MyCobot Reach rollout hot path on N MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 1000 --warmup 100
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one env.step() of every environment (one launch of the fused step kernel = controller + 20 physics
+sub-steps + observation + reward + termination + TimeLimit + auto-reset).  Workload = BASELINE.json configs[1]:
+Reach, 8192 envs per GPU, free-space dynamics, `joint` controller (SURVEY 8(d) "Config 2", primary), dense reward,
+actions ~ U(-1,1) float32 already resident in HBM, auto-reset on.  Weak scaling: every rank owns 8192 envs keyed by
+global env id; there is no collective on the step path (RCCL is used once, after the timed region, to reduce the
+episode statistics for logging).  The IK controller (100 sub-steps per step) is reported as a secondary figure.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+N_ENVS_PER_GPU = 8192
+# Algorithmic (compulsory) HBM bytes per env-step, SURVEY.md 8(d): Reach with the cube's state dropped:
+# B = 2*S + A + O, S = 46 doubles + counters, A = 28 B, O = 135 B  ->  939 B.   (DESIGN.md "Bytes per env-step")
+BYTES_PER_ENV_STEP = 939
+HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
+FP64_VECTOR_PEAK_TFLOPS = 78.6  # [RECALL, AMD datasheet]; the guide lists no FP64 vector figure
+
+
+def cpu_baseline(controller: str, budget_envs: int, steps: int):
+    """The CPU oracle (kind "port": this repo's C restatement, NOT MuJoCo) on all host cores, bounded sample."""
+    import numpy as np
+    from tests.common import make_oracle
+    cores = os.cpu_count() or 1
+    ora = make_oracle(budget_envs, controller_type=controller, reward_type="dense", seed=0, n_threads=cores)
+    ora.reset(seed=0)
+    rng = np.random.default_rng(0)
+    acts = [rng.uniform(-1, 1, (budget_envs, ora.act_dim)).astype(np.float32) for _ in range(4)]
+    ora.step(acts[0])
+    t0 = time.perf_counter()
+    for t in range(steps):
+        ora.step(acts[t % 4])
+    dt = time.perf_counter() - t0
+    return {"value": budget_envs * steps / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": f"{budget_envs} envs x {steps} steps, Reach/{controller}, OpenMP over envs, {dt:.1f}s wall; "
+                      "this repo's C float64 restatement, not MuJoCo (unavailable offline)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--controller", default="joint", choices=["joint", "IK"])
+    ap.add_argument("--envs-per-gpu", type=int, default=N_ENVS_PER_GPU)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    dev = torch.device("cuda", local_rank)
+    from mycobotgym_amd import MyCobotVecEnv
+
+    n = args.envs_per_gpu
+    K, W = args.steps, args.warmup
+
+    def run(controller, steps, warmup):
+        envs = MyCobotVecEnv(n, has_object=False, controller_type=controller, reward_type="dense", device=dev,
+                             seed=0, env_id_offset=rank * n)
+        envs.reset(seed=0)
+        g = torch.Generator(device=dev); g.manual_seed(1234 + rank)
+        pool = torch.rand(16, n, envs.action_dim, device=dev, generator=g) * 2 - 1     # resident action batches
+        for t in range(warmup):
+            envs.step_async(pool[t % 16])
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for t in range(steps):
+            envs.step_async(pool[t % 16])
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        # kernel-only duration on the launch stream with HIP events (roofline leg)
+        ms = envs.time_steps(pool[0], min(steps, 200))
+        kernel_ms = ms / min(steps, 200)
+        # logging path: episode statistics reduced over ranks with RCCL, off the timed region
+        b = envs._buf
+        stats = torch.stack([b["ep_return"].sum(), b["ep_length"].double().sum(), b["is_success"].double().sum()])
+        if world > 1:
+            dist.all_reduce(stats, op=dist.ReduceOp.SUM)
+        envs.close()
+        return dt, kernel_ms, stats.tolist()
+
+    dt, kernel_ms, stats = run(args.controller, K, W)
+    total_envs = n * world
+    value = total_envs * K / dt
+    substeps = 20 if args.controller == "joint" else 100
+    out = {
+        "metric": "env-steps/sec (whole node), MyCobot Reach, N_envs=8192/GPU",
+        "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
+        "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"MyCobot Reach, {n} envs/GPU, no contacts (free-space dynamics), controller={args.controller}, "
+                               f"{substeps} physics sub-steps per env-step, dense reward, auto-reset, TimeLimit 50",
+                   "envs_per_gpu": n, "total_envs": total_envs, "controller": args.controller,
+                   "parallelism": f"env-sharded x{world}, no step-path collective"},
+        "physics_substeps_per_sec": value * substeps,
+    }
+    if rank == 0:
+        algo_bytes = BYTES_PER_ENV_STEP * n
+        achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
+        traffic = None; src = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
+        if os.path.exists(pmc):
+            with open(pmc) as f:
+                pj = json.load(f)
+            if pj.get("controller") == args.controller and pj.get("n_envs") == n:
+                traffic = pj.get("hbm_bytes_per_launch"); src = "profiles/pmc_latest.json: " + pj.get("note", "")
+        out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                           "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": src,
+                           "kernel": "step_reach_kernel", "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": algo_bytes,
+                           "note": "nominal roofline only: with all sub-steps fused the path moves ~1 KB per env-step and is "
+                                   "bound by dependent FP64 VALU issue, not by HBM (SURVEY 8(d)); see DESIGN.md"}
+        if not args.no_secondary and world == 1:
+            other = "IK" if args.controller == "joint" else "joint"
+            dt2, k2, _ = run(other, max(K // 5, 20), max(W // 5, 5))
+            out["secondary"] = {"controller": other, "env_steps_per_sec": n * max(K // 5, 20) / dt2, "kernel_ms": k2,
+                                "physics_substeps_per_sec": n * max(K // 5, 20) / dt2 * (100 if other == "IK" else 20)}
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args.controller, 2048, 20)
+        out["episode_stats"] = {"sum_return": stats[0], "sum_length": stats[1], "sum_success": stats[2]}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -40,23 +40,29 @@ enum { MCG_REWARD_SPARSE = 0, MCG_REWARD_DENSE = 1, MCG_REWARD_SHAPING = 2 };
 
 /* Numeric model block (produced by mycobotgym_amd/model/specialize.py from the compiled MJCF).
    13 bodies: link1..6, right gear/finger, left gear/finger, right/left hinge, cube. */
+typedef struct mcg_body {          /* 16 doubles = 128 B: one body's constants, contiguous for wide scalar loads */
+  double r[3];                      /* body origin in its parent's frame */
+  double mass, mc[3];               /* mass, mass * centre of mass (body frame, about the origin) */
+  double inertia[6];                /* xx yy zz xy xz yz about the body origin */
+  double armature, damping;         /* of the body's hinge (cube: unused, see cube_damping) */
+  double pad;
+} mcg_body;
+
 typedef struct mcg_model {
   double timestep;
   double base_pos[3], base_mat[9], gravity_base[3];
-  double r[13][3];                  /* body origin in its parent's frame */
-  double mass[13], mc[13][3];       /* mass, mass * centre of mass (body frame, about the origin) */
-  double inertia[13][6];            /* xx yy zz xy xz yz about the body origin */
-  double armature[18], damping[18];
+  mcg_body body[13];
+  double cube_damping[6];
   double jnt_range[12][2];
-  double limit_par[12][7];          /* K B d0 dmax width midpoint power (refsafe applied) */
+  double limit_par[12][10];         /* K B d0 dmax width midpoint power 1/width 1/mid^(p-1) 1/(1-mid)^(p-1); refsafe applied */
   double limit_diag[12];            /* dof_invweight0 */
   double eq_anchor1[2][3], eq_anchor2[2][3];
-  double eq_par[3][7], eq_diag[3];  /* connect right, connect left, joint coupling */
+  double eq_par[3][10], eq_diag[3];  /* connect right, connect left, joint coupling */
   double act_gain[7], act_bias[7][3], act_ctrlrange[7][2], act_forcerange[7][2], tendon_coef[2];
   double site_eef[3];               /* EEF site in the link6 frame */
   /* PickAndPlace only */
   double cube_half[3], table_pos[3], table_half[3], pad_box[2][6];
-  double contact_par[3][12];        /* table-cube, right pad-cube, left pad-cube: K B d0 dmax width mid power | friction[5] */
+  double contact_par[3][15];        /* table-cube, right pad-cube, left pad-cube: the 10 solver numbers | friction[5] */
   double contact_diag[3][2];        /* summed body_invweight0 (translational, rotational) */
 } mcg_model;
 

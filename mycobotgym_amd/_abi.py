@@ -20,24 +20,26 @@ REWARD_SPARSE, REWARD_DENSE, REWARD_SHAPING = 0, 1, 2
 d = C.c_double
 
 
+class McgBody(C.Structure):
+    _fields_ = [("r", d * 3), ("mass", d), ("mc", d * 3), ("inertia", d * 6), ("armature", d), ("damping", d), ("pad", d)]
+
+
 class McgModel(C.Structure):
     _fields_ = [
         ("timestep", d),
         ("base_pos", d * 3), ("base_mat", d * 9), ("gravity_base", d * 3),
-        ("r", (d * 3) * 13),
-        ("mass", d * 13), ("mc", (d * 3) * 13),
-        ("inertia", (d * 6) * 13),
-        ("armature", d * 18), ("damping", d * 18),
+        ("body", (d * 16) * 13),          # mcg_body[13], see McgBody for the layout of one row
+        ("cube_damping", d * 6),
         ("jnt_range", (d * 2) * 12),
-        ("limit_par", (d * 7) * 12),
+        ("limit_par", (d * 10) * 12),
         ("limit_diag", d * 12),
         ("eq_anchor1", (d * 3) * 2), ("eq_anchor2", (d * 3) * 2),
-        ("eq_par", (d * 7) * 3), ("eq_diag", d * 3),
+        ("eq_par", (d * 10) * 3), ("eq_diag", d * 3),
         ("act_gain", d * 7), ("act_bias", (d * 3) * 7), ("act_ctrlrange", (d * 2) * 7),
         ("act_forcerange", (d * 2) * 7), ("tendon_coef", d * 2),
         ("site_eef", d * 3),
         ("cube_half", d * 3), ("table_pos", d * 3), ("table_half", d * 3), ("pad_box", (d * 6) * 2),
-        ("contact_par", (d * 12) * 3),
+        ("contact_par", (d * 15) * 3),
         ("contact_diag", (d * 2) * 3),
     ]
 

@@ -83,27 +83,156 @@ MCG_DEV void sym_rot_up(real c, real s, real* I) {
   I[iKB] = s * ka + c * kb;
 }
 
-// Impedance sigmoid (MuJoCo getimpedance [RECALL]); par = K B d0 dmax width midpoint power
+// Uniform-pointer laundering: hides the model pointer from loop-invariant code motion so that the (wave-uniform,
+// scalar) loads of model constants stay next to their uses instead of being hoisted out of the sub-step loop and
+// spilled -- with one wave per SIMD every spilled SGPR costs two issue slots (v_writelane / v_readlane).
+// The pointer is carried in the constant address space (4) so that these reads are emitted as s_load.
+typedef const __attribute__((address_space(4))) mcg_model* ModelPtr;
+typedef const __attribute__((address_space(4))) real* CRealPtr;
+MCG_DEV ModelPtr as_model_ptr(const mcg_model* p) { return (ModelPtr)p; }
+MCG_DEV ModelPtr launder(ModelPtr p) { asm volatile("" : "+s"(p)); return p; }
+// Scheduling fence between body blocks / stages: without it the machine scheduler clusters the scalar loads of a
+// whole unrolled pass at the top of the (several-thousand-instruction) block and spills hundreds of SGPRs.
+#define MCG_FENCE() __builtin_amdgcn_sched_barrier(0)
+// ... and instruction selection would still sink a block's arithmetic below the following blocks' loads.  Pinning a
+// block's results through an empty volatile asm orders "everything they depend on" before the next block's loads.
+MCG_DEV void pin(real& a) { asm volatile("" : "+v"(a)); }
+MCG_DEV void pin3(real* v) { asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2])); }
+MCG_DEV void pin6(real* v) { asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5])); }
+template <int N> MCG_DEV void ldc(CRealPtr src, real* dst) { for (int k = 0; k < N; k++) dst[k] = src[k]; }
+struct BodyC { real r[3], mass, mc[3], inertia[6], armature, damping; };
+MCG_DEV BodyC load_body(ModelPtr P, int i) {
+  BodyC b;
+  ldc<3>(P->body[i].r, b.r); b.mass = P->body[i].mass; ldc<3>(P->body[i].mc, b.mc); ldc<6>(P->body[i].inertia, b.inertia);
+  b.armature = P->body[i].armature; b.damping = P->body[i].damping;
+  return b;
+}
+
+// 1/d to full double precision: v_rcp_f64 seed + two Newton steps (5 issue slots instead of the ~12 of an IEEE fdiv)
+MCG_DEV real rcp_nr(real d) {
+  real y = __builtin_amdgcn_rcp(d);
+  real e = fma(-d, y, 1.0); y = fma(y, e, y);
+  e = fma(-d, y, 1.0); y = fma(y, e, y);
+  return y;
+}
+
+// sin and cos for |x| up to a few turns (joint angles): Cody-Waite reduction by pi/2 in two pieces and the fdlibm
+// kernel polynomials on [-pi/4, pi/4]; branch-free, ~30 issue slots, < 1 ulp.
+struct TrigC { real t[16]; };
+__constant__ const real kTrig[16] = {
+    6.36619772367581382433e-01, 1.57079632673412561417e+00, 6.07710050650619224932e-11,          // 2/pi, pio2_1, pio2_1t
+    1.58969099521155010221e-10, -2.50507602534068634195e-08, 2.75573137070700676789e-06,         // S6 .. S1
+    -1.98412698298579493134e-04, 8.33333333332248946124e-03, -1.66666666666666324348e-01,
+    -1.13596475577881948265e-11, 2.08757232129817482790e-09, -2.75573143513906633035e-07,        // C6 .. C1
+    2.48015872894767294178e-05, -1.38888888888741095749e-03, 4.16666666666666019037e-02, 0.0};
+MCG_DEV TrigC load_trig() {
+  TrigC T; CRealPtr p = (CRealPtr)kTrig; asm volatile("" : "+s"(p));
+  for (int k = 0; k < 16; k++) T.t[k] = p[k];
+  return T;
+}
+MCG_DEV void sincos_cw(const TrigC& T, real x, real& s, real& c) {
+  const real k = rint(x * T.t[0]);
+  real r = fma(-k, T.t[1], x);
+  r = fma(-k, T.t[2], r);
+  const real z = r * r;
+  real ps = fma(z, T.t[3], T.t[4]);
+  ps = fma(z, ps, T.t[5]); ps = fma(z, ps, T.t[6]);
+  ps = fma(z, ps, T.t[7]); ps = fma(z, ps, T.t[8]);
+  const real sr = fma(r * z, ps, r);
+  real pc = fma(z, T.t[9], T.t[10]);
+  pc = fma(z, pc, T.t[11]); pc = fma(z, pc, T.t[12]);
+  pc = fma(z, pc, T.t[13]); pc = fma(z, pc, T.t[14]);
+  const real cr = fma(z * z, pc, fma(z, -0.5, 1.0));
+  const int q = (int)k;
+  const real s0 = (q & 1) ? cr : sr, c0 = (q & 1) ? sr : cr;
+  s = (q & 2) ? -s0 : s0;
+  c = ((q + 1) & 2) ? -c0 : c0;
+}
+
+// Impedance sigmoid (MuJoCo getimpedance [RECALL]); par = K B d0 dmax width midpoint power 1/width a b
 MCG_DEV real impedance(const real* par, real dist) {
-  real d0 = par[2], dmax = par[3], width = par[4], mid = par[5], power = par[6];
+  const real d0 = par[2], dmax = par[3], width = par[4], mid = par[5], power = par[6];
   real imp;
-  if (d0 == dmax || width <= MINVAL) imp = 0.5 * (d0 + dmax);
+  if (d0 == dmax || width <= MINVAL) imp = 0.5 * (d0 + dmax);           // wave-uniform branch
   else {
-    real x = fabs(dist) / width;
-    if (x >= 1) imp = dmax;
-    else if (x == 0) imp = d0;
-    else {
-      real y;
-      if (power == 1) y = x;
-      else if (x <= mid) y = pow(x, power) / pow(mid, power - 1);
-      else y = 1 - pow(1 - x, power) / pow(1 - mid, power - 1);
-      imp = d0 + y * (dmax - d0);
-    }
+    const real x = fabs(dist) * par[7];
+    real y;
+    if (power == 2) {                                                   // wave-uniform; the model's default
+      const real u = 1 - x;
+      y = (x <= mid) ? par[8] * (x * x) : 1 - par[9] * (u * u);
+    } else y = x;       // power == 1; any other power is rejected by mcg_create (keeps pow() out of the hot loop)
+    imp = d0 + y * (dmax - d0);
+    imp = (x >= 1) ? dmax : imp;
+    imp = (x == 0) ? d0 : imp;
   }
   return fmin(fmax(imp, MINIMP), MAXIMP);
 }
 
-// dense symmetric positive definite solve, n = 12, lower triangle packed row-major: A[i*(i+1)/2 + j]
+constexpr int tri(int i, int j) { return i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i; }
+
+// ---------------------------------------------------------------------------- sparse L^T D L with fixed patterns
+// The joint-space matrices have compile-time sparsity: M follows the kinematic tree (no fill-in when eliminated
+// leaves-first, Featherstone); H = M + J^T D J adds the two connect cliques {gear, finger, hinge} and the gear-gear
+// coupling.  The symbolic factorisation runs in constexpr; the numeric code below touches only structural non-zeros.
+struct Pattern { bool nz[NB][NB]; };
+
+constexpr bool is_ancestor_or_self(int a, int i) {       // a on the path from i to the root
+  while (i >= 0) { if (i == a) return true; i = PAR[i]; }
+  return false;
+}
+constexpr Pattern symbolic(bool with_constraints) {
+  Pattern P{};
+  for (int i = 0; i < NB; i++) for (int j = 0; j <= i; j++) P.nz[i][j] = is_ancestor_or_self(j, i);
+  if (with_constraints) {
+    constexpr int grp[2][3] = {{6, 7, 10}, {8, 9, 11}};
+    for (int g = 0; g < 2; g++) for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) {
+      int i = grp[g][a], j = grp[g][b];
+      if (i >= j) P.nz[i][j] = true;
+    }
+    for (int g = 0; g < 2; g++) for (int a = 0; a < 3; a++) for (int j = 0; j < 6; j++) P.nz[grp[g][a]][j] = true;
+    P.nz[8][6] = true;
+  }
+  for (int k = NB - 1; k >= 0; k--)                      // fill-in of the leaves-first elimination
+    for (int i = 0; i < k; i++) if (P.nz[k][i])
+      for (int j = 0; j <= i; j++) if (P.nz[k][j]) P.nz[i][j] = true;
+  return P;
+}
+constexpr Pattern PAT_M = symbolic(false);
+constexpr Pattern PAT_H = symbolic(true);
+
+// in place on the packed lower triangle: A = L^T D L, L unit lower (stored below the diagonal), dinv = 1 / D
+template <const Pattern& PT>
+MCG_DEV void ldl_factor(real* A, real* dinv) {
+  static_for<NB>([&](auto Kk) {
+    constexpr int k = NB - 1 - Kk;
+    dinv[k] = rcp_nr(A[tri(k, k)]);
+    static_for<k>([&](auto Ii) {
+      constexpr int i = k - 1 - Ii;
+      if constexpr (PT.nz[k][i]) {
+        const real l = A[tri(k, i)] * dinv[k];
+        static_for<i + 1>([&](auto Jj) {
+          constexpr int j = Jj;
+          if constexpr (PT.nz[k][j]) A[tri(i, j)] = fma(-l, A[tri(k, j)], A[tri(i, j)]);
+        });
+        A[tri(k, i)] = l;
+      }
+    });
+  });
+}
+template <const Pattern& PT>
+MCG_DEV void ldl_solve(const real* A, const real* dinv, real* x) {
+  static_for<NB>([&](auto Kk) {
+    constexpr int k = NB - 1 - Kk;
+    static_for<k>([&](auto Ii) { constexpr int i = Ii; if constexpr (PT.nz[k][i]) x[i] = fma(-A[tri(k, i)], x[k], x[i]); });
+  });
+  static_for<NB>([&](auto Kk) { constexpr int k = Kk; x[k] *= dinv[k]; });
+  static_for<NB>([&](auto Kk) {
+    constexpr int k = Kk;
+    static_for<k>([&](auto Ii) { constexpr int i = Ii; if constexpr (PT.nz[k][i]) x[k] = fma(-A[tri(k, i)], x[i], x[k]); });
+  });
+}
+
+// dense SPD solve for the 6x6 IK system (once per control step; not on the sub-step path)
 template <int N>
 MCG_DEV void chol_factor(real* A) {
   static_for<N>([&](auto I) {
@@ -132,139 +261,175 @@ MCG_DEV void chol_solve(const real* L, real* x) {
     x[i] = s / L[i * (i + 1) / 2 + i];
   });
 }
-constexpr int tri(int i, int j) { return i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i; }
 
 // ------------------------------------------------------------------------------------- robot sub-step state
 struct Robot {
   real q[NB], qd[NB], ctrl[7], warm[NB];
 };
 
+// Per-lane scratch in LDS: slot k of this lane lives at base[k * 64] (lane-contiguous rows: conflict-free
+// ds_read_b64 / ds_write_b64 with immediate offsets).  The joint-space inertia M is kept here between the stages
+// that consume it, so that only one 12x12 system occupies registers at a time.
+constexpr int LDS_SLOTS = NB * (NB + 1) / 2;
+struct LaneScratch {
+  real* base;
+  MCG_DEV real ld(int k) const { return base[k * 64]; }
+  MCG_DEV void st(int k, real v) const { base[k * 64] = v; }
+};
+
 // One physics sub-step (mj_step) of the 12-dof robot.  `qlag` receives the positions the forward pass used.
-MCG_DEV void robot_substep(const mcg_model* __restrict__ P, Robot& S, real* qlag6) {
-  const real h = P->timestep;
+MCG_DEV void robot_substep(ModelPtr Pm, Robot& S, real* qlag6, const LaneScratch MS) {
+  const real h = launder(Pm)->timestep;
   real cs[NB], sn[NB];
-  static_for<NB>([&](auto I) { constexpr int i = I; sincos(AXS[i] * S.q[i], &sn[i], &cs[i]); });
+  {
+    const TrigC T = load_trig();
+    static_for<NB>([&](auto I) { constexpr int i = I; sincos_cw(T, AXS[i] * S.q[i], sn[i], cs[i]); });
+  }
   static_for<6>([&](auto I) { constexpr int i = I; qlag6[i] = S.q[i]; });
+  static_for<NB>([&](auto I) { constexpr int i = I; pin(sn[i]); pin(cs[i]); });
+  MCG_FENCE();
 
   // ---- P6 recursive Newton-Euler, q'' = 0: bias = Coriolis + centrifugal + gravity        (mj_rne, flg_acc=0)
   real F[NB][3], Nn[NB][3];                 // net force / moment about the body origin, body frame
   real w[NB][3], al[NB][3], ac[NB][3];      // angular velocity, angular acceleration, linear acceleration of the origin
   static_for<NB>([&](auto I) {
     constexpr int i = I; constexpr int p = PAR[i]; constexpr int K = AXK[i];
-    real wp[3], alp[3], ap[3];
-    if constexpr (p < 0) {
-      wp[0] = wp[1] = wp[2] = 0; alp[0] = alp[1] = alp[2] = 0;
-      ap[0] = P->gravity_base[0]; ap[1] = P->gravity_base[1]; ap[2] = P->gravity_base[2];
-    } else {
-      for (int k = 0; k < 3; k++) { wp[k] = w[p][k]; alp[k] = al[p][k]; ap[k] = ac[p][k]; }
-    }
-    const real* r = P->r[i];
-    real t[3], accp[3];
-    cross(wp, r, t);
-    accp[0] = ap[0]; accp[1] = ap[1]; accp[2] = ap[2];
-    cross_add(alp, r, accp); cross_add(wp, t, accp);
-    rot_down<K>(cs[i], sn[i], accp, ac[i]);
-    real we[3];
-    rot_down<K>(cs[i], sn[i], wp, we);
-    rot_down<K>(cs[i], sn[i], alp, al[i]);
-    const real g = AXS[i] * S.qd[i];
     constexpr int A = (K + 1) % 3, B = (K + 2) % 3;
-    // al += (E wp) x (g e_K)
-    al[i][A] += we[B] * g; al[i][B] -= we[A] * g;
-    w[i][0] = we[0]; w[i][1] = we[1]; w[i][2] = we[2]; w[i][K] += g;
-    // wrench
-    const real m = P->mass[i]; const real* mc = P->mc[i]; const real* In = P->inertia[i];
+    const BodyC bc = load_body(launder(Pm), i); const BodyC* b = &bc;
+    const real g = AXS[i] * S.qd[i];
+    if constexpr (p < 0) {
+      // static base: w_p = al_p = 0, a_p = -gravity (base frame)
+      real gb[3]; ldc<3>(launder(Pm)->gravity_base, gb);
+      rot_down<K>(cs[i], sn[i], gb, ac[i]);
+      w[i][0] = w[i][1] = w[i][2] = 0; w[i][K] = g;
+      al[i][0] = al[i][1] = al[i][2] = 0;
+    } else {
+      real t[3], accp[3], we[3];
+      cross(w[p], b->r, t);
+      accp[0] = ac[p][0]; accp[1] = ac[p][1]; accp[2] = ac[p][2];
+      cross_add(al[p], b->r, accp); cross_add(w[p], t, accp);
+      rot_down<K>(cs[i], sn[i], accp, ac[i]);
+      rot_down<K>(cs[i], sn[i], w[p], we);
+      rot_down<K>(cs[i], sn[i], al[p], al[i]);
+      al[i][A] += we[B] * g; al[i][B] -= we[A] * g;          // + (E w_p) x (g e_K)
+      w[i][0] = we[0]; w[i][1] = we[1]; w[i][2] = we[2]; w[i][K] += g;
+    }
     real t2[3], Iw[3];
-    cross(w[i], mc, t2);
-    F[i][0] = m * ac[i][0]; F[i][1] = m * ac[i][1]; F[i][2] = m * ac[i][2];
-    cross_add(al[i], mc, F[i]); cross_add(w[i], t2, F[i]);
-    sym_mul(In, al[i], Nn[i]); sym_mul(In, w[i], Iw);
-    cross_add(w[i], Iw, Nn[i]); cross_add(mc, ac[i], Nn[i]);
+    cross(w[i], b->mc, t2);
+    F[i][0] = b->mass * ac[i][0]; F[i][1] = b->mass * ac[i][1]; F[i][2] = b->mass * ac[i][2];
+    cross_add(al[i], b->mc, F[i]); cross_add(w[i], t2, F[i]);
+    sym_mul(b->inertia, al[i], Nn[i]); sym_mul(b->inertia, w[i], Iw);
+    cross_add(w[i], Iw, Nn[i]); cross_add(b->mc, ac[i], Nn[i]);
+    pin3(F[i]); pin3(Nn[i]);
+    MCG_FENCE();
   });
-  real bias[NB];
+  real fs[NB];        // becomes qfrc_smooth = passive - bias + actuation
   static_for<NB>([&](auto I) {
     constexpr int i = NB - 1 - I; constexpr int p = PAR[i]; constexpr int K = AXK[i];
-    bias[i] = AXS[i] * Nn[i][K];
+    const BodyC bc = load_body(launder(Pm), i); const BodyC* b = &bc;
+    fs[i] = -b->damping * S.qd[i] - AXS[i] * Nn[i][K];
     if constexpr (p >= 0) {
       real fp[3], np[3];
       rot_up<K>(cs[i], sn[i], F[i], fp); rot_up<K>(cs[i], sn[i], Nn[i], np);
-      cross_add(P->r[i], fp, np);
+      cross_add(b->r, fp, np);
       for (int k = 0; k < 3; k++) { F[p][k] += fp[k]; Nn[p][k] += np[k]; }
+      pin3(F[p]); pin3(Nn[p]);
     }
+    pin(fs[i]);
+    MCG_FENCE();
   });
 
-  // ---- P3 composite rigid bodies -> joint-space inertia M (packed lower triangle)             (mj_crb)
-  real M[NB * (NB + 1) / 2];
-  for (int k = 0; k < NB * (NB + 1) / 2; k++) M[k] = 0;
-  real cm[NB], cmc[NB][3], cI[NB][6];
-  static_for<NB>([&](auto I) {
-    constexpr int i = I;
-    cm[i] = P->mass[i];
-    for (int k = 0; k < 3; k++) cmc[i][k] = P->mc[i][k];
-    for (int k = 0; k < 6; k++) cI[i][k] = P->inertia[i][k];
-  });
-  static_for<NB>([&](auto I) {
-    constexpr int i = NB - 1 - I; constexpr int K = AXK[i]; constexpr int A = (K + 1) % 3, B = (K + 2) % 3;
-    // wrench of a unit acceleration about joint i acting on the composite body i (frame i, about origin i)
-    real f[3], n[3];
-    constexpr int iKA = (K + A == 1) ? 3 : (K + A == 2) ? 4 : 5;
-    constexpr int iKB = (K + B == 1) ? 3 : (K + B == 2) ? 4 : 5;
-    const real sg = AXS[i];
-    n[K] = sg * cI[i][K]; n[A] = sg * cI[i][iKA]; n[B] = sg * cI[i][iKB];
-    f[K] = 0; f[A] = -sg * cmc[i][B]; f[B] = sg * cmc[i][A];          // (sg e_K) x mc
-    M[tri(i, i)] = cI[i][K] + P->armature[i];
-    // walk to the root: M[i][j] = axis_j . moment about origin j
-    real fj[3] = {f[0], f[1], f[2]}, nj[3] = {n[0], n[1], n[2]};
-    auto up = [&](auto self, auto Cur) -> void {
-      constexpr int cur = Cur; constexpr int pj = PAR[cur];
-      if constexpr (pj >= 0) {
-        real f2[3], n2[3];
-        rot_up<AXK[cur]>(cs[cur], sn[cur], fj, f2); rot_up<AXK[cur]>(cs[cur], sn[cur], nj, n2);
-        cross_add(P->r[cur], f2, n2);
-        for (int k = 0; k < 3; k++) { fj[k] = f2[k]; nj[k] = n2[k]; }
-        M[tri(i, pj)] = AXS[pj] * nj[AXK[pj]];
-        self(self, std::integral_constant<int, pj>{});
-      }
-    };
-    up(up, std::integral_constant<int, i>{});
-    // add composite i to its parent
-    constexpr int p = PAR[i];
-    if constexpr (p >= 0) {
-      real It[6], h3[3];
-      for (int k = 0; k < 6; k++) It[k] = cI[i][k];
-      sym_rot_up<K>(cs[i], sn[i], It);
-      rot_up<K>(cs[i], sn[i], cmc[i], h3);
-      const real* r = P->r[i]; const real m = cm[i];
-      real rr = dot3(r, r), rh = dot3(r, h3);
-      real d = m * rr + 2 * rh;
-      cI[p][0] += It[0] + d - (m * r[0] * r[0] + 2 * r[0] * h3[0]);
-      cI[p][1] += It[1] + d - (m * r[1] * r[1] + 2 * r[1] * h3[1]);
-      cI[p][2] += It[2] + d - (m * r[2] * r[2] + 2 * r[2] * h3[2]);
-      cI[p][3] += It[3] - (m * r[0] * r[1] + r[0] * h3[1] + h3[0] * r[1]);
-      cI[p][4] += It[4] - (m * r[0] * r[2] + r[0] * h3[2] + h3[0] * r[2]);
-      cI[p][5] += It[5] - (m * r[1] * r[2] + r[1] * h3[2] + h3[1] * r[2]);
-      cm[p] += m;
-      for (int k = 0; k < 3; k++) cmc[p][k] += h3[k] + m * r[k];
-    }
-  });
-
-  // ---- P7 actuation + passive damping -> qfrc_smooth                       (mj_fwdActuation, mj_passive)
-  real fs[NB];
-  static_for<NB>([&](auto I) { constexpr int i = I; fs[i] = -P->damping[i] * S.qd[i] - bias[i]; });
-  static_for<6>([&](auto I) {
-    constexpr int u = I;
-    real c = fmin(fmax(S.ctrl[u], P->act_ctrlrange[u][0]), P->act_ctrlrange[u][1]);
-    real f = P->act_gain[u] * c + P->act_bias[u][0] + P->act_bias[u][1] * S.q[u] + P->act_bias[u][2] * S.qd[u];
-    f = fmin(fmax(f, P->act_forcerange[u][0]), P->act_forcerange[u][1]);
-    fs[u] += f;
-  });
+  // ---- P7 actuation                                                             (mj_fwdActuation)
   {
-    const real c0 = P->tendon_coef[0], c1 = P->tendon_coef[1];
+    ModelPtr Q = launder(Pm);
+    static_for<6>([&](auto I) {
+      constexpr int u = I;
+      real c = fmin(fmax(S.ctrl[u], Q->act_ctrlrange[u][0]), Q->act_ctrlrange[u][1]);
+      real f = Q->act_gain[u] * c + Q->act_bias[u][0] + Q->act_bias[u][1] * S.q[u] + Q->act_bias[u][2] * S.qd[u];
+      fs[u] += fmin(fmax(f, Q->act_forcerange[u][0]), Q->act_forcerange[u][1]);
+    });
+    const real c0 = Q->tendon_coef[0], c1 = Q->tendon_coef[1];
     real len = c0 * S.q[6] + c1 * S.q[8], vel = c0 * S.qd[6] + c1 * S.qd[8];
-    real c = fmin(fmax(S.ctrl[6], P->act_ctrlrange[6][0]), P->act_ctrlrange[6][1]);
-    real f = P->act_gain[6] * c + P->act_bias[6][0] + P->act_bias[6][1] * len + P->act_bias[6][2] * vel;
-    f = fmin(fmax(f, P->act_forcerange[6][0]), P->act_forcerange[6][1]);
+    real c = fmin(fmax(S.ctrl[6], Q->act_ctrlrange[6][0]), Q->act_ctrlrange[6][1]);
+    real f = Q->act_gain[6] * c + Q->act_bias[6][0] + Q->act_bias[6][1] * len + Q->act_bias[6][2] * vel;
+    f = fmin(fmax(f, Q->act_forcerange[6][0]), Q->act_forcerange[6][1]);
     fs[6] += c0 * f; fs[8] += c1 * f;
+  }
+  static_for<NB>([&](auto I) { constexpr int i = I; pin(fs[i]); });
+  MCG_FENCE();
+
+  // ---- P3 composite rigid bodies -> joint-space inertia M (packed lower triangle, in LDS)      (mj_crb)
+  {
+    real cm[NB], cmc[NB][3], cI[NB][6];
+    static_for<NB>([&](auto I) {
+      constexpr int i = NB - 1 - I; constexpr int K = AXK[i]; constexpr int A = (K + 1) % 3, B = (K + 2) % 3;
+      constexpr int p = PAR[i];
+      constexpr bool leaf = (i == 7 || i == 9 || i == 10 || i == 11);
+      const BodyC bc = load_body(launder(Pm), i); const BodyC* b = &bc;
+      if constexpr (leaf) {
+        cm[i] = b->mass;
+        for (int k = 0; k < 3; k++) cmc[i][k] = b->mc[k];
+        for (int k = 0; k < 6; k++) cI[i][k] = b->inertia[k];
+      } else {          // children (higher index) have already added their composites
+        cm[i] += b->mass;
+        for (int k = 0; k < 3; k++) cmc[i][k] += b->mc[k];
+        for (int k = 0; k < 6; k++) cI[i][k] += b->inertia[k];
+      }
+      // wrench of a unit acceleration about joint i acting on composite body i (frame i, about origin i)
+      constexpr int iKA = (K + A == 1) ? 3 : (K + A == 2) ? 4 : 5;
+      constexpr int iKB = (K + B == 1) ? 3 : (K + B == 2) ? 4 : 5;
+      const real sg = AXS[i];
+      real fj[3], nj[3];
+      nj[K] = sg * cI[i][K]; nj[A] = sg * cI[i][iKA]; nj[B] = sg * cI[i][iKB];
+      fj[K] = 0; fj[A] = -sg * cmc[i][B]; fj[B] = sg * cmc[i][A];          // (sg e_K) x mc
+      MS.st(tri(i, i), cI[i][K] + b->armature);
+      // walk to the root: M[i][j] = axis_j . moment about origin j
+      auto up = [&](auto self, auto Cur) -> void {
+        constexpr int cur = Cur; constexpr int pj = PAR[cur];
+        if constexpr (pj >= 0) {
+          constexpr int Kc = AXK[cur];
+          real rc[3]; ldc<3>(launder(Pm)->body[cur].r, rc);
+          real f2[3], n2[3];
+          rot_up<Kc>(cs[cur], sn[cur], fj, f2);
+          rot_up<Kc>(cs[cur], sn[cur], nj, n2);
+          cross_add(rc, f2, n2);
+          for (int k = 0; k < 3; k++) { fj[k] = f2[k]; nj[k] = n2[k]; }
+          MS.st(tri(i, pj), AXS[pj] * nj[AXK[pj]]);
+          self(self, std::integral_constant<int, pj>{});
+        }
+      };
+      up(up, std::integral_constant<int, i>{});
+      // add composite i to its parent
+      if constexpr (p >= 0) {
+        constexpr bool first_child = (i == 11 || i == 7 || i == 9 || i < 6);   // highest-index child of its parent
+        real It[6], h3[3];
+        for (int k = 0; k < 6; k++) It[k] = cI[i][k];
+        sym_rot_up<K>(cs[i], sn[i], It);
+        rot_up<K>(cs[i], sn[i], cmc[i], h3);
+        const real* r = b->r; const real m = cm[i];
+        const real rr = dot3(r, r), rh = dot3(r, h3);
+        const real d = m * rr + 2 * rh;
+        real add[6];
+        add[0] = It[0] + d - (m * r[0] * r[0] + 2 * r[0] * h3[0]);
+        add[1] = It[1] + d - (m * r[1] * r[1] + 2 * r[1] * h3[1]);
+        add[2] = It[2] + d - (m * r[2] * r[2] + 2 * r[2] * h3[2]);
+        add[3] = It[3] - (m * r[0] * r[1] + r[0] * h3[1] + h3[0] * r[1]);
+        add[4] = It[4] - (m * r[0] * r[2] + r[0] * h3[2] + h3[0] * r[2]);
+        add[5] = It[5] - (m * r[1] * r[2] + r[1] * h3[2] + h3[1] * r[2]);
+        if constexpr (first_child) {
+          cm[p] = m;
+          for (int k = 0; k < 3; k++) cmc[p][k] = h3[k] + m * r[k];
+          for (int k = 0; k < 6; k++) cI[p][k] = add[k];
+        } else {
+          cm[p] += m;
+          for (int k = 0; k < 3; k++) cmc[p][k] += h3[k] + m * r[k];
+          for (int k = 0; k < 6; k++) cI[p][k] += add[k];
+        }
+        pin(cm[p]); pin3(cmc[p]); pin6(cI[p]);
+      }
+      asm volatile("" ::: "memory");      // the M entries of this body are in LDS before the next block starts
+      MCG_FENCE();
+    });
   }
 
   // ---- P5 constraint rows                                                   (mj_makeConstraint)
@@ -280,144 +445,173 @@ MCG_DEV void robot_substep(const mcg_model* __restrict__ P, Robot& S, real* qlag
       for (int k = 0; k < 3; k++) ax5[i][k] = t[k];
     });
   });
-  // two connects; side 0: gear 6 / finger 7 / hinge 10, side 1: gear 8 / finger 9 / hinge 11
-  real Jc[2][3][9];      // rows x (arm 0..5, gear, finger, hinge)
+  // two connects; side 0: gear 6 / finger 7 / hinge 10, side 1: gear 8 / finger 9 / hinge 11.
+  // Jc[sd][row][col], cols = arm 0..5, gear, finger, hinge; the y row has no gripper entries (planar mechanism).
+  real Jc[2][3][9];
   real Dc[2], arefc[2][3];
   static_for<2>([&](auto Sd) {
     constexpr int sd = Sd; constexpr int g = 6 + 2 * sd, fi = 7 + 2 * sd, hg = 10 + sd;
-    // all three joints turn about +-y of the link6 frame: compose by plane rotations
-    real o_g[3] = {P->r[g][0], P->r[g][1], P->r[g][2]};
-    real t[3], o_f[3], p1[3], p2[3];
-    rot_up<1>(cs[g], sn[g], P->r[fi], t);
-    for (int k = 0; k < 3; k++) o_f[k] = o_g[k] + t[k];
-    real t2[3];
-    rot_up<1>(cs[fi], sn[fi], P->eq_anchor1[sd], t2); rot_up<1>(cs[g], sn[g], t2, t);
+    ModelPtr Q = launder(Pm);
+    real rg[3], rh[3], rf[3], an1[3], an2[3], par[10];
+    ldc<3>(Q->body[g].r, rg); ldc<3>(Q->body[hg].r, rh); ldc<3>(Q->body[fi].r, rf);
+    ldc<3>(Q->eq_anchor1[sd], an1); ldc<3>(Q->eq_anchor2[sd], an2); ldc<10>(Q->eq_par[sd], par);
+    real t[3], t2[3], o_f[3], p1[3], p2[3];
+    rot_up<1>(cs[g], sn[g], rf, t);
+    for (int k = 0; k < 3; k++) o_f[k] = rg[k] + t[k];
+    rot_up<1>(cs[fi], sn[fi], an1, t2); rot_up<1>(cs[g], sn[g], t2, t);
     for (int k = 0; k < 3; k++) p1[k] = o_f[k] + t[k];
-    rot_up<1>(cs[hg], sn[hg], P->eq_anchor2[sd], t);
-    for (int k = 0; k < 3; k++) p2[k] = P->r[hg][k] + t[k];
-    real pos[3] = {p1[0] - p2[0], p1[1] - p2[1], p1[2] - p2[2]};
-    // Jacobian columns: axis x lever
+    rot_up<1>(cs[hg], sn[hg], an2, t);
+    for (int k = 0; k < 3; k++) p2[k] = rh[k] + t[k];
+    const real pos[3] = {p1[0] - p2[0], p1[1] - p2[1], p1[2] - p2[2]};
     static_for<6>([&](auto I) { constexpr int i = I; real c3[3]; cross(ax5[i], pos, c3); for (int k = 0; k < 3; k++) Jc[sd][k][i] = c3[k]; });
-    real lg[3] = {p1[0] - o_g[0], p1[1] - o_g[1], p1[2] - o_g[2]};
-    real lf[3] = {p1[0] - o_f[0], p1[1] - o_f[1], p1[2] - o_f[2]};
-    real lh[3] = {p2[0] - P->r[hg][0], p2[1] - P->r[hg][1], p2[2] - P->r[hg][2]};
     // (s e_y) x d = s (d_z, 0, -d_x)
-    Jc[sd][0][6] = AXS[g] * lg[2];  Jc[sd][1][6] = 0; Jc[sd][2][6] = -AXS[g] * lg[0];
-    Jc[sd][0][7] = AXS[fi] * lf[2]; Jc[sd][1][7] = 0; Jc[sd][2][7] = -AXS[fi] * lf[0];
-    Jc[sd][0][8] = -AXS[hg] * lh[2]; Jc[sd][1][8] = 0; Jc[sd][2][8] = AXS[hg] * lh[0];
-    real nrm = sqrt(dot3(pos, pos));
-    real imp = impedance(P->eq_par[sd], nrm);
-    real R = fmax(MINVAL, (1 - imp) * P->eq_diag[sd] / imp);
-    Dc[sd] = 1 / R;
-    for (int k = 0; k < 3; k++) {
+    Jc[sd][0][6] = AXS[g] * (p1[2] - rg[2]);   Jc[sd][2][6] = -AXS[g] * (p1[0] - rg[0]);
+    Jc[sd][0][7] = AXS[fi] * (p1[2] - o_f[2]); Jc[sd][2][7] = -AXS[fi] * (p1[0] - o_f[0]);
+    Jc[sd][0][8] = -AXS[hg] * (p2[2] - rh[2]); Jc[sd][2][8] = AXS[hg] * (p2[0] - rh[0]);
+    Jc[sd][1][6] = Jc[sd][1][7] = Jc[sd][1][8] = 0;
+    const real imp = impedance(par, sqrt(dot3(pos, pos)));
+    Dc[sd] = imp * rcp_nr(fmax(MINVAL * imp, (1 - imp) * Q->eq_diag[sd]));      // 1 / max(MINVAL, (1-imp) diag / imp)
+    static_for<3>([&](auto Kk) {
+      constexpr int k = Kk;
       real vel = 0;
-      static_for<6>([&](auto I) { constexpr int i = I; vel += Jc[sd][k][i] * S.qd[i]; });
-      vel += Jc[sd][k][6] * S.qd[g] + Jc[sd][k][7] * S.qd[fi] + Jc[sd][k][8] * S.qd[hg];
-      arefc[sd][k] = -P->eq_par[sd][1] * vel - P->eq_par[sd][0] * imp * pos[k];
-    }
+      static_for<6>([&](auto I) { constexpr int i = I; vel = fma(Jc[sd][k][i], S.qd[i], vel); });
+      if constexpr (k != 1) vel += Jc[sd][k][6] * S.qd[g] + Jc[sd][k][7] * S.qd[fi] + Jc[sd][k][8] * S.qd[hg];
+      arefc[sd][k] = -par[1] * vel - par[0] * imp * pos[k];
+    });
+    pin(Dc[sd]); pin3(arefc[sd]);
+    for (int k = 0; k < 3; k++) { pin3(&Jc[sd][k][0]); pin3(&Jc[sd][k][3]); pin3(&Jc[sd][k][6]); }
+    MCG_FENCE();
   });
   // joint coupling q6 - q8 = 0
   real Dj, arefj;
   {
-    real pos = S.q[6] - S.q[8];
-    real imp = impedance(P->eq_par[2], pos);
-    Dj = 1 / fmax(MINVAL, (1 - imp) * P->eq_diag[2] / imp);
-    arefj = -P->eq_par[2][1] * (S.qd[6] - S.qd[8]) - P->eq_par[2][0] * imp * pos;
+    ModelPtr Q = launder(Pm);
+    real par[10]; ldc<10>(Q->eq_par[2], par);
+    const real pos = S.q[6] - S.q[8];
+    const real imp = impedance(par, pos);
+    Dj = imp * rcp_nr(fmax(MINVAL * imp, (1 - imp) * Q->eq_diag[2]));
+    arefj = -par[1] * (S.qd[6] - S.qd[8]) - par[0] * imp * pos;
   }
-  // joint limits on dofs 0..9: a row exists while violated; sign = d(dist)/dq
+  // joint limits on dofs 0..9: a row exists while violated; sign = d(dist)/dq.
+  // Control flow is wave-uniform (__any) with per-lane selects: hipcc (ROCm 7.2) places spill stores of values
+  // merged after a lane-divergent region BEFORE the exec mask is restored, silently dropping lanes (see DESIGN.md
+  // "Compiler hazard"), so no lane-divergent branch is allowed around code that may spill.
   real Dl[10], arefl[10], sgl[10];
   bool any_limit = false;
   static_for<10>([&](auto I) {
     constexpr int j = I;
-    real lo = S.q[j] - P->jnt_range[j][0], hi = P->jnt_range[j][1] - S.q[j];
-    real dist = 0, sg = 0;
-    if (lo < 0) { dist = lo; sg = 1; }
-    if (hi < 0) { dist = hi; sg = -1; }
+    ModelPtr Q = launder(Pm);
+    const real lo = S.q[j] - Q->jnt_range[j][0], hi = Q->jnt_range[j][1] - S.q[j];
+    real dist = (lo < 0) ? lo : 0.0, sg = (lo < 0) ? 1.0 : 0.0;
+    dist = (hi < 0) ? hi : dist; sg = (hi < 0) ? -1.0 : sg;
     sgl[j] = sg; Dl[j] = 0; arefl[j] = 0;
-    if (sg != 0) {
-      real imp = impedance(P->limit_par[j], dist);
-      Dl[j] = 1 / fmax(MINVAL, (1 - imp) * P->limit_diag[j] / imp);
-      arefl[j] = -P->limit_par[j][1] * (sg * S.qd[j]) - P->limit_par[j][0] * imp * dist;
-      any_limit = true;
+    if (__any(sg != 0)) {
+      real par[10]; ldc<10>(Q->limit_par[j], par);
+      const real imp = impedance(par, dist);
+      const real D = imp * rcp_nr(fmax(MINVAL * imp, (1 - imp) * Q->limit_diag[j]));
+      const real ar = -par[1] * (sg * S.qd[j]) - par[0] * imp * dist;
+      Dl[j] = (sg != 0) ? D : 0.0; arefl[j] = (sg != 0) ? ar : 0.0;
+      any_limit = any_limit || (sg != 0);
     }
   });
+  static_for<10>([&](auto I) { constexpr int j = I; pin(Dl[j]); pin(arefl[j]); pin(sgl[j]); });
+  MCG_FENCE();
 
-  // ---- P8/P9: H0 = M + J^T D J over the equality rows, g0 = qfrc_smooth + J^T D aref      (Newton system)
-  real H0[NB * (NB + 1) / 2], g0[NB];
-  for (int k = 0; k < NB * (NB + 1) / 2; k++) H0[k] = M[k];
+  // ---- P8/P9: g0 = qfrc_smooth + J^T D aref over the equality rows                          (Newton system)
+  real g0[NB];
   static_for<NB>([&](auto I) { constexpr int i = I; g0[i] = fs[i]; });
   static_for<2>([&](auto Sd) {
     constexpr int sd = Sd;
     constexpr int idx[9] = {0, 1, 2, 3, 4, 5, 6 + 2 * sd, 7 + 2 * sd, 10 + sd};
-    for (int k = 0; k < 3; k++) {
-      if (k == 1) {   // y row: gripper entries are structurally zero
-        static_for<6>([&](auto A_) { constexpr int a = A_;
-          const real ja = Dc[sd] * Jc[sd][1][a];
-          g0[a] += ja * arefc[sd][1];
-          static_for<a + 1>([&](auto B_) { constexpr int b = B_; H0[tri(a, b)] += ja * Jc[sd][1][b]; }); });
-      } else {
-        static_for<9>([&](auto A_) { constexpr int a = A_;
-          const real ja = Dc[sd] * Jc[sd][k][a];
-          g0[idx[a]] += ja * arefc[sd][k];
-          static_for<a + 1>([&](auto B_) { constexpr int b = B_; H0[tri(idx[a], idx[b])] += ja * Jc[sd][k][b]; }); });
-      }
-    }
+    static_for<3>([&](auto Kk) {
+      constexpr int k = Kk; constexpr int ncol = (k == 1) ? 6 : 9;
+      static_for<ncol>([&](auto A_) { constexpr int a = A_;
+        g0[idx[a]] = fma(Dc[sd] * Jc[sd][k][a], arefc[sd][k], g0[idx[a]]); });
+    });
   });
-  H0[tri(6, 6)] += Dj; H0[tri(8, 8)] += Dj; H0[tri(8, 6)] -= Dj;
   g0[6] += Dj * arefj; g0[8] -= Dj * arefj;
+  // H = M + J^T D J (equality rows) + active limit rows, assembled from LDS-resident M for each Newton iteration
+  auto build_H = [&](real* H, const bool* act_) {
+    static_for<NB>([&](auto I) { constexpr int i = I;
+      static_for<i + 1>([&](auto Jj) { constexpr int j = Jj;
+        if constexpr (PAT_M.nz[i][j]) H[tri(i, j)] = MS.ld(tri(i, j));
+        else if constexpr (PAT_H.nz[i][j]) H[tri(i, j)] = 0.0; }); });
+    static_for<2>([&](auto Sd) {
+      constexpr int sd = Sd;
+      constexpr int idx[9] = {0, 1, 2, 3, 4, 5, 6 + 2 * sd, 7 + 2 * sd, 10 + sd};
+      static_for<3>([&](auto Kk) {
+        constexpr int k = Kk; constexpr int ncol = (k == 1) ? 6 : 9;
+        static_for<ncol>([&](auto A_) { constexpr int a = A_;
+          const real ja = Dc[sd] * Jc[sd][k][a];
+          static_for<a + 1>([&](auto B_) { constexpr int b = B_; H[tri(idx[a], idx[b])] = fma(ja, Jc[sd][k][b], H[tri(idx[a], idx[b])]); }); });
+      });
+    });
+    H[tri(6, 6)] += Dj; H[tri(8, 8)] += Dj; H[tri(8, 6)] -= Dj;
+    static_for<10>([&](auto I) { constexpr int j = I; H[tri(j, j)] += act_[j] ? Dl[j] : 0.0; });
+  };
 
   // ---- Newton iterations over the limit rows' active set, exact line search               (mj_fwdConstraint)
+  // Wave-uniform loop; a lane that has converged keeps recomputing its own (unchanged) system and commits nothing.
   real a[NB];
   static_for<NB>([&](auto I) { constexpr int i = I; a[i] = S.warm[i]; });
   bool act[10];
   static_for<10>([&](auto I) { constexpr int j = I; act[j] = (sgl[j] != 0) && (sgl[j] * a[j] - arefl[j] < 0); });
-  real L[NB * (NB + 1) / 2];
+  bool conv = false;
   for (int it = 0; it < 50; it++) {
-    real x[NB];
-    for (int k = 0; k < NB * (NB + 1) / 2; k++) L[k] = H0[k];
+    real L[NB * (NB + 1) / 2], dinv[NB], x[NB];
+    build_H(L, act);
     static_for<NB>([&](auto I) { constexpr int i = I; x[i] = g0[i]; });
+    static_for<10>([&](auto I) { constexpr int j = I; x[j] += act[j] ? sgl[j] * Dl[j] * arefl[j] : 0.0; });
+    ldl_factor<PAT_H>(L, dinv);
+    ldl_solve<PAT_H>(L, dinv, x);
+    bool same = true;            // does the minimiser of this quadratic piece keep the assumed active set?
     static_for<10>([&](auto I) { constexpr int j = I;
-      if (act[j]) { L[tri(j, j)] += Dl[j]; x[j] += sgl[j] * Dl[j] * arefl[j]; } });
-    chol_factor<NB>(L);
-    chol_solve<NB>(L, x);
-    if (!any_limit) { static_for<NB>([&](auto I) { constexpr int i = I; a[i] = x[i]; }); break; }
-    // direction p = x - a; phi'(alpha) = (alpha - 1) p^T H p on the first piece
+      const bool now = (sgl[j] != 0) && (sgl[j] * x[j] - arefl[j] < 0);
+      same = same && (now == act[j]); });
+    const bool finish = !conv && (!any_limit || same);
+    static_for<NB>([&](auto I) { constexpr int i = I; a[i] = finish ? x[i] : a[i]; });
+    conv = conv || finish;
+    if (!__any(!conv)) break;
+    // some lane crossed a breakpoint: exact line search from a along p = x - a (committed where !conv only);
+    // phi'(alpha) = (alpha - 1) p^T H p on the first piece, its slope changes by +-D p_j^2 at each breakpoint
     real p[NB], Hp[NB];
     static_for<NB>([&](auto I) { constexpr int i = I; p[i] = x[i] - a[i]; });
-    static_for<NB>([&](auto I) { constexpr int i = I; real s = 0;
-      static_for<NB>([&](auto Jj) { constexpr int j = Jj; s += H0[tri(i, j)] * p[j]; }); Hp[i] = s; });
+    build_H(L, act);
+    static_for<NB>([&](auto I) { constexpr int i = I; real sacc = 0;
+      static_for<NB>([&](auto Jj) { constexpr int j = Jj;
+        if constexpr (PAT_H.nz[i > j ? i : j][i > j ? j : i]) sacc = fma(L[tri(i, j)], p[j], sacc); }); Hp[i] = sacc; });
     real slope = 0;
-    static_for<NB>([&](auto I) { constexpr int i = I; slope += p[i] * Hp[i]; });
-    static_for<10>([&](auto I) { constexpr int j = I; if (act[j]) slope += Dl[j] * p[j] * p[j]; });
+    static_for<NB>([&](auto I) { constexpr int i = I; slope = fma(p[i], Hp[i], slope); });
     real val = -slope, alpha = 0;
-    bool crossed = false;
-    // breakpoints alpha_j = -r_j / (sg_j p_j) of the existing rows, visited in increasing order
     real bp[10];
     static_for<10>([&](auto I) { constexpr int j = I;
-      real rj = sgl[j] * a[j] - arefl[j], dj = sgl[j] * p[j];
-      real al_ = (sgl[j] != 0 && dj != 0) ? -rj / dj : -1;
+      const real rj = sgl[j] * a[j] - arefl[j], dj = sgl[j] * p[j];
+      const real al_ = (sgl[j] != 0 && dj != 0) ? -rj / dj : -1.0;
       bp[j] = al_ > 0 ? al_ : INFINITY; });
-    for (int step = 0; step <= 10; step++) {
+    bool ls_done = false;
+    for (int step = 0; step <= 10; step++) {               // uniform trip count, predicated body
       real nxt = INFINITY; int jn = -1;
-      static_for<10>([&](auto I) { constexpr int j = I; if (bp[j] < nxt) { nxt = bp[j]; jn = j; } });
-      if (slope > 0 && val + slope * (nxt - alpha) >= 0) { alpha = alpha - val / slope; break; }
-      if (jn < 0) { alpha = 1; break; }
-      val += slope * (nxt - alpha); alpha = nxt;
+      static_for<10>([&](auto I) { constexpr int j = I; const bool lt = bp[j] < nxt; nxt = lt ? bp[j] : nxt; jn = lt ? j : jn; });
+      const bool root = !ls_done && (slope > 0) && (val + slope * (nxt - alpha) >= 0);
+      alpha = root ? alpha - val / slope : alpha;
+      ls_done = ls_done || root;
+      const bool none = !ls_done && (jn < 0);
+      alpha = none ? 1.0 : alpha;
+      ls_done = ls_done || none;
+      const bool adv = !ls_done;
+      val = adv ? val + slope * (nxt - alpha) : val;
+      alpha = adv ? nxt : alpha;
       static_for<10>([&](auto I) { constexpr int j = I;
-        if (j == jn) {
-          real rj = sgl[j] * a[j] - arefl[j];
-          if (rj < 0) slope -= Dl[j] * p[j] * p[j]; else slope += Dl[j] * p[j] * p[j];
-          bp[j] = INFINITY;
-        } });
-      crossed = true;
+        const bool hit = adv && (j == jn);
+        const real rj = sgl[j] * a[j] - arefl[j];
+        const real dsl = Dl[j] * p[j] * p[j];
+        slope = hit ? (rj < 0 ? slope - dsl : slope + dsl) : slope;
+        bp[j] = hit ? INFINITY : bp[j]; });
     }
-    static_for<NB>([&](auto I) { constexpr int i = I; a[i] += alpha * p[i]; });
-    bool same = true;
+    static_for<NB>([&](auto I) { constexpr int i = I; a[i] = conv ? a[i] : fma(alpha, p[i], a[i]); });
     static_for<10>([&](auto I) { constexpr int j = I;
-      bool now = (sgl[j] != 0) && (sgl[j] * a[j] - arefl[j] < 0);
-      if (now != act[j]) same = false;
-      act[j] = now; });
-    if (!crossed && same) break;
+      const bool now = (sgl[j] != 0) && (sgl[j] * a[j] - arefl[j] < 0);
+      act[j] = conv ? act[j] : now; });
   }
 
   // ---- constraint forces -> qfrc_constraint; P10 implicit-damping Euler                  (mj_Euler, mj_advance)
@@ -426,22 +620,29 @@ MCG_DEV void robot_substep(const mcg_model* __restrict__ P, Robot& S, real* qlag
   static_for<2>([&](auto Sd) {
     constexpr int sd = Sd;
     constexpr int idx[9] = {0, 1, 2, 3, 4, 5, 6 + 2 * sd, 7 + 2 * sd, 10 + sd};
-    for (int k = 0; k < 3; k++) {
+    static_for<3>([&](auto Kk) {
+      constexpr int k = Kk; constexpr int ncol = (k == 1) ? 6 : 9;
       real jar = -arefc[sd][k];
-      static_for<9>([&](auto A_) { constexpr int c = A_; jar += Jc[sd][k][c] * a[idx[c]]; });
-      real force = -Dc[sd] * jar;
-      static_for<9>([&](auto A_) { constexpr int c = A_; rhs[idx[c]] += Jc[sd][k][c] * force; });
-    }
+      static_for<ncol>([&](auto A_) { constexpr int c = A_; jar = fma(Jc[sd][k][c], a[idx[c]], jar); });
+      const real force = -Dc[sd] * jar;
+      static_for<ncol>([&](auto A_) { constexpr int c = A_; rhs[idx[c]] = fma(Jc[sd][k][c], force, rhs[idx[c]]); });
+    });
   });
-  { real force = -Dj * (a[6] - a[8] - arefj); rhs[6] += force; rhs[8] -= force; }
+  { const real force = -Dj * (a[6] - a[8] - arefj); rhs[6] += force; rhs[8] -= force; }
   static_for<10>([&](auto I) { constexpr int j = I;
-    if (sgl[j] != 0) { real jar = sgl[j] * a[j] - arefl[j]; if (jar < 0) rhs[j] += sgl[j] * (-Dl[j] * jar); } });
-  static_for<NB>([&](auto I) { constexpr int i = I; M[tri(i, i)] += h * P->damping[i]; });
-  chol_factor<NB>(M);
-  chol_solve<NB>(M, rhs);
+    const real jar = sgl[j] * a[j] - arefl[j];
+    rhs[j] += (sgl[j] != 0 && jar < 0) ? sgl[j] * (-Dl[j] * jar) : 0.0; });
+  {
+    real Mh[NB * (NB + 1) / 2], dinv[NB];
+    static_for<NB>([&](auto I) { constexpr int i = I;
+      static_for<i + 1>([&](auto Jj) { constexpr int j = Jj; if constexpr (PAT_M.nz[i][j]) Mh[tri(i, j)] = MS.ld(tri(i, j)); }); });
+    static_for<NB>([&](auto I) { constexpr int i = I; Mh[tri(i, i)] = fma(h, launder(Pm)->body[i].damping, Mh[tri(i, i)]); });
+    ldl_factor<PAT_M>(Mh, dinv);
+    ldl_solve<PAT_M>(Mh, dinv, rhs);
+  }
   static_for<NB>([&](auto I) { constexpr int i = I;
-    S.qd[i] += h * rhs[i];
-    S.q[i] += h * S.qd[i];
+    S.qd[i] = fma(h, rhs[i], S.qd[i]);
+    S.q[i] = fma(h, S.qd[i], S.q[i]);
     S.warm[i] = a[i]; });
 }
 
@@ -449,22 +650,23 @@ MCG_DEV void robot_substep(const mcg_model* __restrict__ P, Robot& S, real* qlag
 // EEF site pose and its 6x6 Jacobian at arm angles q6 (mj_kinematics + mj_jacSite for site EEF, P1/P11).
 struct EefPose { real pos[3], mat[9], jacp[3][6], jacr[3][6]; };
 
-MCG_DEV void eef_forward(const mcg_model* __restrict__ P, const real* q6, EefPose& E, bool want_jac) {
+MCG_DEV void eef_forward(ModelPtr P, const real* q6, EefPose& E, bool want_jac) {
   real R[9], p[3], anchor[6][3], axis[6][3];
+  const TrigC T = load_trig();
   for (int k = 0; k < 9; k++) R[k] = P->base_mat[k];
   for (int k = 0; k < 3; k++) p[k] = P->base_pos[k];
   static_for<6>([&](auto I) {
     constexpr int i = I; constexpr int K = AXK[i]; constexpr int A = (K + 1) % 3, B = (K + 2) % 3;
-    const real* r = P->r[i];
+    real r[3]; ldc<3>(P->body[i].r, r);
     for (int k = 0; k < 3; k++) p[k] += R[3 * k] * r[0] + R[3 * k + 1] * r[1] + R[3 * k + 2] * r[2];
     for (int k = 0; k < 3; k++) { anchor[i][k] = p[k]; axis[i][k] = AXS[i] * R[3 * k + K]; }
-    real s, c; sincos(AXS[i] * q6[i], &s, &c);
+    real s, c; sincos_cw(T, AXS[i] * q6[i], s, c);
     for (int k = 0; k < 3; k++) {      // R <- R * Rot(e_K, theta): mixes columns A and B
       real ca = R[3 * k + A], cb = R[3 * k + B];
       R[3 * k + A] = c * ca + s * cb; R[3 * k + B] = -s * ca + c * cb;
     }
   });
-  const real* se = P->site_eef;
+  real se[3]; ldc<3>(P->site_eef, se);
   for (int k = 0; k < 3; k++) E.pos[k] = p[k] + R[3 * k] * se[0] + R[3 * k + 1] * se[1] + R[3 * k + 2] * se[2];
   for (int k = 0; k < 9; k++) E.mat[k] = R[k];
   if (want_jac) {

@@ -52,48 +52,58 @@ struct Env {            // one lane's working set
   Robot R;
   real qlag6[6], goal[3], epret;
   int32_t elapsed, episode, eplen;
-  uint32_t draw;
 };
 
 // ------------------------------------------------------------------------------------------------- sampling
-__device__ void rng_pair(const Cfg& C, int i, Env& E, uint32_t stream, real& u0, real& u1) {
+__device__ void rng_pair(const Cfg& C, int i, int32_t episode, uint32_t draw, uint32_t stream, real& u0, real& u1) {
   unsigned long long gid = (unsigned long long)(C.env_id_offset + i);
   uint32_t r[4];
-  philox4x32_10((uint32_t)gid, (uint32_t)E.episode, E.draw++, stream ^ ((uint32_t)(gid >> 32) << 8),
+  philox4x32_10((uint32_t)gid, (uint32_t)episode, draw, stream ^ ((uint32_t)(gid >> 32) << 8),
                 (uint32_t)C.seed, (uint32_t)(C.seed >> 32), r);
   u0 = (real)((((unsigned long long)r[0] << 32) | r[1]) >> 11) * (1.0 / 9007199254740992.0);
   u1 = (real)((((unsigned long long)r[2] << 32) | r[3]) >> 11) * (1.0 / 9007199254740992.0);
 }
 
-// _sample_goal (mycobot.py:238-243) with generate_random_point_inside_rectangle (utils.py:14-21)
-__device__ void sample_goal(const Cfg& C, int i, Env& E, real* g) {
+// _sample_goal (mycobot.py:238-243) with generate_random_point_inside_rectangle (utils.py:14-21); uses draws d, d+1
+__device__ void sample_goal(const Cfg& C, int i, int32_t episode, uint32_t draw, real* g) {
   real ux, uy, uc, uz;
-  rng_pair(C, i, E, 0, ux, uy);
-  rng_pair(C, i, E, 0, uc, uz);
+  rng_pair(C, i, episode, draw, 0, ux, uy);
+  rng_pair(C, i, episode, draw + 1, 0, uc, uz);
   // a + (b - a) * u as one explicit fma: rounds identically on the CPU oracle and here
   g[0] = fma(0.12 - -0.12, ux, -0.12);
   g[1] = fma(0.06 - -0.06, uy, -0.06);
-  g[2] = C.height_offset;
-  if (C.target_in_the_air && uc < 0.5) g[2] = fma(0.1 - 0.0, uz, C.height_offset);
+  const real air = fma(0.1 - 0.0, uz, C.height_offset);
+  g[2] = (C.target_in_the_air && uc < 0.5) ? air : C.height_offset;
 }
 
-// reset_model (mycobot.py:207-236), Reach: the object position stays the initial gripper xy
-__device__ void reset_env(const Cfg& C, int i, Env& E) {
-  E.draw = 0;
-  for (int k = 0; k < NB; k++) { E.R.q[k] = C.init_qpos[k]; E.R.qd[k] = C.init_qvel[k]; }
-  for (int k = 0; k < 7; k++) E.R.ctrl[k] = C.init_ctrl[k];
-  real ox = C.igx[0], oy = C.igx[1];
+// reset_model (mycobot.py:207-236), Reach: the object position stays the initial gripper xy.
+// Every lane of the wave computes a fresh episode; it is committed where `doit`.  The rejection loop is
+// wave-uniform (__any) with per-lane selects -- see the compiler hazard note in mcg_dynamics.hpp.
+__device__ void reset_env(const Cfg& C, int i, Env& E, bool doit) {
+  const real ox = C.igx[0], oy = C.igx[1];
+  real goal[3] = {0, 0, 0};
+  uint32_t draw = 0;
+  bool need = true;
   int tries = 0;
-  sample_goal(C, i, E, E.goal);
-  while (sqrt((E.goal[0] - ox) * (E.goal[0] - ox) + (E.goal[1] - oy) * (E.goal[1] - oy)) < 0.1 && tries++ < 1000)
-    sample_goal(C, i, E, E.goal);
-  for (int k = 0; k < 6; k++) E.qlag6[k] = E.R.q[k];
-  E.elapsed = 0; E.epret = 0; E.eplen = 0;
-  E.episode++;
+  do {
+    real g[3];
+    sample_goal(C, i, E.episode, draw, g);
+    const bool rej = sqrt((g[0] - ox) * (g[0] - ox) + (g[1] - oy) * (g[1] - oy)) < 0.1;
+    for (int k = 0; k < 3; k++) goal[k] = need ? g[k] : goal[k];
+    draw += need ? 2u : 0u;
+    need = need && rej && (tries < 1000);
+    tries++;
+  } while (__any(need));
+  for (int k = 0; k < NB; k++) { E.R.q[k] = doit ? C.init_qpos[k] : E.R.q[k]; E.R.qd[k] = doit ? C.init_qvel[k] : E.R.qd[k]; }
+  for (int k = 0; k < 7; k++) E.R.ctrl[k] = doit ? C.init_ctrl[k] : E.R.ctrl[k];
+  for (int k = 0; k < 6; k++) E.qlag6[k] = doit ? C.init_qpos[k] : E.qlag6[k];
+  for (int k = 0; k < 3; k++) E.goal[k] = doit ? goal[k] : E.goal[k];
+  E.elapsed = doit ? 0 : E.elapsed; E.epret = doit ? 0.0 : E.epret; E.eplen = doit ? 0 : E.eplen;
+  E.episode += doit ? 1 : 0;
 }
 
 // _get_obs / generate_mujoco_observations for Reach (mycobot.py:245-283, 342-388): 10 numbers
-__device__ void observe_reach(const Cfg& C, const mcg_model* __restrict__ P, const Env& E, real* obs, real* ag) {
+__device__ void observe_reach(const Cfg& C, ModelPtr P, const Env& E, real* obs, real* ag) {
   EefPose X;
   eef_forward(P, E.qlag6, X, true);
   for (int k = 0; k < 3; k++) {
@@ -111,7 +121,6 @@ __device__ void load_env(const View& V, int i, Env& E) {
   for (int k = 0; k < 6; k++) E.qlag6[k] = V.qlag(k, i);
   for (int k = 0; k < 3; k++) E.goal[k] = V.goal(k, i);
   E.epret = V.epret(i); E.elapsed = V.elapsed(i); E.episode = V.episode(i); E.eplen = V.eplen(i);
-  E.draw = 0;
 }
 __device__ void store_env(const View& V, int i, const Env& E) {
   for (int k = 0; k < NB; k++) { V.qpos(k, i) = E.R.q[k]; V.qvel(k, i) = E.R.qd[k]; V.warm(k, i) = E.R.warm[k]; }
@@ -130,8 +139,11 @@ __device__ void write_obs(const mcg_step_out& O, int i, int D, const real* obs, 
 // ------------------------------------------------------------------------------------------------ step kernel
 // MyCobotEnv.step (mycobot.py:132-205) for Reach, controller = joint | IK.
 template <int CONTROLLER>
-__global__ __launch_bounds__(64) void step_reach_kernel(Cfg C, View V, const mcg_model* __restrict__ P,
+__global__ __launch_bounds__(64) void step_reach_kernel(Cfg C, View V, const mcg_model* __restrict__ Pg,
                                                         const float* __restrict__ actions, mcg_step_out O) {
+  __shared__ real lds[LDS_SLOTS][64];
+  const LaneScratch MS{&lds[0][threadIdx.x]};
+  const ModelPtr P = as_model_ptr(Pg);
   const int i = blockIdx.x * 64 + threadIdx.x;
   if (i >= C.n) return;
   Env E;
@@ -157,11 +169,11 @@ __global__ __launch_bounds__(64) void step_reach_kernel(Cfg C, View V, const mcg
       ik_delta(X, tpos, tquat, dq);
       for (int k = 0; k < 6; k++) E.R.ctrl[k] += dq[k];
       E.R.ctrl[6] = grip;
-      for (int s = 0; s < C.frame_skip; s++) robot_substep(P, E.R, E.qlag6);
+      for (int s = 0; s < C.frame_skip; s++) robot_substep(P, E.R, E.qlag6, MS);
     }
   } else {
     for (int k = 0; k < 7; k++) E.R.ctrl[k] = (real)act[k];
-    for (int s = 0; s < C.frame_skip; s++) robot_substep(P, E.R, E.qlag6);
+    for (int s = 0; s < C.frame_skip; s++) robot_substep(P, E.R, E.qlag6, MS);
   }
 
   real obs[10], ag[3];
@@ -179,28 +191,34 @@ __global__ __launch_bounds__(64) void step_reach_kernel(Cfg C, View V, const mcg
   if (O.is_success) O.is_success[i] = succ;
   if (O.ep_return) O.ep_return[i] = E.epret;
   if (O.ep_length) O.ep_length[i] = E.eplen;
-  if ((term || trunc) && C.auto_reset) {
-    if (O.final_obs) for (int k = 0; k < 10; k++) O.final_obs[(size_t)i * 10 + k] = obs[k];
-    if (O.final_achieved) for (int k = 0; k < 3; k++) O.final_achieved[(size_t)i * 3 + k] = ag[k];
-    if (O.final_desired) for (int k = 0; k < 3; k++) O.final_desired[(size_t)i * 3 + k] = E.goal[k];
-    reset_env(C, i, E);
-    observe_reach(C, P, E, obs, ag);
+  const bool done = (term || trunc) && C.auto_reset;
+  if (__any(done)) {                       // wave-uniform; per-lane effects are predicated on `done`
+    if (done) {                            // plain stores of live registers only
+      if (O.final_obs) for (int k = 0; k < 10; k++) O.final_obs[(size_t)i * 10 + k] = obs[k];
+      if (O.final_achieved) for (int k = 0; k < 3; k++) O.final_achieved[(size_t)i * 3 + k] = ag[k];
+      if (O.final_desired) for (int k = 0; k < 3; k++) O.final_desired[(size_t)i * 3 + k] = E.goal[k];
+    }
+    reset_env(C, i, E, done);
+    real obs2[10], ag2[3];
+    observe_reach(C, P, E, obs2, ag2);
+    for (int k = 0; k < 10; k++) obs[k] = done ? obs2[k] : obs[k];
+    for (int k = 0; k < 3; k++) ag[k] = done ? ag2[k] : ag[k];
   }
   write_obs(O, i, 10, obs, ag, E.goal);
   store_env(V, i, E);
 }
 
-__global__ __launch_bounds__(64) void reset_reach_kernel(Cfg C, View V, const mcg_model* __restrict__ P,
+__global__ __launch_bounds__(64) void reset_reach_kernel(Cfg C, View V, const mcg_model* __restrict__ Pg,
                                                          const uint8_t* __restrict__ mask, int reseed, mcg_step_out O) {
   const int i = blockIdx.x * 64 + threadIdx.x;
   if (i >= C.n) return;
+  const ModelPtr P = as_model_ptr(Pg);
   Env E;
   load_env(V, i, E);
-  if (!mask || mask[i]) {
-    if (reseed) E.episode = 0;
-    reset_env(C, i, E);
-    store_env(V, i, E);
-  }
+  const bool doit = !mask || mask[i];
+  E.episode = (doit && reseed) ? 0 : E.episode;
+  reset_env(C, i, E, doit);
+  store_env(V, i, E);
   real obs[10], ag[3];
   observe_reach(C, P, E, obs, ag);
   write_obs(O, i, 10, obs, ag, E.goal);
@@ -257,6 +275,13 @@ int mcg_create(const mcg_config* c, const mcg_model* model, int device, mcg_env*
   if (c->controller == MCG_CTRL_JOINT && c->fetch_env) return fail(MCG_ERR_ARG, "Joint controller not supported for Fetch env%s");  // mycobot.py:96
   if (c->reward_type == MCG_REWARD_SHAPING) return fail(MCG_ERR_UNSUPPORTED, "mcg_create: reward_shaping needs the contact stage (not built yet)%s");
   if (c->reward_type != MCG_REWARD_SPARSE && c->reward_type != MCG_REWARD_DENSE) return fail(MCG_ERR_ARG, "mcg_create: bad reward_type%s");
+  {
+    const mcg_model* mm = model ? model : &kDefaultModels[0];
+    bool ok = true;
+    for (int k = 0; k < 12; k++) ok = ok && (mm->limit_par[k][6] == 1.0 || mm->limit_par[k][6] == 2.0);
+    for (int k = 0; k < 3; k++) ok = ok && (mm->eq_par[k][6] == 1.0 || mm->eq_par[k][6] == 2.0);
+    if (!ok) return fail(MCG_ERR_UNSUPPORTED, "mcg_create: solimp power must be 1 or 2 (the MJCF default is 2)%s");
+  }
   if (c->frame_skip <= 0 || c->control_steps <= 0 || c->max_episode_steps <= 0) return fail(MCG_ERR_ARG, "mcg_create: frame_skip, control_steps, max_episode_steps must be positive%s");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(MCG_ERR_HIP, "mcg_create: no HIP device (this engine has no CPU path)%s");

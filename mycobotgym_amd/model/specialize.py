@@ -27,6 +27,8 @@ NB_ROBOT = 12
 MOVING = ["link1", "link2", "link3", "link4", "link5", "link6", "right_gear_link", "right_finger_link",
           "left_gear_link", "left_finger_link", "right_hinge_link", "left_hinge_link"]
 PARENT = [-1, 0, 1, 2, 3, 4, 5, 6, 5, 8, 5, 5]
+AXIS_K = [2, 0, 0, 0, 2, 0, 1, 1, 1, 1, 1, 1]          # must match AXK / AXS in csrc/mcg_dynamics.hpp
+AXIS_S = [-1.0, -1.0, 1.0, -1.0, -1.0, -1.0, 1.0, -1.0, -1.0, 1.0, 1.0, 1.0]
 MINIMP, MAXIMP, MINVAL = 1e-4, 0.9999, 1e-15
 
 
@@ -37,7 +39,7 @@ def _axis_code(ax):
 
 
 def _solparams(solref, solimp, timestep):
-    """(K, B, d0, dmax, width, midpoint, power) with refsafe and the solimp clamps applied."""
+    """(K, B, d0, dmax, width, midpoint, power, 1/width, 1/mid^(p-1), 1/(1-mid)^(p-1)); refsafe + solimp clamps applied."""
     tc, damp = float(solref[0]), float(solref[1])
     d0, dmax, width, mid, power = [float(x) for x in solimp]
     d0 = min(max(d0, MINIMP), MAXIMP); dmax = min(max(dmax, MINIMP), MAXIMP)
@@ -49,7 +51,8 @@ def _solparams(solref, solimp, timestep):
     else:
         K = -tc / max(MINVAL, dmax * dmax)
         B = -damp / max(MINVAL, dmax)
-    return [K, B, d0, dmax, width, mid, power]
+    invw = 1.0 / width if width > MINVAL else 0.0
+    return [K, B, d0, dmax, width, mid, power, invw, 1.0 / mid ** (power - 1), 1.0 / (1 - mid) ** (power - 1)]
 
 
 def mix_contact(m, g1, g2):
@@ -120,6 +123,7 @@ def specialize(m: dict) -> dict:
                 stack.append((ch, Rch, pos + R @ np.asarray(m["body_pos"][ch])))
         inertia[i] = [I[0, 0], I[1, 1], I[2, 2], I[0, 1], I[0, 2], I[1, 2]]
     out.update(r=r, mass=mass, mc=mc, inertia=inertia, axis_k=axis_k, axis_s=axis_s)
+    assert axis_k == AXIS_K and axis_s == AXIS_S, "joint axes differ from the structure compiled into the kernels"
     # structural facts the kernels rely on
     assert [axis_k[i] for i in range(6, 12)] == [1] * 6, "gripper joints must all turn about local y"
 
@@ -128,8 +132,13 @@ def specialize(m: dict) -> dict:
     arm = np.zeros(18); damp = np.zeros(18)
     arm[:nv] = m["dof_armature"]; damp[:nv] = m["dof_damping"]
     out["armature"] = arm; out["damping"] = damp
+    body = np.zeros((13, 16))         # mcg_body rows: r(3) mass mc(3) inertia(6) armature damping pad
+    body[:, 0:3] = r; body[:, 3] = mass; body[:, 4:7] = mc; body[:, 7:13] = inertia
+    body[:12, 13] = arm[:12]; body[:12, 14] = damp[:12]
+    out["body"] = body
+    out["cube_damping"] = damp[12:18]
     rng = np.zeros((12, 2)); limited = []
-    lim_par = np.zeros((12, 7))
+    lim_par = np.zeros((12, 10))
     for i in range(12):
         j = [jj for jj in range(m["njnt"]) if m["jnt_body"][jj] == ids[i]][0]
         assert m["jnt_dofadr"][j] == i and m["jnt_qposadr"][j] == i

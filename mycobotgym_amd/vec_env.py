@@ -134,7 +134,8 @@ class MyCobotVecEnv:
         self.observation_space = Dict({k: batch_box(v, self.num_envs) for k, v in self.single_observation_space.spaces.items()})
 
         n, D, dev = self.num_envs, self.obs_dim, self.device
-        f64 = dict(dtype=torch.float64, device=dev); u8 = dict(dtype=torch.uint8, device=dev)
+        # flags are torch.bool buffers the kernel fills with 0/1 bytes: no conversion kernels on the step path
+        f64 = dict(dtype=torch.float64, device=dev); u8 = dict(dtype=torch.bool, device=dev)
         self._buf = {
             "obs": torch.zeros(n, D, **f64), "achieved_goal": torch.zeros(n, 3, **f64),
             "desired_goal": torch.zeros(n, 3, **f64), "reward": torch.zeros(n, **f64),
@@ -180,14 +181,21 @@ class MyCobotVecEnv:
         with torch.cuda.device(self.device):
             _abi.check(self._lib.mcg_step(self._h, C.c_void_p(a.data_ptr()), C.byref(self._out), self._stream()), "mcg_step")
         b = self._buf
-        terminated, truncated = b["terminated"].bool(), b["truncated"].bool()
-        done = terminated | truncated
-        info = {"is_success": b["is_success"].bool(),
+        terminated, truncated = b["terminated"], b["truncated"]
+        done = truncated          # truncated = is_success | time-limit, so it already covers terminated (D-4)
+        info = {"is_success": b["is_success"],
                 "final_observation": {"observation": b["final_obs"], "achieved_goal": b["final_achieved"],
                                       "desired_goal": b["final_desired"]},
                 "_final_observation": done,
                 "episode": {"r": b["ep_return"], "l": b["ep_length"]}, "_episode": done}
         return self._obs(), b["reward"], terminated, truncated, info
+
+    def step_async(self, actions: torch.Tensor) -> dict:
+        """Launch one step on the current stream and return the raw output buffers (no Python-side packaging).
+        `actions` must already be a contiguous float32 [N, A] tensor on this device."""
+        with torch.cuda.device(self.device):
+            _abi.check(self._lib.mcg_step(self._h, C.c_void_p(actions.data_ptr()), C.byref(self._out), self._stream()), "mcg_step")
+        return self._buf
 
     def compute_reward(self, achieved_goal, desired_goal, info=None):
         """Batched GoalEnv reward (mycobot.py:289-298); sparse is returned as float32 like the reference."""

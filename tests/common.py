@@ -80,6 +80,8 @@ def step_errors(envs, ora, actions):
     e = np.abs(obs["observation"].cpu().numpy() - o["obs"]).max(axis=1)
     e = np.maximum(e, np.abs(obs["achieved_goal"].cpu().numpy() - o["achieved"]).max(axis=1))
     e = np.maximum(e, np.abs(rew.cpu().numpy() - o["reward"]))
+    # goals come from the Philox reset draws: they must agree bit for bit, also right after an auto-reset
+    assert np.array_equal(obs["desired_goal"].cpu().numpy(), o["desired"]), "desired_goal differs (reset draws)"
     flags_equal = (np.array_equal(term.cpu().numpy(), o["terminated"].astype(bool))
                    and np.array_equal(trunc.cpu().numpy(), o["truncated"].astype(bool)))
     return e, flags_equal, o
