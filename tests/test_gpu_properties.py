@@ -1,0 +1,126 @@
+"""GPU: size-independent properties at BASELINE's full size (8192 envs) and API behaviour of the HIP engine."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+N_FULL = 8192
+
+
+@pytest.fixture(scope="module")
+def torch_cuda(built):
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+def _roll(envs, torch, steps, seed=0):
+    g = torch.Generator(device="cuda"); g.manual_seed(seed)
+    outs = []
+    for t in range(steps):
+        a = torch.rand(envs.num_envs, envs.action_dim, device="cuda", generator=g) * 2 - 1
+        obs, rew, term, trunc, info = envs.step(a)
+        outs.append((obs["observation"].clone(), rew.clone(), trunc.clone(), obs["desired_goal"].clone()))
+    return outs
+
+
+@pytest.mark.parametrize("controller", ["joint", "IK"])
+def test_full_size_determinism_and_sanity(torch_cuda, controller):
+    """Two engines, same seed, 8192 envs, 60 steps (crosses the TimeLimit reset): bit-identical; values sane."""
+    torch = torch_cuda
+    from mycobotgym_amd import MyCobotVecEnv
+    runs = []
+    for rep in range(2):
+        envs = MyCobotVecEnv(N_FULL, has_object=False, controller_type=controller, reward_type="dense", seed=11)
+        envs.reset(seed=11)
+        runs.append(_roll(envs, torch, 60 if controller == "joint" else 52))
+        envs.close()
+    for (o1, r1, t1, g1), (o2, r2, t2, g2) in zip(*runs):
+        assert torch.equal(o1, o2) and torch.equal(r1, r2) and torch.equal(t1, t2) and torch.equal(g1, g2)
+    obs, rew, trunc, goal = runs[0][-1]
+    assert torch.isfinite(obs).all() and (rew <= 0).all()
+    assert (obs[:, :3].abs() < 1.0).all()                         # the gripper stays within the arm's reach
+    assert runs[0][49][2].all()                                   # TimeLimit(50): every env truncates at step 50
+    assert (goal[:, 0].abs() <= 0.12).all() and (goal[:, 1].abs() <= 0.06).all()
+
+
+def test_shard_invariance(torch_cuda):
+    """Env i of an 8192-env engine == env 0.. of a small engine created with env_id_offset = i (global-id RNG keys,
+    no cross-env coupling): the multi-GPU sharding rule, checked on one GPU."""
+    torch = torch_cuda
+    from mycobotgym_amd import MyCobotVecEnv
+    big = MyCobotVecEnv(N_FULL, has_object=False, controller_type="joint", reward_type="dense", seed=3)
+    off, n = 5000, 192
+    small = MyCobotVecEnv(n, has_object=False, controller_type="joint", reward_type="dense", seed=3, env_id_offset=off)
+    ob, _ = big.reset(seed=3); os_, _ = small.reset(seed=3)
+    assert torch.equal(ob["desired_goal"][off:off + n], os_["desired_goal"])
+    g = torch.Generator(device="cuda"); g.manual_seed(1)
+    for t in range(55):
+        a = torch.rand(N_FULL, 7, device="cuda", generator=g) * 2 - 1
+        ob, rb, _, tb, _ = big.step(a); os_, rs, _, ts, _ = small.step(a[off:off + n].contiguous())
+        assert torch.equal(ob["observation"][off:off + n], os_["observation"]) and torch.equal(rb[off:off + n], rs)
+        assert torch.equal(ob["desired_goal"][off:off + n], os_["desired_goal"]) and torch.equal(tb[off:off + n], ts)
+    big.close(); small.close()
+
+
+def test_state_roundtrip_and_api(torch_cuda):
+    torch = torch_cuda
+    from mycobotgym_amd import make
+    envs = make("MyCobotReach-Sparse-joint-v0", num_envs=300)
+    with pytest.raises(RuntimeError, match="before calling env.reset"):
+        envs.step(torch.zeros(300, 7))
+    obs, info = envs.reset(seed=0)
+    assert set(obs) == {"observation", "achieved_goal", "desired_goal"} and info == {}
+    assert obs["observation"].shape == (300, 10) and obs["observation"].dtype == torch.float64
+    assert envs.single_action_space.shape == (7,) and envs.action_space.shape == (300, 7)
+    with pytest.raises(ValueError):
+        envs.step(torch.zeros(300, 6))
+    obs, rew, term, trunc, info = envs.step(np.zeros((300, 7), np.float32))       # numpy actions are accepted
+    assert rew.shape == (300,) and term.dtype == torch.bool and set(torch.unique(rew).tolist()) <= {-1.0, 0.0}
+    assert {"is_success", "final_observation", "_final_observation", "episode"} <= set(info)
+    s = envs.get_state()
+    assert s["qpos"].shape == (12, 300) and s["elapsed"].eq(1).all()
+    s2 = {k: v.clone() for k, v in s.items()}; s2["qpos"] += 0.01
+    envs.set_state(**s2)
+    assert torch.equal(envs.get_state()["qpos"], s2["qpos"])
+    envs.load_state_dict(s)
+    assert all(torch.equal(envs.state_dict()[k], s[k]) for k in s)
+    # actions outside [-1, 1] are clipped (mycobot.py:133)
+    envs.load_state_dict(s); o1 = envs.step(torch.full((300, 7), 5.0))[0]["observation"].clone()
+    envs.load_state_dict(s); o2 = envs.step(torch.full((300, 7), 1.0))[0]["observation"].clone()
+    assert torch.equal(o1, o2)
+    envs.close()
+
+
+def test_masked_reset(torch_cuda):
+    torch = torch_cuda
+    from mycobotgym_amd import MyCobotVecEnv
+    envs = MyCobotVecEnv(128, has_object=False, controller_type="joint", reward_type="dense", seed=2)
+    envs.reset(seed=2)
+    for _ in range(3):
+        envs.step(torch.rand(128, 7, device="cuda") * 2 - 1)
+    before = envs.get_state()
+    mask = torch.zeros(128, dtype=torch.bool, device="cuda"); mask[::4] = True
+    envs.reset(mask=mask)
+    after = envs.get_state()
+    assert after["elapsed"][mask].eq(0).all() and after["elapsed"][~mask].eq(3).all()
+    assert torch.equal(after["qpos"][:, ~mask], before["qpos"][:, ~mask]) and after["qpos"][:, mask].eq(0).all()
+    assert after["episode"][mask].eq(2).all() and after["episode"][~mask].eq(1).all()
+    envs.close()
+
+
+def test_exact_mesh_variant_and_fetch(torch_cuda):
+    """Model variants share the binary: exact mesh inertia; fetch keyframe with the fixed target quaternion."""
+    from tests.common import make_pair, sync_oracle_to, step_errors
+    rng = np.random.default_rng(0)
+    for kw in (dict(controller_type="joint", mesh_inertia="exact"), dict(controller_type="IK", fetch_env=True)):
+        envs, ora = make_pair(128, reward_type="dense", seed=4, **kw)
+        o_hip, _ = envs.reset(seed=4); o_ora = ora.reset(seed=4)
+        assert np.abs(o_hip["observation"].cpu().numpy() - o_ora[0]).max() < 1e-12
+        assert envs.action_dim == (4 if kw.get("fetch_env") else 7)
+        errs = []
+        for t in range(10):
+            sync_oracle_to(envs, ora)
+            e, flags, _ = step_errors(envs, ora, rng.uniform(-1, 1, (128, envs.action_dim)).astype(np.float32))
+            assert flags; errs.append(e)
+        assert np.median(np.concatenate(errs)) < 1e-9
+        envs.close()
