@@ -32,10 +32,14 @@ FP64_VECTOR_PEAK_TFLOPS = 78.6  # [RECALL, AMD datasheet]; the guide lists no FP
 
 
 def cpu_baseline(controller: str, budget_envs: int, steps: int):
-    """The CPU oracle (kind "port": this repo's C restatement, NOT MuJoCo) on all host cores, bounded sample."""
+    """The CPU oracle (kind "port": this repo's C restatement, NOT MuJoCo) on the host cores this job may use."""
     import numpy as np
     from tests.common import make_oracle
-    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = min(cores, 16)     # a one-GPU box's CPU share is 16 cores
     ora = make_oracle(budget_envs, controller_type=controller, reward_type="dense", seed=0, n_threads=cores)
     ora.reset(seed=0)
     rng = np.random.default_rng(0)
@@ -91,21 +95,23 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
+        # HIP events on the launch stream (mcg_step enqueues on torch's current stream, so torch events see it)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
+        ev0.record()
         for t in range(steps):
             envs.step_async(pool[t % 16])
+        ev1.record()
         torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
         dt = time.perf_counter() - t0
+        kernel_ms = ev0.elapsed_time(ev1) / steps      # average launch-to-launch duration over the timed region
         if world > 1:
             tt = torch.tensor([dt], dtype=torch.float64, device=dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
-        # kernel-only duration on the launch stream with HIP events (roofline leg)
-        ms = envs.time_steps(pool[0], min(steps, 200))
-        kernel_ms = ms / min(steps, 200)
         # logging path: episode statistics reduced over ranks with RCCL, off the timed region
         b = envs._buf
         stats = torch.stack([b["ep_return"].sum(), b["ep_length"].double().sum(), b["is_success"].double().sum()])
@@ -150,7 +156,7 @@ def main():
             out["secondary"] = {"controller": other, "env_steps_per_sec": n * max(K // 5, 20) / dt2, "kernel_ms": k2,
                                 "physics_substeps_per_sec": n * max(K // 5, 20) / dt2 * (100 if other == "IK" else 20)}
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(args.controller, 2048, 20)
+            out["cpu_baseline"] = cpu_baseline(args.controller, 8192, 40)
         out["episode_stats"] = {"sum_return": stats[0], "sum_length": stats[1], "sum_success": stats[2]}
         print(json.dumps(out), flush=True)
     if world > 1:

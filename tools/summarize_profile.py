@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Condense the rocprofv3 outputs of tools/profile_r.sh into profiles/<tag>_summary.{json,md} and profiles/pmc_latest.json.
+
+FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE under-reports wide coalesced reads by exactly 2x
+(MI355X_MICROARCH.md, HBM section), so read bytes are reported both raw and x2-corrected.
+"""
+import csv, glob, json, os, statistics, sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+src = os.path.join(root, "gpurun_out", tag)
+KERNEL = "step_reach_kernel<0>"
+
+
+def rows(pattern):
+    out = []
+    for f in glob.glob(os.path.join(src, pattern)):
+        out += list(csv.DictReader(open(f)))
+    return out
+
+
+summary = {"tag": tag, "kernel": KERNEL}
+kt = [r for r in rows("stats/*/*_kernel_trace.csv") if KERNEL in r["Kernel_Name"]]
+dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in kt]
+summary["kernel_trace"] = {"launches": len(dur), "avg_us": statistics.mean(dur), "median_us": statistics.median(dur),
+                           "min_us": min(dur), "max_us": max(dur), "vgpr": int(kt[0]["VGPR_Count"]),
+                           "agpr": int(kt[0]["Accum_VGPR_Count"]), "sgpr": int(kt[0]["SGPR_Count"]),
+                           "scratch_bytes_per_lane": int(kt[0]["Scratch_Size"]), "lds_bytes_per_wg": int(kt[0]["LDS_Block_Size"]),
+                           "grid": int(kt[0]["Grid_Size_X"]), "workgroup": int(kt[0]["Workgroup_Size_X"])}
+stats = [r for r in rows("stats/*/*_kernel_stats.csv")]
+summary["kernel_stats_top"] = [{"name": r["Name"][:90], "calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]),
+                                "pct": float(r["Percentage"])} for r in stats[:4]]
+counters = {}
+for d in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2"):
+    for r in rows(f"{d}/*/*_counter_collection.csv"):
+        if KERNEL in r["Kernel_Name"]:
+            counters.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+summary["counters_avg_per_launch"] = {k: statistics.mean(v) for k, v in counters.items()}
+c = summary["counters_avg_per_launch"]
+n_envs = summary["kernel_trace"]["grid"]
+if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+    rd_raw, wr = c["FETCH_SIZE"] * 1024, c["WRITE_SIZE"] * 1024
+    summary["hbm"] = {"read_bytes_raw": rd_raw, "read_bytes_x2_corrected": 2 * rd_raw, "write_bytes": wr,
+                      "bytes_per_launch_corrected": 2 * rd_raw + wr, "bytes_per_env_step_corrected": (2 * rd_raw + wr) / n_envs,
+                      "algorithmic_bytes_per_env_step": 939}
+if "SQ_INSTS_VALU" in c and "SQ_WAVES" in c:
+    waves = c["SQ_WAVES"]
+    summary["per_wave"] = {k: c[k] / waves for k in c if k.startswith("SQ_") and k != "SQ_WAVES"}
+    summary["per_wave"]["waves"] = waves
+os.makedirs(os.path.join(root, "profiles"), exist_ok=True)
+json.dump(summary, open(os.path.join(root, "profiles", f"{tag}_summary.json"), "w"), indent=1)
+if "hbm" in summary:
+    json.dump({"controller": "joint", "n_envs": n_envs, "hbm_bytes_per_launch": summary["hbm"]["bytes_per_launch_corrected"],
+               "note": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH_SIZE x2 (gfx950), tag {tag}"},
+              open(os.path.join(root, "profiles", "pmc_latest.json"), "w"), indent=1)
+print(json.dumps(summary, indent=1))
