@@ -1,12 +1,230 @@
 /*
  * ORACLE -- TEST INFRASTRUCTURE ONLY (see mco_physics.h).
  *
- * P4 `mj_collision` for the box geoms of the PickAndPlace scene (cube, table top, finger pads).
- * Placeholder in this revision: the free-space (Reach) configs run with enable_contact = 0.
+ * P4 `mj_collision` restated for the primitive geoms of the PickAndPlace scene: the cube, the table box, the two
+ * finger-pad boxes and the ground plane (/root/reference/mycobotgym/envs/assets/mycobot280_main.xml:81,87,195-199,
+ * 222-225,262).  The 28 mesh geoms (convex hulls in MuJoCo) are outside this build's scope and never
+ * produce contacts here.
+ *
+ * Pair filter [RECALL mj_collision]: both geoms' bodies welded to the world -> skip; same weld body -> skip;
+ * parent-child weld bodies -> skip unless the parent is the world; `<exclude>` pairs -> skip;
+ * (contype1 & conaffinity2) | (contype2 & conaffinity1) must be non-zero; bounding-sphere rejection.
+ * Pair parameters [RECALL mj_contactParam]: condim = max, friction = element-wise max, solref = mean if both
+ * time constants are positive else element-wise min, solimp = mean, margin = gap = 0.
+ *
+ * Narrow phase.  MuJoCo's own mjc_BoxBox / mjc_PlaneBox are restated by their published behaviour, not line by
+ * line: plane-box reports every box vertex below the plane; box-box is the classic separating-axis test over the
+ * 15 axes followed by clipping of the incident face against the reference face (face contact, up to 8 points) or
+ * the closest points of the two edges (edge contact, 1 point).  Contact position = midpoint between the two
+ * surfaces, frame x axis = normal from geom1 to geom2, dist < 0 = penetration; only dist < margin (= 0) is kept.
+ * The HIP kernel implements exactly this procedure and is checked against it.
  */
 #include "mco_physics.h"
 
+#include <math.h>
+#include <string.h>
+
+static double dot3(const double* a, const double* b) { return a[0]*b[0] + a[1]*b[1] + a[2]*b[2]; }
+static void cross3(double* r, const double* a, const double* b) {
+  double x = a[1]*b[2] - a[2]*b[1], y = a[2]*b[0] - a[0]*b[2], z = a[0]*b[1] - a[1]*b[0];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+static void col(const double* M, int k, double* v) { v[0] = M[k]; v[1] = M[3 + k]; v[2] = M[6 + k]; }
+
+/* mju_makeFrame [RECALL]: complete a unit normal to a right-handed orthonormal frame (rows of `frame`) */
+static void make_frame(double* frame) {
+  double* n = frame; double* t1 = frame + 3; double* t2 = frame + 6;
+  double tmp[3] = { 0, 0, 0 };
+  if (n[1] < 0.5 && n[1] > -0.5) tmp[1] = 1; else tmp[2] = 1;
+  double d = dot3(n, tmp);
+  for (int k = 0; k < 3; k++) t1[k] = tmp[k] - d * n[k];
+  double l = sqrt(dot3(t1, t1));
+  for (int k = 0; k < 3; k++) t1[k] /= l;
+  cross3(t2, n, t1);
+}
+
+static void mix_params(const mco_model* m, int g1, int g2, mco_contact* c) {
+  c->dim = m->geom_condim[g1] > m->geom_condim[g2] ? m->geom_condim[g1] : m->geom_condim[g2];
+  double f[3];
+  for (int k = 0; k < 3; k++) f[k] = fmax(m->geom_friction[g1][k], m->geom_friction[g2][k]);
+  c->friction[0] = c->friction[1] = f[0]; c->friction[2] = f[1]; c->friction[3] = c->friction[4] = f[2];
+  if (m->geom_solref[g1][0] > 0 && m->geom_solref[g2][0] > 0)
+    for (int k = 0; k < 2; k++) c->solref[k] = 0.5 * (m->geom_solref[g1][k] + m->geom_solref[g2][k]);
+  else
+    for (int k = 0; k < 2; k++) c->solref[k] = fmin(m->geom_solref[g1][k], m->geom_solref[g2][k]);
+  for (int k = 0; k < 5; k++) c->solimp[k] = 0.5 * (m->geom_solimp[g1][k] + m->geom_solimp[g2][k]);
+  c->includemargin = 0;
+}
+
+static void add_contact(const mco_model* m, mco_data* d, int g1, int g2, const double* pos, const double* normal, double dist) {
+  if (!(dist < 0) || d->ncon >= MCO_MAXCON) return;
+  mco_contact* c = &d->contact[d->ncon++];
+  memset(c, 0, sizeof(*c));
+  c->geom1 = g1; c->geom2 = g2; c->dist = dist;
+  memcpy(c->pos, pos, 3 * sizeof(double));
+  memcpy(c->frame, normal, 3 * sizeof(double));
+  make_frame(c->frame);
+  mix_params(m, g1, g2, c);
+}
+
+/* ------------------------------------------------------------------------------------- plane - box */
+static void plane_box(const mco_model* m, mco_data* d, int gp, int gb) {
+  double n[3]; col(d->geom_xmat[gp], 2, n);
+  const double* pp = d->geom_xpos[gp]; const double* pb = d->geom_xpos[gb]; const double* R = d->geom_xmat[gb];
+  const double* h = m->geom_size[gb];
+  for (int v = 0; v < 8; v++) {
+    double loc[3] = { (v & 1 ? h[0] : -h[0]), (v & 2 ? h[1] : -h[1]), (v & 4 ? h[2] : -h[2]) }, w[3];
+    for (int k = 0; k < 3; k++) w[k] = pb[k] + R[3*k]*loc[0] + R[3*k+1]*loc[1] + R[3*k+2]*loc[2];
+    double rel[3] = { w[0] - pp[0], w[1] - pp[1], w[2] - pp[2] };
+    double dist = dot3(rel, n);
+    double pos[3] = { w[0] - 0.5*dist*n[0], w[1] - 0.5*dist*n[1], w[2] - 0.5*dist*n[2] };
+    add_contact(m, d, gp, gb, pos, n, dist);
+  }
+}
+
+/* --------------------------------------------------------------------------------------- box - box */
+#define EDGE_FUDGE 1.05      /* an edge axis must beat the best face axis by 5 % (avoids flicker on parallel faces) */
+
+static void box_box(const mco_model* m, mco_data* d, int ga, int gb) {
+  const double* pa = d->geom_xpos[ga]; const double* pb = d->geom_xpos[gb];
+  const double* Ra = d->geom_xmat[ga]; const double* Rb = d->geom_xmat[gb];
+  const double* ha = m->geom_size[ga]; const double* hb = m->geom_size[gb];
+  double A[3][3], B[3][3], p[3] = { pb[0] - pa[0], pb[1] - pa[1], pb[2] - pa[2] };
+  for (int k = 0; k < 3; k++) { col(Ra, k, A[k]); col(Rb, k, B[k]); }
+  double C[3][3], Q[3][3];              /* C = A^T B, Q = |C| */
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { C[i][j] = dot3(A[i], B[j]); Q[i][j] = fabs(C[i][j]); }
+  double pA[3] = { dot3(A[0], p), dot3(A[1], p), dot3(A[2], p) };      /* p in A's frame */
+  double pB[3] = { dot3(B[0], p), dot3(B[1], p), dot3(B[2], p) };
+  double best = -INFINITY; int code = -1; double nrm[3] = { 0, 0, 0 }; int invert = 0;
+  /* face axes of A, then of B */
+  for (int i = 0; i < 3; i++) {
+    double s = fabs(pA[i]) - (ha[i] + hb[0]*Q[i][0] + hb[1]*Q[i][1] + hb[2]*Q[i][2]);
+    if (s > 0) return;
+    if (s > best) { best = s; code = i; memcpy(nrm, A[i], sizeof(nrm)); invert = pA[i] < 0; }
+  }
+  for (int j = 0; j < 3; j++) {
+    double s = fabs(pB[j]) - (hb[j] + ha[0]*Q[0][j] + ha[1]*Q[1][j] + ha[2]*Q[2][j]);
+    if (s > 0) return;
+    if (s > best) { best = s; code = 3 + j; memcpy(nrm, B[j], sizeof(nrm)); invert = pB[j] < 0; }
+  }
+  /* edge axes A_i x B_j */
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
+    int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+    double expr = pA[i2]*C[i1][j] - pA[i1]*C[i2][j];                  /* p . (A_i x B_j) */
+    double len = sqrt(fmax(0.0, 1 - C[i][j]*C[i][j]));
+    if (len < 1e-9) continue;                                          /* parallel edges: covered by the face axes */
+    double s = (fabs(expr) - (ha[i1]*Q[i2][j] + ha[i2]*Q[i1][j] + hb[j1]*Q[i][j2] + hb[j2]*Q[i][j1])) / len;
+    if (s > 0) return;
+    if (s * EDGE_FUDGE > best) {
+      best = s; code = 6 + 3*i + j;
+      double L[3]; cross3(L, A[i], B[j]);
+      for (int k = 0; k < 3; k++) nrm[k] = L[k] / len;
+      invert = expr < 0;
+    }
+  }
+  if (code < 0) return;
+  double normal[3];                                                    /* from box A (geom1) to box B (geom2) */
+  for (int k = 0; k < 3; k++) normal[k] = invert ? -nrm[k] : nrm[k];
+
+  if (code >= 6) {
+    /* edge-edge: one contact at the midpoint of the closest points of the two supporting edges */
+    int i = (code - 6) / 3, j = (code - 6) % 3;
+    double ea[3], eb[3];
+    for (int k = 0; k < 3; k++) { ea[k] = pa[k]; eb[k] = pb[k]; }
+    for (int a = 0; a < 3; a++) if (a != i) { double sg = dot3(normal, A[a]) > 0 ? 1.0 : -1.0; for (int k = 0; k < 3; k++) ea[k] += sg * ha[a] * A[a][k]; }
+    for (int b = 0; b < 3; b++) if (b != j) { double sg = dot3(normal, B[b]) > 0 ? -1.0 : 1.0; for (int k = 0; k < 3; k++) eb[k] += sg * hb[b] * B[b][k]; }
+    /* closest points of lines ea + s A_i and eb + t B_j */
+    double w[3] = { eb[0] - ea[0], eb[1] - ea[1], eb[2] - ea[2] };
+    double uaub = C[i][j], q1 = dot3(A[i], w), q2 = -dot3(B[j], w), dd = 1 - uaub*uaub;
+    double s = dd <= 1e-12 ? 0 : (q1 + uaub*q2) / dd, t = dd <= 1e-12 ? 0 : (uaub*q1 + q2) / dd;
+    double pos[3];
+    for (int k = 0; k < 3; k++) pos[k] = 0.5 * ((ea[k] + s*A[i][k]) + (eb[k] + t*B[j][k]));
+    add_contact(m, d, ga, gb, pos, normal, best);
+    return;
+  }
+
+  /* face contact: reference box owns the axis, the incident box is clipped against its face */
+  const double (*Rr)[3] = code < 3 ? A : B; const double (*Ri)[3] = code < 3 ? B : A;
+  const double* pr = code < 3 ? pa : pb; const double* pi = code < 3 ? pb : pa;
+  const double* hr = code < 3 ? ha : hb; const double* hi = code < 3 ? hb : ha;
+  int ax = code % 3;
+  double n2[3];                                                        /* reference-face normal, pointing at the incident box */
+  for (int k = 0; k < 3; k++) n2[k] = code < 3 ? normal[k] : -normal[k];
+  /* incident face: the face of the incident box most anti-parallel to n2 */
+  double nr[3] = { dot3(n2, Ri[0]), dot3(n2, Ri[1]), dot3(n2, Ri[2]) };
+  int lan = fabs(nr[0]) > fabs(nr[1]) ? (fabs(nr[0]) > fabs(nr[2]) ? 0 : 2) : (fabs(nr[1]) > fabs(nr[2]) ? 1 : 2);
+  int a1 = (lan + 1) % 3, a2 = (lan + 2) % 3;
+  double center[3];
+  for (int k = 0; k < 3; k++) center[k] = pi[k] - pr[k] + (nr[lan] < 0 ? hi[lan] : -hi[lan]) * Ri[lan][k];
+  int c1 = (ax + 1) % 3, c2 = (ax + 2) % 3;
+  /* incident quad in the 2-D coordinates (c1, c2) of the reference face */
+  double cx = dot3(center, Rr[c1]), cy = dot3(center, Rr[c2]);
+  double m11 = dot3(Rr[c1], Ri[a1]), m12 = dot3(Rr[c1], Ri[a2]), m21 = dot3(Rr[c2], Ri[a1]), m22 = dot3(Rr[c2], Ri[a2]);
+  double k1 = m11*hi[a1], k2 = m21*hi[a1], k3 = m12*hi[a2], k4 = m22*hi[a2];
+  double poly[16][2] = { { cx - k1 - k3, cy - k2 - k4 }, { cx - k1 + k3, cy - k2 + k4 },
+                         { cx + k1 + k3, cy + k2 + k4 }, { cx + k1 - k3, cy + k2 - k4 } }, tmp[16][2];
+  int np = 4;
+  double rect[2] = { hr[c1], hr[c2] };
+  /* Sutherland-Hodgman against x <= r, x >= -r, y <= r, y >= -r */
+  for (int dir = 0; dir < 2; dir++) for (int sgn = -1; sgn <= 1; sgn += 2) {
+    int nq = 0;
+    for (int v = 0; v < np; v++) {
+      const double* P = poly[v]; const double* Nx = poly[(v + 1) % np];
+      int inP = sgn * P[dir] < rect[dir], inN = sgn * Nx[dir] < rect[dir];
+      if (inP) { tmp[nq][0] = P[0]; tmp[nq][1] = P[1]; nq++; }
+      if (inP != inN) {
+        double tt = (sgn * rect[dir] - P[dir]) / (Nx[dir] - P[dir]);
+        tmp[nq][1 - dir] = P[1 - dir] + tt * (Nx[1 - dir] - P[1 - dir]); tmp[nq][dir] = sgn * rect[dir]; nq++;
+      }
+      if (nq >= 15) break;
+    }
+    np = nq; memcpy(poly, tmp, sizeof(poly));
+    if (np == 0) return;
+  }
+  /* back to 3-D on the incident face; keep the points that lie below the reference face */
+  double det1 = 1.0 / (m11*m22 - m12*m21);
+  double im11 = m22*det1, im12 = -m12*det1, im21 = -m21*det1, im22 = m11*det1;
+  int kept = 0;
+  for (int v = 0; v < np && kept < 8; v++) {
+    double qx = poly[v][0] - cx, qy = poly[v][1] - cy;
+    double u1 = im11*qx + im12*qy, u2 = im21*qx + im22*qy, pt[3];
+    for (int k = 0; k < 3; k++) pt[k] = center[k] + u1*Ri[a1][k] + u2*Ri[a2][k];      /* relative to pr */
+    double depth = hr[ax] - dot3(n2, pt);
+    if (depth > 0) {
+      double pos[3];
+      for (int k = 0; k < 3; k++) pos[k] = pr[k] + pt[k] + 0.5*depth*n2[k];
+      add_contact(m, d, ga, gb, pos, normal, -depth);
+      kept++;
+    }
+  }
+}
+
+static int filtered(const mco_model* m, int g1, int g2) {
+  int b1 = m->geom_body[g1], b2 = m->geom_body[g2];
+  int w1 = m->body_weldid[b1], w2 = m->body_weldid[b2];
+  if (w1 == 0 && w2 == 0) return 1;
+  if (w1 == w2) return 1;
+  int p1 = m->body_weldid[m->body_parent[w1]], p2 = m->body_weldid[m->body_parent[w2]];
+  if ((w1 != 0 && w2 != 0) && (p1 == w2 || p2 == w1)) return 1;
+  for (int e = 0; e < m->nexclude; e++)
+    if ((m->exclude[e][0] == b1 && m->exclude[e][1] == b2) || (m->exclude[e][0] == b2 && m->exclude[e][1] == b1)) return 1;
+  if (!((m->geom_contype[g1] & m->geom_conaffinity[g2]) || (m->geom_contype[g2] & m->geom_conaffinity[g1]))) return 1;
+  return 0;
+}
+
 void mco_collision(const mco_model* m, mco_data* d) {
-  (void)m;
   d->ncon = 0;
+  for (int g1 = 0; g1 < m->ngeom; g1++) for (int g2 = g1 + 1; g2 < m->ngeom; g2++) {
+    int t1 = m->geom_type[g1], t2 = m->geom_type[g2];
+    if (t1 == MCO_GEOM_MESH || t2 == MCO_GEOM_MESH) continue;           /* convex-mesh collision: out of scope */
+    if (filtered(m, g1, g2)) continue;
+    if (t1 == MCO_GEOM_PLANE && t2 == MCO_GEOM_BOX) plane_box(m, d, g1, g2);
+    else if (t1 == MCO_GEOM_BOX && t2 == MCO_GEOM_BOX) {
+      const double* s1 = m->geom_size[g1]; const double* s2 = m->geom_size[g2];
+      double r = sqrt(dot3(s1, s1)) + sqrt(dot3(s2, s2));
+      double dp[3] = { d->geom_xpos[g2][0] - d->geom_xpos[g1][0], d->geom_xpos[g2][1] - d->geom_xpos[g1][1], d->geom_xpos[g2][2] - d->geom_xpos[g1][2] };
+      if (dot3(dp, dp) > r * r) continue;                               /* bounding spheres */
+      box_box(m, d, g1, g2);
+    }
+  }
 }

@@ -142,6 +142,31 @@ void mco_compute_reward(const double* achieved, const double* desired, int n, in
   }
 }
 
+/* ------------------------------------------------ stage_rewards + check_contact (mycobot.py:402-448, utils.py:598-604) */
+static int check_contact(const mco_data* d, int g1, int g2) {
+  for (int c = 0; c < d->ncon; c++)
+    if ((d->contact[c].geom1 == g1 && d->contact[c].geom2 == g2) || (d->contact[c].geom1 == g2 && d->contact[c].geom2 == g1)) return 1;
+  return 0;
+}
+static double shaped_reward(const mco_envs* e, int i) {
+  /* reach 0.2 (1 - tanh d_grip,obj); grasp 0.5 iff both pads touch the cube; lift 0.5 + 0.4 (1 - tanh d_obj,target).
+     The `target0` site is only moved in _render_callback (mycobot.py:309-311), so without rendering it stays at its
+     MJCF position (-0.15, 0, 0.21); that is what is restated here. */
+  const mco_data* d = &e->env[i].d;
+  const double target0[3] = { -0.15, 0.0, 0.21 };
+  const double* grip = d->site_xpos[e->cfg.eef_site]; const double* obj = d->site_xpos[e->cfg.obj_site];
+  double dx = grip[0] - obj[0], dy = grip[1] - obj[1], dz = grip[2] - obj[2];
+  double r_reach = (1 - tanh(sqrt(dx * dx + dy * dy + dz * dz))) * 0.2;
+  double r_grasp = (check_contact(d, e->cfg.pad_geom[0], e->cfg.obj_geom) && check_contact(d, e->cfg.pad_geom[1], e->cfg.obj_geom)) ? 0.5 : 0.0;
+  double r_lift = 0.0;
+  if (r_grasp > 0.0) {
+    double tx = obj[0] - target0[0], ty = obj[1] - target0[1], tz = obj[2] - target0[2];
+    r_lift = 0.5 + (1 - tanh(sqrt(tx * tx + ty * ty + tz * tz))) * (0.9 - 0.5);
+  }
+  double mx = r_reach > r_grasp ? r_reach : r_grasp;
+  return (mx > r_lift ? mx : r_lift) * 100;
+}
+
 /* ------------------------------------------------------------------------------ reset_model */
 static void reset_one(mco_envs* e, int i) {
   env_t* v = &e->env[i];
@@ -176,7 +201,9 @@ static void domain_randomise(mco_envs* e, int i, env_t* v) {
      sliding friction of the cube and pad geoms; invweight0 stays nominal (no mj_setConst). */
   mco_model* m = &e->env_model[i];
   double um, uf;
+  uint32_t keep = v->draw; v->draw = 0;       /* stream 1 has its own draw counter: DR does not shift the goal draws */
   rng_pair(e, i, v, 1, &um, &uf);
+  v->draw = keep;
   double ms = e->cfg.dr_mass_range[0] + (e->cfg.dr_mass_range[1] - e->cfg.dr_mass_range[0]) * um;
   double fs = e->cfg.dr_friction_range[0] + (e->cfg.dr_friction_range[1] - e->cfg.dr_friction_range[0]) * uf;
   if (e->cfg.has_object) {
@@ -266,7 +293,8 @@ void mco_envs_step(mco_envs* e, const float* actions, double* obs, double* achie
     get_obs(e, i, o, ag, dg);
     double dist = goal_distance(ag, dg);
     int succ = dist < e->cfg.distance_threshold;
-    mco_compute_reward(ag, dg, 1, e->cfg.reward_type, e->cfg.distance_threshold, &r);
+    if (e->cfg.reward_type == MCO_REWARD_SHAPING) r = shaped_reward(e, i);
+    else mco_compute_reward(ag, dg, 1, e->cfg.reward_type, e->cfg.distance_threshold, &r);
     v->elapsed++; v->ep_length++; v->ep_return += r;
     int term = succ, trunc = succ || (v->elapsed >= e->cfg.max_episode_steps);   /* D-4 + TimeLimit */
     reward[i] = r; terminated[i] = (uint8_t)term; truncated[i] = (uint8_t)trunc; is_success[i] = (uint8_t)succ;

@@ -30,7 +30,8 @@ def soften_gains(tab, scale=0.1):
 
 def make_oracle(n, has_object=False, controller_type="joint", fetch_env=False, reward_type="dense", seed=0,
                 env_id_offset=0, mesh_inertia="legacy", frame_skip=20, control_steps=5, max_episode_steps=50,
-                target_in_the_air=True, distance_threshold=0.01, auto_reset=True, n_threads=None, table=None):
+                target_in_the_air=True, distance_threshold=0.01, auto_reset=True, n_threads=None, table=None,
+                domain_randomization=None):
     from oracle import pyoracle as po
     from mycobotgym_amd.vec_env import initial_state
     tab = table if table is not None else load_json(table_name(has_object, mesh_inertia))
@@ -49,11 +50,18 @@ def make_oracle(n, has_object=False, controller_type="joint", fetch_env=False, r
     cfg.grip_jnt[1] = tab["jnt_name"].index("robot0:left_gear_joint")
     cfg.n_threads = n_threads or min(os.cpu_count() or 1, 16)
     cfg.pad_geom[0] = cfg.pad_geom[1] = cfg.obj_geom = -1
+    if has_object:
+        cfg.pad_geom[0] = tab["geom_name"].index("right_finger_layer"); cfg.pad_geom[1] = tab["geom_name"].index("left_finger_layer")
+        cfg.obj_geom = tab["geom_name"].index("object0")
     cfg.distance_threshold = distance_threshold; cfg.height_offset = height
     for k, v in enumerate(qpos): cfg.init_qpos[k] = v
     for k, v in enumerate(qvel): cfg.init_qvel[k] = v
     for k, v in enumerate(ctrl): cfg.init_ctrl[k] = v
     cfg.seed = seed; cfg.env_id_offset = env_id_offset
+    if domain_randomization:
+        cfg.dr_enable = 1
+        cfg.dr_mass_range[0], cfg.dr_mass_range[1] = domain_randomization.get("mass", (1.0, 1.0))
+        cfg.dr_friction_range[0], cfg.dr_friction_range[1] = domain_randomization.get("friction", (1.0, 1.0))
     return po.OracleEnvs(model, cfg)
 
 

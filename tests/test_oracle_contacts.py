@@ -1,0 +1,134 @@
+"""Oracle P4 (collision) and contact rows: box-box / plane-box geometry, the resting cube, friction, a scripted grasp.
+
+Known answer NOT reproduced: the reference keyframes (mycobot280.xml:6, mycobot280_mocap.xml:7) store the resting cube
+at z = 0.209981, i.e. 1.9e-5 below 0.21; the restated contact model settles 9.59e-6 below -- its own analytic value
+(checked here), a factor 1.98 ~ (1 + mu^2) stiffer.  One of the [RECALL] regularisation rules for pyramidal contacts is
+therefore off by that factor; which one cannot be decided without MuJoCo.
+"""
+import ctypes as C
+import json
+
+import numpy as np
+import pytest
+
+from tests.common import load_json, make_oracle
+
+
+@pytest.fixture(scope="module")
+def po(built):
+    from oracle import pyoracle
+    return pyoracle
+
+
+def _scene(po, cube_pos, cube_quat=(1, 0, 0, 0), qvel=None):
+    tab = load_json("mycobot280")
+    om = po.OracleModel(tab, enable_contact=True); d = po.OracleData(om)
+    q = np.asarray(tab["qpos0"], dtype=float).copy(); q[12:15] = cube_pos; q[15:19] = cube_quat
+    d.set_state(qpos=q, qvel=np.zeros(18) if qvel is None else qvel)
+    return tab, om, d
+
+
+def _contacts(d):
+    n = int(d.get("ncon", (1,), np.int32)[0])
+    nefc = int(d.get("nefc", (1,), np.int32)[0])
+    return n, nefc
+
+
+def test_cube_on_table_four_face_contacts(po):
+    tab, om, d = _scene(po, [-0.05, 0.0, 0.2099])
+    d.forward()
+    n, nefc = _contacts(d)
+    assert n == 4 and nefc == 7 + 4 * 6                      # 7 equality rows + 4 condim-4 pyramids
+    pos = d.get("efc_pos", (224,))[7:31]
+    assert np.allclose(pos, -1e-4, atol=1e-12)               # dist = -penetration on every pyramid row
+    # separated: no contact; cube over the table edge: fewer vertices inside
+    tab, om, d = _scene(po, [-0.05, 0.0, 0.2101]); d.forward(); assert _contacts(d)[0] == 0
+    # half over the x = 0.2 edge: the incident face is clipped to the table top (2 vertices + 2 clip points)
+    tab, om, d = _scene(po, [0.2, 0.0, 0.2099]); d.forward(); assert _contacts(d)[0] == 4
+    tab, om, d = _scene(po, [0.2105, 0.0, 0.2099]); d.forward(); assert _contacts(d)[0] == 0
+    # on the ground plane next to the table
+    tab, om, d = _scene(po, [0.5, 0.0, 0.0099]); d.forward(); assert _contacts(d)[0] == 4
+
+
+def test_edge_contact_and_tilted_cube(po):
+    # cube rotated 45 deg about x and lowered: one bottom edge touches the table -> 2 vertices
+    c, s = np.cos(np.pi / 8), np.sin(np.pi / 8)
+    tab, om, d = _scene(po, [-0.05, 0.0, 0.2 + 0.01 * np.sqrt(2) - 1e-4], (c, s, 0, 0))
+    d.forward()
+    assert _contacts(d)[0] == 2
+
+
+def test_rest_height_matches_model_prediction_not_keyframe(po):
+    tab, om, d = _scene(po, [-0.05, 0.0, 0.21])
+    d.step(1500)
+    pen = 0.21 - d.qpos[14]
+    assert abs(d.qvel[14]) < 1e-10 and np.abs(d.qvel[12:18]).max() < 1e-9
+    # analytic: 4 contacts x 6 rows, D = 1 / (2 mu^2 R), R = (1 - imp) / imp * tran (1 + mu^2), aref = K imp pen
+    K, imp_d0, imp_d1, width = 9551.195, 0.9495, 0.9745, 0.001
+    def residual(p):
+        x = p / width; imp = imp_d0 + 2 * x * x * (imp_d1 - imp_d0)
+        D = 1 / (2 * (1 - imp) / imp * 125 * 2)
+        return 24 * D * K * imp * p - 0.008 * 9.81
+    lo, hi = 1e-7, 1e-4
+    for _ in range(80):
+        mid = 0.5 * (lo + hi); lo, hi = (mid, hi) if residual(mid) < 0 else (lo, mid)
+    assert abs(pen - lo) < 2e-9
+    assert 9.4e-6 < pen < 9.8e-6                      # the keyframes say 1.9e-5: unpinned [RECALL] factor ~2
+
+
+def test_friction_holds_then_slides(po):
+    """Tangential push below mu * N sticks (soft: creeps), above it slides: Coulomb behaviour of the pyramid."""
+    tab = load_json("mycobot280")
+    om = po.OracleModel(tab, enable_contact=True); d = po.OracleData(om)
+    d.step(600)                                        # settle
+    v = d.qvel.copy(); v[12] = 0.05; d.set_state(qvel=v)
+    d.step(200)
+    assert abs(d.qvel[12]) < 5e-3                      # friction (mu = 1) stops a 5 cm/s slide within 0.4 s
+    assert abs(d.qpos[14] - 0.20999) < 2e-5
+
+
+def test_scripted_grasp_pinches_the_cube(po):
+    tab = load_json("mycobot280")
+    om = po.OracleModel(tab, enable_contact=True); d = po.OracleData(om)
+    key = tab["keys"][0]
+    d.set_state(qpos=key["qpos"], ctrl=key["ctrl"]); d.forward()
+    gn = tab["geom_name"]; gr, gl, gc = gn.index("right_finger_layer"), gn.index("left_finger_layer"), gn.index("object0")
+    gx = d.get("geom_xpos", (48, 3))
+    q = np.asarray(key["qpos"], dtype=float).copy(); q[12:15] = 0.5 * (gx[gr] + gx[gl]); q[15:19] = [1, 0, 0, 0]
+    ctrl = np.asarray(key["ctrl"], dtype=float).copy(); ctrl[6] = 1.0
+    d.set_state(qpos=q, qvel=np.zeros(18), ctrl=ctrl)
+    z0 = q[14]
+    d.step(20 * 12)
+    assert d.qpos[6] > 0.6                              # gripper closed on the cube
+    ncon = int(d.get("ncon", (1,), np.int32)[0])
+    g1 = d.get("efc_id", (224,), np.int32)
+    assert ncon >= 2
+    # the cube is held: it has dropped far less than free fall would (0.5 g t^2 = 1.1 m in 0.48 s)
+    assert z0 - d.qpos[14] < 0.05
+    assert int(d.get("warning_badstate", (1,), np.int32)[0]) == 0
+
+
+def test_pickandplace_env_obs_layout_and_shaping(built):
+    """25-number observation (Appendix A.6) and the staged reward with the stale target site (Appendix D-8)."""
+    ora = make_oracle(4, has_object=True, controller_type="joint", reward_type="reward_shaping", seed=0)
+    obs, ag, dg = ora.reset(seed=0)
+    assert obs.shape == (4, 25)
+    grip, objp, rel = obs[:, 0:3], obs[:, 3:6], obs[:, 6:9]
+    assert np.allclose(rel, objp - grip) and np.allclose(ag, objp)
+    assert np.allclose(objp[:, 2], 0.21) and np.all(np.hypot(objp[:, 0] - grip[:, 0], objp[:, 1] - grip[:, 1]) >= 0.1)
+    assert np.all(np.hypot(dg[:, 0] - objp[:, 0], dg[:, 1] - objp[:, 1]) >= 0.1)          # mycobot.py:232
+    o = ora.step(np.zeros((4, 7), np.float32))
+    d = np.linalg.norm(o["obs"][:, 0:3] - o["obs"][:, 3:6], axis=1)
+    assert np.allclose(o["reward"], 100 * 0.2 * (1 - np.tanh(d)), atol=1e-12)             # reach stage only
+
+
+def test_domain_randomisation_changes_only_the_cube(built):
+    ora = make_oracle(16, has_object=True, controller_type="joint", seed=1,
+                      domain_randomization={"mass": (0.5, 2.0), "friction": (0.5, 1.5)})
+    ora.reset(seed=1)
+    o1 = ora.step(np.zeros((16, 7), np.float32))
+    base = make_oracle(16, has_object=True, controller_type="joint", seed=1); base.reset(seed=1)
+    o2 = base.step(np.zeros((16, 7), np.float32))
+    # same goals and cube placement (DR draws use their own stream); arm identical, cube rest height differs with mass
+    assert np.array_equal(o1["desired"], o2["desired"]) and np.allclose(o1["obs"][:, 0:3], o2["obs"][:, 0:3], atol=1e-12)
+    assert np.abs(o1["obs"][:, 5] - o2["obs"][:, 5]).max() > 1e-7
