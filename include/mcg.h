@@ -64,6 +64,7 @@ typedef struct mcg_model {
   double cube_half[3], table_pos[3], table_half[3], pad_box[2][6];
   double contact_par[3][15];        /* table-cube, right pad-cube, left pad-cube: the 10 solver numbers | friction[5] */
   double contact_diag[3][2];        /* summed body_invweight0 (translational, rotational) */
+  double geom_friction0[3];         /* sliding friction of the table, pad and cube geoms (re-mixed under domain randomisation) */
 } mcg_model;
 
 typedef struct mcg_config {
@@ -114,6 +115,7 @@ typedef struct mcg_state {
   double* goal;      /* [3, N] */
   int32_t* elapsed;  /* [N] */
   int32_t* episode;  /* [N]       per-env episode counter (RNG stream position) */
+  double* dr_scale;  /* [2, N]    domain-randomisation scales of the current episode: cube mass, sliding friction */
 } mcg_state;
 
 typedef struct mcg_env mcg_env;

@@ -41,6 +41,7 @@ class McgModel(C.Structure):
         ("cube_half", d * 3), ("table_pos", d * 3), ("table_half", d * 3), ("pad_box", (d * 6) * 2),
         ("contact_par", (d * 15) * 3),
         ("contact_diag", (d * 2) * 3),
+        ("geom_friction0", d * 3),
     ]
 
     @classmethod
@@ -79,7 +80,7 @@ class McgStepOut(C.Structure):
 
 
 class McgState(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in ("qpos", "qvel", "ctrl", "warm", "qpos_lag", "goal", "elapsed", "episode")]
+    _fields_ = [(n, C.c_void_p) for n in ("qpos", "qvel", "ctrl", "warm", "qpos_lag", "goal", "elapsed", "episode", "dr_scale")]
 
 
 EXPORTS = ("mcg_abi_version", "mcg_last_error", "mcg_default_model", "mcg_create", "mcg_destroy", "mcg_obs_dim",

@@ -1,0 +1,436 @@
+// mcg_cube.hpp -- the free cube of PickAndPlace: collision against the table / ground / finger pads, pyramidal
+// contact rows, primal Newton solve, quaternion integration.  One env per lane.
+//
+// Replaces for this scene what mujoco.mj_step does for the `object0` body and its contacts
+// (/root/reference/mycobotgym/envs/assets/mycobot280_main.xml:81,87,195-199,222-225,260-265; call sites
+// mycobot.py:170,193): mj_collision (P4) over the primitive geoms, mj_makeConstraint / mj_projectConstraint for
+// condim-4 pyramidal contacts (P5), their part of mj_fwdConstraint (P9) and mj_Euler for a free joint (P10).
+// Convex-mesh geoms are out of scope.
+//
+// Contacts of one env live in LDS (runtime-indexed lists cannot live in registers): 16 slots per contact.
+#pragma once
+
+#include "mcg_dynamics.hpp"
+
+namespace mcg {
+
+constexpr int MAXCON = 12;           // contacts kept per env (the oracle is built with the same cap)
+constexpr int CON_STRIDE = 16;       // pos[3] n[3] t1[3] t2[3] dist D kterm type
+constexpr int PNP_LANES = 32;        // envs per wave in the PickAndPlace kernels: twice the LDS per env; a wave costs the
+                                     // same with 32 or 64 active lanes (measured), and 8192 envs then cover all 256 CUs
+constexpr int LDS_CON = LDS_SLOTS;
+constexpr int LDS_POLY = LDS_CON + MAXCON * CON_STRIDE;     // two clip polygons of 16 x 2
+constexpr int LDS_ROW = LDS_POLY + 64;                      // per pyramid row: r0, dr (line search)
+constexpr int LDS_ACT = LDS_ROW + MAXCON * 12;              // per contact: active-row bit mask (as a double)
+constexpr int PNP_SLOTS = LDS_ACT + MAXCON;
+typedef LaneScratchT<PNP_LANES> PnpScratch;
+
+enum { PAIR_TABLE_CUBE = 0, PAIR_PADR_CUBE = 1, PAIR_PADL_CUBE = 2 };   // rows of mcg_model.contact_par / contact_diag
+
+struct Cube {
+  real pos[3], quat[4], vel[6], warm[6];     // vel = world linear velocity, body-frame angular velocity (MuJoCo free joint)
+};
+
+MCG_DEV void quat_to_mat(const real* q, real* m) {       // row-major world <- body
+  const real q00 = q[0]*q[0], q01 = q[0]*q[1], q02 = q[0]*q[2], q03 = q[0]*q[3];
+  const real q11 = q[1]*q[1], q12 = q[1]*q[2], q13 = q[1]*q[3], q22 = q[2]*q[2], q23 = q[2]*q[3], q33 = q[3]*q[3];
+  m[0] = q00 + q11 - q22 - q33; m[4] = q00 - q11 + q22 - q33; m[8] = q00 - q11 - q22 + q33;
+  m[1] = 2*(q12 - q03); m[2] = 2*(q13 + q02); m[3] = 2*(q12 + q03);
+  m[5] = 2*(q23 - q01); m[6] = 2*(q13 - q02); m[7] = 2*(q23 + q01);
+}
+
+// mju_makeFrame [RECALL]: tangents completing a unit normal
+MCG_DEV void make_frame(const real* n, real* t1, real* t2) {
+  const bool usey = (n[1] < 0.5 && n[1] > -0.5);
+  real tmp[3] = {0.0, usey ? 1.0 : 0.0, usey ? 0.0 : 1.0};
+  const real d = dot3(n, tmp);
+  for (int k = 0; k < 3; k++) t1[k] = tmp[k] - d * n[k];
+  const real l = sqrt(dot3(t1, t1));
+  for (int k = 0; k < 3; k++) t1[k] /= l;
+  cross(n, t1, t2);
+}
+
+template <class LS>
+struct ContactList {
+  const LS S;
+  int n;
+  MCG_DEV void add(const real* pos, const real* normal, real dist, int type) {
+    const bool ok = (dist < 0) && (n < MAXCON);
+    if (ok) {                           // plain LDS stores of live registers (no value is merged across this branch)
+      const int b = LDS_CON + n * CON_STRIDE;
+      real t1[3], t2[3];
+      make_frame(normal, t1, t2);
+      for (int k = 0; k < 3; k++) { S.st(b + k, pos[k]); S.st(b + 3 + k, normal[k]); S.st(b + 6 + k, t1[k]); S.st(b + 9 + k, t2[k]); }
+      S.st(b + 12, dist); S.st(b + 15, (real)type);
+    }
+    n += ok ? 1 : 0;
+  }
+};
+
+// mjc_PlaneBox restated: every box vertex below the plane z = 0 of the world (the scene's only plane)
+template <class LS>
+MCG_DEV void ground_box(ContactList<LS>& CL, const real* pb, const real* Rb, const real* hb, int type) {
+  const real n[3] = {0, 0, 1};
+  for (int v = 0; v < 8; v++) {
+    const real lx = (v & 1) ? hb[0] : -hb[0], ly = (v & 2) ? hb[1] : -hb[1], lz = (v & 4) ? hb[2] : -hb[2];
+    real w[3];
+    for (int k = 0; k < 3; k++) w[k] = pb[k] + Rb[3*k]*lx + Rb[3*k+1]*ly + Rb[3*k+2]*lz;
+    const real dist = w[2];
+    const real pos[3] = {w[0], w[1], w[2] - 0.5 * dist};
+    CL.add(pos, n, dist, type);
+  }
+}
+
+// mjc_BoxBox restated by behaviour: separating-axis test over 15 axes, then face clipping (<= 8 points) or one
+// edge-edge point; position = midpoint between the surfaces, normal from box A to box B, dist < 0.
+// A, B: rotation matrices row-major (world <- box).  Lanes with `live == false` do nothing.
+template <class LS>
+MCG_DEV void box_box(ContactList<LS>& CL, bool live, const real* pa, const real* Ra, const real* ha,
+                     const real* pb, const real* Rb, const real* hb, int type) {
+  const LS& S = CL.S;
+  real A[3][3], B[3][3], p[3] = {pb[0] - pa[0], pb[1] - pa[1], pb[2] - pa[2]};
+  for (int k = 0; k < 3; k++) for (int r = 0; r < 3; r++) { A[k][r] = Ra[3*r + k]; B[k][r] = Rb[3*r + k]; }
+  real Cm[3][3], Q[3][3];
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { Cm[i][j] = dot3(A[i], B[j]); Q[i][j] = fabs(Cm[i][j]); }
+  const real pA[3] = {dot3(A[0], p), dot3(A[1], p), dot3(A[2], p)};
+  const real pB[3] = {dot3(B[0], p), dot3(B[1], p), dot3(B[2], p)};
+  real best = -INFINITY; int code = -1; real nrm[3] = {0, 0, 0}; bool invert = false; bool sep = !live;
+  for (int i = 0; i < 3; i++) {
+    const real s = fabs(pA[i]) - (ha[i] + hb[0]*Q[i][0] + hb[1]*Q[i][1] + hb[2]*Q[i][2]);
+    sep = sep || (s > 0);
+    const bool tk = s > best;
+    best = tk ? s : best; code = tk ? i : code; invert = tk ? (pA[i] < 0) : invert;
+    for (int k = 0; k < 3; k++) nrm[k] = tk ? A[i][k] : nrm[k];
+  }
+  for (int j = 0; j < 3; j++) {
+    const real s = fabs(pB[j]) - (hb[j] + ha[0]*Q[0][j] + ha[1]*Q[1][j] + ha[2]*Q[2][j]);
+    sep = sep || (s > 0);
+    const bool tk = s > best;
+    best = tk ? s : best; code = tk ? 3 + j : code; invert = tk ? (pB[j] < 0) : invert;
+    for (int k = 0; k < 3; k++) nrm[k] = tk ? B[j][k] : nrm[k];
+  }
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
+    const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+    const real expr = pA[i2]*Cm[i1][j] - pA[i1]*Cm[i2][j];
+    const real len = sqrt(fmax(0.0, 1 - Cm[i][j]*Cm[i][j]));
+    const bool valid = len >= 1e-9;
+    const real s = (fabs(expr) - (ha[i1]*Q[i2][j] + ha[i2]*Q[i1][j] + hb[j1]*Q[i][j2] + hb[j2]*Q[i][j1])) / (valid ? len : 1.0);
+    sep = sep || (valid && s > 0);
+    const bool tk = valid && (s * 1.05 > best);
+    real L[3]; cross(A[i], B[j], L);
+    best = tk ? s : best; code = tk ? 6 + 3*i + j : code; invert = tk ? (expr < 0) : invert;
+    for (int k = 0; k < 3; k++) nrm[k] = tk ? L[k] / len : nrm[k];
+  }
+  const bool hit = !sep && code >= 0;
+  if (!__any(hit)) return;
+  real normal[3];
+  for (int k = 0; k < 3; k++) normal[k] = invert ? -nrm[k] : nrm[k];
+
+  // ---- edge-edge (rare): one point
+  if (__any(hit && code >= 6)) {
+    const int ce = code >= 6 ? code - 6 : 0;
+    const int i = ce / 3, j = ce % 3;
+    real ea[3], eb[3], Ai[3], Bj[3];
+    for (int k = 0; k < 3; k++) { ea[k] = pa[k]; eb[k] = pb[k]; Ai[k] = (i == 0) ? A[0][k] : (i == 1) ? A[1][k] : A[2][k]; Bj[k] = (j == 0) ? B[0][k] : (j == 1) ? B[1][k] : B[2][k]; }
+    for (int a = 0; a < 3; a++) { const real sg = (a == i) ? 0.0 : (dot3(normal, A[a]) > 0 ? 1.0 : -1.0); for (int k = 0; k < 3; k++) ea[k] += sg * ha[a] * A[a][k]; }
+    for (int b = 0; b < 3; b++) { const real sg = (b == j) ? 0.0 : (dot3(normal, B[b]) > 0 ? -1.0 : 1.0); for (int k = 0; k < 3; k++) eb[k] += sg * hb[b] * B[b][k]; }
+    const real w[3] = {eb[0] - ea[0], eb[1] - ea[1], eb[2] - ea[2]};
+    const real uaub = dot3(Ai, Bj), q1 = dot3(Ai, w), q2 = -dot3(Bj, w), dd = 1 - uaub*uaub;
+    const real s = dd <= 1e-12 ? 0.0 : (q1 + uaub*q2) / dd, t = dd <= 1e-12 ? 0.0 : (uaub*q1 + q2) / dd;
+    real pos[3];
+    for (int k = 0; k < 3; k++) pos[k] = 0.5 * ((ea[k] + s*Ai[k]) + (eb[k] + t*Bj[k]));
+    CL.add(pos, normal, (hit && code >= 6) ? best : 1.0, type);
+  }
+  if (!__any(hit && code < 6)) return;
+
+  // ---- face contact: clip the incident face against the reference face
+  const bool face = hit && code < 6;
+  const bool refA = code < 3;
+  const int ax = face ? code % 3 : 0;
+  real Rr[3][3], Ri[3][3], pr[3], pi[3], hr[3], hi[3], n2[3];
+  for (int k = 0; k < 3; k++) {
+    for (int r = 0; r < 3; r++) { Rr[k][r] = refA ? A[k][r] : B[k][r]; Ri[k][r] = refA ? B[k][r] : A[k][r]; }
+    pr[k] = refA ? pa[k] : pb[k]; pi[k] = refA ? pb[k] : pa[k]; hr[k] = refA ? ha[k] : hb[k]; hi[k] = refA ? hb[k] : ha[k];
+    n2[k] = refA ? normal[k] : -normal[k];
+  }
+  const real nr[3] = {dot3(n2, Ri[0]), dot3(n2, Ri[1]), dot3(n2, Ri[2])};
+  const int lan = fabs(nr[0]) > fabs(nr[1]) ? (fabs(nr[0]) > fabs(nr[2]) ? 0 : 2) : (fabs(nr[1]) > fabs(nr[2]) ? 1 : 2);
+  const int a1 = (lan + 1) % 3, a2 = (lan + 2) % 3, c1 = (ax + 1) % 3, c2 = (ax + 2) % 3;
+  auto pick = [](const real (*M)[3], int idx, real* out) { for (int k = 0; k < 3; k++) out[k] = (idx == 0) ? M[0][k] : (idx == 1) ? M[1][k] : M[2][k]; };
+  auto pickv = [](const real* v, int idx) { return (idx == 0) ? v[0] : (idx == 1) ? v[1] : v[2]; };
+  real Rilan[3], Ria1[3], Ria2[3], Rrc1[3], Rrc2[3];
+  pick(Ri, lan, Rilan); pick(Ri, a1, Ria1); pick(Ri, a2, Ria2); pick(Rr, c1, Rrc1); pick(Rr, c2, Rrc2);
+  const real hilan = pickv(hi, lan), hia1 = pickv(hi, a1), hia2 = pickv(hi, a2), hrax = pickv(hr, ax);
+  real center[3];
+  for (int k = 0; k < 3; k++) center[k] = pi[k] - pr[k] + (pickv(nr, lan) < 0 ? hilan : -hilan) * Rilan[k];
+  const real cx = dot3(center, Rrc1), cy = dot3(center, Rrc2);
+  const real m11 = dot3(Rrc1, Ria1), m12 = dot3(Rrc1, Ria2), m21 = dot3(Rrc2, Ria1), m22 = dot3(Rrc2, Ria2);
+  const real k1 = m11*hia1, k2 = m21*hia1, k3 = m12*hia2, k4 = m22*hia2;
+  const real rect[2] = {pickv(hr, c1), pickv(hr, c2)};
+  // polygons in LDS: P at LDS_POLY + 2 v + {0,1}, T at LDS_POLY + 32 + 2 v + {0,1}
+  S.st(LDS_POLY + 0, cx - k1 - k3); S.st(LDS_POLY + 1, cy - k2 - k4);
+  S.st(LDS_POLY + 2, cx - k1 + k3); S.st(LDS_POLY + 3, cy - k2 + k4);
+  S.st(LDS_POLY + 4, cx + k1 + k3); S.st(LDS_POLY + 5, cy + k2 + k4);
+  S.st(LDS_POLY + 6, cx + k1 - k3); S.st(LDS_POLY + 7, cy + k2 - k4);
+  int np = face ? 4 : 0;
+  int src = LDS_POLY, dst = LDS_POLY + 32;
+  for (int dir = 0; dir < 2; dir++) for (int sgn = -1; sgn <= 1; sgn += 2) {
+    int nq = 0;
+    const real lim = dir == 0 ? rect[0] : rect[1];
+    for (int v = 0; __any(v < np); v++) {
+      const bool on = v < np;
+      const int vn = (v + 1 < np) ? v + 1 : 0;
+      const real Pd = S.ld(src + 2*v + dir), Po = S.ld(src + 2*v + 1 - dir);
+      const real Nd = S.ld(src + 2*vn + dir), No = S.ld(src + 2*vn + 1 - dir);
+      const bool inP = sgn * Pd < lim, inN = sgn * Nd < lim;
+      if (on && inP && nq < 15) { S.st(dst + 2*nq + dir, Pd); S.st(dst + 2*nq + 1 - dir, Po); }
+      nq += (on && inP && nq < 15) ? 1 : 0;
+      const real tt = (sgn * lim - Pd) / (Nd - Pd);
+      if (on && (inP != inN) && nq < 15) { S.st(dst + 2*nq + dir, sgn * lim); S.st(dst + 2*nq + 1 - dir, Po + tt * (No - Po)); }
+      nq += (on && (inP != inN) && nq < 15) ? 1 : 0;
+    }
+    np = nq;
+    const int tswap = src; src = dst; dst = tswap;
+  }
+  const real det1 = 1.0 / (m11*m22 - m12*m21);
+  const real im11 = m22*det1, im12 = -m12*det1, im21 = -m21*det1, im22 = m11*det1;
+  int kept = 0;
+  for (int v = 0; __any(v < np); v++) {
+    const bool on = (v < np) && (kept < 8);
+    const real qx = S.ld(src + 2*v) - cx, qy = S.ld(src + 2*v + 1) - cy;
+    const real u1 = im11*qx + im12*qy, u2 = im21*qx + im22*qy;
+    real pt[3];
+    for (int k = 0; k < 3; k++) pt[k] = center[k] + u1*Ria1[k] + u2*Ria2[k];
+    const real depth = hrax - dot3(n2, pt);
+    real pos[3];
+    for (int k = 0; k < 3; k++) pos[k] = pr[k] + pt[k] + 0.5*depth*n2[k];
+    const bool take = on && (depth > 0);
+    CL.add(pos, normal, take ? -depth : 1.0, type);
+    kept += take ? 1 : 0;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ cube sub-step
+// Row vectors of a contact in the cube's 6 dofs: J = [dir ; Rc^T (arm x dir)] for a translational direction,
+// [0 ; Rc^T n] for torsion.  The cube is always geom2 of its pairs, so the cube side enters with +.
+struct CubeRows { real Jn[6], J1[6], J2[6], Jt[6]; };
+
+template <class LS>
+MCG_DEV void cube_rows(const LS& S, int c, const real* Rc, const real* cpos, CubeRows& R) {
+  const int b = LDS_CON + c * CON_STRIDE;
+  real pos[3], n[3], t1[3], t2[3], arm[3], x[3];
+  for (int k = 0; k < 3; k++) { pos[k] = S.ld(b + k); n[k] = S.ld(b + 3 + k); t1[k] = S.ld(b + 6 + k); t2[k] = S.ld(b + 9 + k); arm[k] = pos[k] - cpos[k]; }
+  auto fill = [&](const real* d, real* J) {
+    cross(arm, d, x);
+    for (int k = 0; k < 3; k++) { J[k] = d[k]; J[3 + k] = Rc[k]*x[0] + Rc[3 + k]*x[1] + Rc[6 + k]*x[2]; }
+  };
+  fill(n, R.Jn); fill(t1, R.J1); fill(t2, R.J2);
+  for (int k = 0; k < 3; k++) { R.Jt[k] = 0; R.Jt[3 + k] = Rc[k]*n[0] + Rc[3 + k]*n[1] + Rc[6 + k]*n[2]; }
+}
+
+// pyramid row r (0..5) of a contact: Jn + sign * mu * Jk
+MCG_DEV void pyramid_row(const CubeRows& R, int r, const real* mu, real* j) {
+  const int k = r >> 1; const real sg = (r & 1) ? -1.0 : 1.0;
+  const real m = sg * ((k == 0) ? mu[0] : (k == 1) ? mu[1] : mu[2]);
+  for (int d = 0; d < 6; d++) { const real jk = (k == 0) ? R.J1[d] : (k == 1) ? R.J2[d] : R.Jt[d]; j[d] = R.Jn[d] + m * jk; }
+}
+
+// One mj_step of the cube when no finger pad touches it (its dynamics then separates exactly from the robot's).
+template <class LS>
+MCG_DEV void cube_substep(ModelPtr Pm, Cube& Cb, real* qlag7, const real* dr, const LS S) {
+  ModelPtr Q = launder(Pm);
+  const real h = Q->timestep;
+  // mj_kinematics normalises the stored quaternion
+  {
+    const real nq = sqrt(Cb.quat[0]*Cb.quat[0] + Cb.quat[1]*Cb.quat[1] + Cb.quat[2]*Cb.quat[2] + Cb.quat[3]*Cb.quat[3]);
+    const bool tiny = nq < MINVAL;
+    for (int k = 0; k < 4; k++) Cb.quat[k] = tiny ? (k == 0 ? 1.0 : 0.0) : Cb.quat[k] / nq;
+  }
+  for (int k = 0; k < 3; k++) qlag7[k] = Cb.pos[k];
+  for (int k = 0; k < 4; k++) qlag7[3 + k] = Cb.quat[k];
+  real Rc[9]; quat_to_mat(Cb.quat, Rc);
+  // dr = per-env domain-randomisation scales (mass, sliding friction); (1, 1) when DR is off
+  const real mass = Q->body[12].mass * dr[0];
+  const real In[3] = {Q->body[12].inertia[0] * dr[0], Q->body[12].inertia[1] * dr[0], Q->body[12].inertia[2] * dr[0]};
+  real Md[6] = {mass, mass, mass, In[0], In[1], In[2]};
+  real damp[6]; ldc<6>(Q->cube_damping, damp);
+  // qfrc_smooth = passive - bias: gravity on the translation, gyroscopic term on the (body-frame) rotation
+  real gb[3]; ldc<3>(Q->gravity_base, gb);             // base frame is a rotation about z: the z component is world z
+  real fs[6];
+  const real* w = Cb.vel + 3;
+  const real Iw[3] = {In[0]*w[0], In[1]*w[1], In[2]*w[2]};
+  real gyro[3]; cross(w, Iw, gyro);
+  fs[0] = -damp[0]*Cb.vel[0]; fs[1] = -damp[1]*Cb.vel[1]; fs[2] = -damp[2]*Cb.vel[2] - mass * gb[2];
+  for (int k = 0; k < 3; k++) fs[3 + k] = -damp[3 + k]*w[k] - gyro[k];
+
+  // ---- P4 collision: ground plane (only when low), table top
+  ContactList<LS> CL{S, 0};
+  real hc[3]; ldc<3>(Q->cube_half, hc);
+  if (__any(Cb.pos[2] < 0.05)) {
+    ContactList<LS> G{S, 0};
+    G.n = CL.n;
+    const bool low = Cb.pos[2] < 0.05;
+    real far[3] = {Cb.pos[0], Cb.pos[1], low ? Cb.pos[2] : 1.0};
+    ground_box(G, far, Rc, hc, PAIR_TABLE_CUBE);
+    CL.n = G.n;
+  }
+  {
+    real tp[3], th[3]; ldc<3>(Q->table_pos, tp); ldc<3>(Q->table_half, th);
+    const real Rt[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    const real dx = Cb.pos[0] - tp[0], dy = Cb.pos[1] - tp[1], dz = Cb.pos[2] - tp[2];
+    const real rs = sqrt(dot3(th, th)) + sqrt(dot3(hc, hc));
+    const bool near = dx*dx + dy*dy + dz*dz <= rs*rs;
+    if (__any(near)) box_box(CL, near, tp, Rt, th, Cb.pos, Rc, hc, PAIR_TABLE_CUBE);
+  }
+  const int ncon = CL.n;
+
+  // ---- P5 per-contact solver numbers (all 6 pyramid rows share D and the position term)
+  real par[15]; ldc<15>(Q->contact_par[PAIR_TABLE_CUBE], par);
+  const real tran = Q->contact_diag[PAIR_TABLE_CUBE][0];
+  // sliding friction re-mixed (element-wise max) with the randomised cube friction; torsional friction as compiled
+  const real mu0 = fmax(Q->geom_friction0[0], Q->geom_friction0[2] * dr[1]);
+  const real mu[3] = {mu0, mu0, par[12]};
+  for (int c = 0; __any(c < ncon); c++) {
+    const int b = LDS_CON + c * CON_STRIDE;
+    const real dist = S.ld(b + 12);
+    const real imp = impedance(par, dist);
+    const real Rn = fmax(MINVAL, (1 - imp) * tran * (1 + mu[0]*mu[0]) / imp);
+    const real Rpy = fmax(MINVAL, 2 * mu[0]*mu[0] * Rn);
+    if (c < ncon) { S.st(b + 13, 1.0 / Rpy); S.st(b + 14, par[0] * imp * dist); }
+  }
+
+  // ---- P9 Newton on the 6 cube dofs; active set = pyramid rows with J a - aref < 0
+  real a[6];
+  for (int k = 0; k < 6; k++) a[k] = Cb.warm[k];
+  auto row_aref = [&](const real* j, real kterm) {       // aref = -B (J qvel) - K imp dist
+    real v = 0; for (int d = 0; d < 6; d++) v += j[d] * Cb.vel[d];
+    return -par[1] * v - kterm;
+  };
+  // initial active set from the warm start
+  for (int c = 0; __any(c < ncon); c++) {
+    CubeRows R; cube_rows(S, c, Rc, Cb.pos, R);
+    const real kterm = S.ld(LDS_CON + c * CON_STRIDE + 14);
+    int mask = 0;
+    for (int r = 0; r < 6; r++) {
+      real j[6]; pyramid_row(R, r, mu, j);
+      real ja = 0; for (int d = 0; d < 6; d++) ja += j[d] * a[d];
+      mask |= (ja - row_aref(j, kterm) < 0) ? (1 << r) : 0;
+    }
+    if (c < ncon) S.st(LDS_ACT + c, (real)mask);
+  }
+  bool conv = false;
+  for (int it = 0; it < 50; it++) {
+    // H = M + sum_active D j j^T (packed lower 6x6), g = fs + sum_active D aref j
+    real H[21], g[6];
+    for (int k = 0; k < 21; k++) H[k] = 0;
+    for (int k = 0; k < 6; k++) { H[tri(k, k)] = Md[k]; g[k] = fs[k]; }
+    for (int c = 0; __any(c < ncon); c++) {
+      CubeRows R; cube_rows(S, c, Rc, Cb.pos, R);
+      const int b = LDS_CON + c * CON_STRIDE;
+      const real D = (c < ncon) ? S.ld(b + 13) : 0.0, kterm = S.ld(b + 14);
+      const int mask = (c < ncon) ? (int)S.ld(LDS_ACT + c) : 0;
+      for (int r = 0; r < 6; r++) {
+        real j[6]; pyramid_row(R, r, mu, j);
+        const real wgt = ((mask >> r) & 1) ? D : 0.0;
+        const real ar = row_aref(j, kterm);
+        for (int d = 0; d < 6; d++) { const real wj = wgt * j[d]; g[d] += wj * ar; for (int e = 0; e <= d; e++) H[tri(d, e)] += wj * j[e]; }
+      }
+    }
+    real x[6];
+    for (int k = 0; k < 6; k++) x[k] = g[k];
+    chol_factor<6>(H); chol_solve<6>(H, x);
+    // active set at x; r0 / dr per row for the line search
+    real p[6]; for (int k = 0; k < 6; k++) p[k] = x[k] - a[k];
+    bool same = true;
+    for (int c = 0; __any(c < ncon); c++) {
+      CubeRows R; cube_rows(S, c, Rc, Cb.pos, R);
+      const real kterm = S.ld(LDS_CON + c * CON_STRIDE + 14);
+      const int mask = (int)S.ld(LDS_ACT + c);
+      for (int r = 0; r < 6; r++) {
+        real j[6]; pyramid_row(R, r, mu, j);
+        real ja = 0, jp = 0; for (int d = 0; d < 6; d++) { ja += j[d] * a[d]; jp += j[d] * p[d]; }
+        const real r0 = ja - row_aref(j, kterm);
+        if (c < ncon) { S.st(LDS_ROW + (c * 6 + r) * 2, r0); S.st(LDS_ROW + (c * 6 + r) * 2 + 1, jp); }
+        const bool now = (r0 + jp) < 0;
+        same = same && (c >= ncon || now == (((mask >> r) & 1) != 0));
+      }
+    }
+    const bool finish = !conv && same;
+    for (int k = 0; k < 6; k++) a[k] = finish ? x[k] : a[k];
+    conv = conv || finish;
+    if (!__any(!conv)) break;
+    // Line search along p on phi'(alpha) = sum_k M_k (a_k - as_k + alpha p_k) p_k + sum_rows D min(0, r0 + alpha dr) dr.
+    // Any descent step that ends in a consistent active set gives the exact minimiser at the final full step, so a
+    // bisection (24 halvings of [0, 2]) is enough here; the oracle walks the breakpoints exactly.
+    real lin0 = 0, quad = 0;
+    for (int k = 0; k < 6; k++) { const real as = fs[k] / Md[k]; lin0 += Md[k] * (a[k] - as) * p[k]; quad += Md[k] * p[k] * p[k]; }
+    auto dphi = [&](real al) {
+      real s = lin0 + al * quad;
+      for (int c = 0; __any(c < ncon); c++) {
+        const real D = (c < ncon) ? S.ld(LDS_CON + c * CON_STRIDE + 13) : 0.0;
+        for (int r = 0; r < 6; r++) {
+          const real r0 = S.ld(LDS_ROW + (c * 6 + r) * 2), dr = S.ld(LDS_ROW + (c * 6 + r) * 2 + 1);
+          const real rr = r0 + al * dr;
+          s += (rr < 0) ? D * rr * dr : 0.0;
+        }
+      }
+      return s;
+    };
+    real lo = 0, hi = 2;
+    const bool beyond = dphi(hi) < 0;
+    for (int b = 0; b < 24; b++) { const real mid = 0.5 * (lo + hi); const bool neg = dphi(mid) < 0; lo = neg ? mid : lo; hi = neg ? hi : mid; }
+    const real alpha = beyond ? 2.0 : 0.5 * (lo + hi);
+    for (int k = 0; k < 6; k++) a[k] = conv ? a[k] : a[k] + alpha * p[k];
+    for (int c = 0; __any(c < ncon); c++) {
+      int mask = 0;
+      for (int r = 0; r < 6; r++) {
+        const real r0 = S.ld(LDS_ROW + (c * 6 + r) * 2), dr = S.ld(LDS_ROW + (c * 6 + r) * 2 + 1);
+        mask |= (r0 + alpha * dr < 0) ? (1 << r) : 0;
+      }
+      if (c < ncon && !conv) S.st(LDS_ACT + c, (real)mask);
+    }
+  }
+
+  // ---- constraint force, implicit-damping Euler (diagonal M), free-joint integration
+  real fc[6] = {0, 0, 0, 0, 0, 0};
+  for (int c = 0; __any(c < ncon); c++) {
+    CubeRows R; cube_rows(S, c, Rc, Cb.pos, R);
+    const int b = LDS_CON + c * CON_STRIDE;
+    const real D = (c < ncon) ? S.ld(b + 13) : 0.0, kterm = S.ld(b + 14);
+    for (int r = 0; r < 6; r++) {
+      real j[6]; pyramid_row(R, r, mu, j);
+      real ja = 0; for (int d = 0; d < 6; d++) ja += j[d] * a[d];
+      const real jar = ja - row_aref(j, kterm);
+      const real f = (jar < 0) ? -D * jar : 0.0;
+      for (int d = 0; d < 6; d++) fc[d] += j[d] * f;
+    }
+  }
+  for (int k = 0; k < 6; k++) {
+    const real acc = (fs[k] + fc[k]) / (Md[k] + h * damp[k]);
+    Cb.vel[k] += h * acc;
+    Cb.warm[k] = a[k];
+  }
+  for (int k = 0; k < 3; k++) Cb.pos[k] += h * Cb.vel[k];
+  {   // mju_quatIntegrate with the body-frame angular velocity
+    real ax[3] = {Cb.vel[3], Cb.vel[4], Cb.vel[5]};
+    const real nw = sqrt(dot3(ax, ax));
+    const bool tiny = nw < MINVAL;
+    for (int k = 0; k < 3; k++) ax[k] = tiny ? (k == 0 ? 1.0 : 0.0) : ax[k] / nw;
+    const real ang = h * nw;
+    real sh, ch; sincos(0.5 * ang, &sh, &ch);
+    const real qr[4] = {ch, ax[0]*sh, ax[1]*sh, ax[2]*sh};
+    real qn[4]; mulquat(Cb.quat, qr, qn);
+    for (int k = 0; k < 4; k++) Cb.quat[k] = qn[k];
+  }
+}
+
+// rotations.mat2euler (gymnasium_robotics) as called at mycobot.py:355-357 [RECALL]
+MCG_DEV void mat2euler(const real* m, real* e) {
+  const real cy = sqrt(m[8]*m[8] + m[5]*m[5]);
+  const bool ok = cy > 4 * 2.220446049250313e-16;
+  e[2] = ok ? -atan2(m[1], m[0]) : -atan2(-m[3], m[4]);
+  e[1] = -atan2(-m[2], cy);
+  e[0] = ok ? -atan2(m[5], m[8]) : 0.0;
+}
+
+}  // namespace mcg

@@ -271,14 +271,17 @@ struct Robot {
 // ds_read_b64 / ds_write_b64 with immediate offsets).  The joint-space inertia M is kept here between the stages
 // that consume it, so that only one 12x12 system occupies registers at a time.
 constexpr int LDS_SLOTS = NB * (NB + 1) / 2;
-struct LaneScratch {
+template <int STRIDE>
+struct LaneScratchT {
   real* base;
-  MCG_DEV real ld(int k) const { return base[k * 64]; }
-  MCG_DEV void st(int k, real v) const { base[k * 64] = v; }
+  MCG_DEV real ld(int k) const { return base[k * STRIDE]; }
+  MCG_DEV void st(int k, real v) const { base[k * STRIDE] = v; }
 };
+typedef LaneScratchT<64> LaneScratch;
 
 // One physics sub-step (mj_step) of the 12-dof robot.  `qlag` receives the positions the forward pass used.
-MCG_DEV void robot_substep(ModelPtr Pm, Robot& S, real* qlag6, const LaneScratch MS) {
+template <class LS>
+MCG_DEV void robot_substep(ModelPtr Pm, Robot& S, real* qlag6, const LS MS) {
   const real h = launder(Pm)->timestep;
   real cs[NB], sn[NB];
   {

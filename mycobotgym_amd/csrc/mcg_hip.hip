@@ -10,9 +10,11 @@
 #include <cstdio>
 #include <cstring>
 #include <new>
+#include <vector>
 
 #include "mcg.h"
 #include "mcg_dynamics.hpp"
+#include "mcg_cube.hpp"
 #include "model_gen.h"
 
 using namespace mcg;
@@ -26,7 +28,8 @@ int fail(int code, const char* fmt, const char* a = "") { snprintf(g_err, sizeof
 // ------------------------------------------------------------------------------------------- device-side views
 struct Cfg {
   int n, has_object, controller, fetch, reward_type, frame_skip, control_steps, max_episode_steps;
-  int target_in_the_air, auto_reset, nq, nv, obs_dim, act_dim;
+  int target_in_the_air, auto_reset, nq, nv, obs_dim, act_dim, dr_enable;
+  double dr_mass[2], dr_fric[2];
   double distance_threshold, height_offset, igx[3], dt, grip_center, grip_range;
   double init_qpos[19], init_qvel[18], init_ctrl[7];
   unsigned long long seed;
@@ -42,11 +45,12 @@ struct View {           // SoA state: field f of env i at d[f * n + i]
   __device__ double& qlag(int k, int i) const { return d[(size_t)(nq + 2 * nv + 7 + k) * n + i]; }
   __device__ double& goal(int k, int i) const { return d[(size_t)(2 * nq + 2 * nv + 7 + k) * n + i]; }
   __device__ double& epret(int i) const { return d[(size_t)(2 * nq + 2 * nv + 10) * n + i]; }
+  __device__ double& dr(int k, int i) const { return d[(size_t)(2 * nq + 2 * nv + 11 + k) * n + i]; }
   __device__ int32_t& elapsed(int i) const { return i32[i]; }
   __device__ int32_t& episode(int i) const { return i32[n + i]; }
   __device__ int32_t& eplen(int i) const { return i32[2 * n + i]; }
 };
-inline int state_doubles(int nq, int nv) { return 2 * nq + 2 * nv + 11; }
+inline int state_doubles(int nq, int nv) { return 2 * nq + 2 * nv + 13; }
 
 struct Env {            // one lane's working set
   Robot R;
@@ -224,6 +228,186 @@ __global__ __launch_bounds__(64) void reset_reach_kernel(Cfg C, View V, const mc
   write_obs(O, i, 10, obs, ag, E.goal);
 }
 
+
+// ===================================================================================== PickAndPlace (has_object)
+struct EnvP {
+  Robot R; Cube Cb;
+  real qlag6[6], qlag7[7], goal[3], epret, dr[2];
+  int32_t elapsed, episode, eplen;
+};
+
+__device__ void load_envp(const View& V, int i, EnvP& E) {
+  for (int k = 0; k < NB; k++) { E.R.q[k] = V.qpos(k, i); E.R.qd[k] = V.qvel(k, i); E.R.warm[k] = V.warm(k, i); }
+  for (int k = 0; k < 7; k++) E.R.ctrl[k] = V.ctrl(k, i);
+  for (int k = 0; k < 3; k++) E.Cb.pos[k] = V.qpos(12 + k, i);
+  for (int k = 0; k < 4; k++) E.Cb.quat[k] = V.qpos(15 + k, i);
+  for (int k = 0; k < 6; k++) { E.Cb.vel[k] = V.qvel(12 + k, i); E.Cb.warm[k] = V.warm(12 + k, i); E.qlag6[k] = V.qlag(k, i); }
+  for (int k = 0; k < 7; k++) E.qlag7[k] = V.qlag(12 + k, i);
+  for (int k = 0; k < 3; k++) E.goal[k] = V.goal(k, i);
+  E.dr[0] = V.dr(0, i); E.dr[1] = V.dr(1, i);
+  E.epret = V.epret(i); E.elapsed = V.elapsed(i); E.episode = V.episode(i); E.eplen = V.eplen(i);
+}
+__device__ void store_envp(const View& V, int i, const EnvP& E) {
+  for (int k = 0; k < NB; k++) { V.qpos(k, i) = E.R.q[k]; V.qvel(k, i) = E.R.qd[k]; V.warm(k, i) = E.R.warm[k]; }
+  for (int k = 0; k < 7; k++) V.ctrl(k, i) = E.R.ctrl[k];
+  for (int k = 0; k < 3; k++) V.qpos(12 + k, i) = E.Cb.pos[k];
+  for (int k = 0; k < 4; k++) V.qpos(15 + k, i) = E.Cb.quat[k];
+  for (int k = 0; k < 6; k++) { V.qvel(12 + k, i) = E.Cb.vel[k]; V.warm(12 + k, i) = E.Cb.warm[k]; V.qlag(k, i) = E.qlag6[k]; }
+  for (int k = 0; k < 7; k++) V.qlag(12 + k, i) = E.qlag7[k];
+  for (int k = 0; k < 3; k++) V.goal(k, i) = E.goal[k];
+  V.dr(0, i) = E.dr[0]; V.dr(1, i) = E.dr[1];
+  V.epret(i) = E.epret; V.elapsed(i) = E.elapsed; V.episode(i) = E.episode; V.eplen(i) = E.eplen;
+}
+
+// reset_model with an object (mycobot.py:207-236): cube xy resampled until >= 0.1 from the initial gripper xy,
+// goal until >= 0.1 from the cube; per-reset domain randomisation (build-defined) on its own stream.
+__device__ void reset_envp(const Cfg& C, int i, EnvP& E, bool doit) {
+  real drs[2] = {1.0, 1.0};
+  if (C.dr_enable) {
+    real um, uf; rng_pair(C, i, E.episode, 0, 1, um, uf);
+    drs[0] = C.dr_mass[0] + (C.dr_mass[1] - C.dr_mass[0]) * um;
+    drs[1] = C.dr_fric[0] + (C.dr_fric[1] - C.dr_fric[0]) * uf;
+  }
+  real oxy[2] = {C.igx[0], C.igx[1]}, goal[3] = {0, 0, 0};
+  uint32_t draw = 0;
+  bool need = true; int tries = 0;
+  do {                                              // object position (mycobot.py:217-219)
+    real g[3]; sample_goal(C, i, E.episode, draw, g);
+    const bool rej = sqrt((g[0] - C.igx[0]) * (g[0] - C.igx[0]) + (g[1] - C.igx[1]) * (g[1] - C.igx[1])) < 0.1;
+    oxy[0] = need ? g[0] : oxy[0]; oxy[1] = need ? g[1] : oxy[1];
+    draw += need ? 2u : 0u;
+    need = need && rej && (tries + 1 < 1000);
+    tries++;
+  } while (__any(need));
+  need = true; tries = 0;
+  do {                                              // goal (mycobot.py:231-233)
+    real g[3]; sample_goal(C, i, E.episode, draw, g);
+    const bool rej = sqrt((g[0] - oxy[0]) * (g[0] - oxy[0]) + (g[1] - oxy[1]) * (g[1] - oxy[1])) < 0.1;
+    for (int k = 0; k < 3; k++) goal[k] = need ? g[k] : goal[k];
+    draw += need ? 2u : 0u;
+    need = need && rej && (tries < 1000);
+    tries++;
+  } while (__any(need));
+  for (int k = 0; k < NB; k++) { E.R.q[k] = doit ? C.init_qpos[k] : E.R.q[k]; E.R.qd[k] = doit ? C.init_qvel[k] : E.R.qd[k]; }
+  for (int k = 0; k < 7; k++) E.R.ctrl[k] = doit ? C.init_ctrl[k] : E.R.ctrl[k];
+  for (int k = 0; k < 6; k++) { E.qlag6[k] = doit ? C.init_qpos[k] : E.qlag6[k]; E.Cb.vel[k] = doit ? C.init_qvel[12 + k] : E.Cb.vel[k]; }
+  E.Cb.pos[0] = doit ? oxy[0] : E.Cb.pos[0]; E.Cb.pos[1] = doit ? oxy[1] : E.Cb.pos[1]; E.Cb.pos[2] = doit ? C.init_qpos[14] : E.Cb.pos[2];
+  {   // mj_forward normalises the stored quaternion
+    real q[4] = {C.init_qpos[15], C.init_qpos[16], C.init_qpos[17], C.init_qpos[18]};
+    const real nq = sqrt(q[0]*q[0] + q[1]*q[1] + q[2]*q[2] + q[3]*q[3]);
+    for (int k = 0; k < 4; k++) E.Cb.quat[k] = doit ? q[k] / nq : E.Cb.quat[k];
+  }
+  for (int k = 0; k < 3; k++) E.qlag7[k] = doit ? E.Cb.pos[k] : E.qlag7[k];
+  for (int k = 0; k < 4; k++) E.qlag7[3 + k] = doit ? E.Cb.quat[k] : E.qlag7[3 + k];
+  for (int k = 0; k < 3; k++) E.goal[k] = doit ? goal[k] : E.goal[k];
+  E.dr[0] = doit ? drs[0] : E.dr[0]; E.dr[1] = doit ? drs[1] : E.dr[1];
+  E.elapsed = doit ? 0 : E.elapsed; E.epret = doit ? 0.0 : E.epret; E.eplen = doit ? 0 : E.eplen;
+  E.episode += doit ? 1 : 0;
+}
+
+// _get_obs with an object (mycobot.py:245-283, 342-388): 25 numbers, Appendix A.6 order
+__device__ void observe_pnp(const Cfg& C, ModelPtr P, const EnvP& E, real* obs, real* ag) {
+  EefPose X;
+  eef_forward(P, E.qlag6, X, true);
+  real gv[3];
+  for (int k = 0; k < 3; k++) { real v = 0; for (int j = 0; j < 6; j++) v += X.jacp[k][j] * E.R.qd[j]; gv[k] = v * C.dt; }
+  real Rl[9], eul[3];
+  quat_to_mat(E.qlag7 + 3, Rl); mat2euler(Rl, eul);
+  for (int k = 0; k < 3; k++) {
+    obs[k] = X.pos[k]; obs[3 + k] = E.qlag7[k]; obs[6 + k] = E.qlag7[k] - X.pos[k];
+    obs[11 + k] = eul[k];
+    obs[14 + k] = E.Cb.vel[k] * C.dt - gv[k];                                         // site at the cube origin: jacp = identity
+    obs[17 + k] = (Rl[3*k]*E.Cb.vel[3] + Rl[3*k+1]*E.Cb.vel[4] + Rl[3*k+2]*E.Cb.vel[5]) * C.dt;   // jacr = lagged body axes
+    obs[20 + k] = gv[k];
+    ag[k] = E.qlag7[k];
+  }
+  obs[9] = E.R.q[6]; obs[10] = E.R.q[8];
+  obs[23] = E.R.qd[6] * C.dt; obs[24] = E.R.qd[8] * C.dt;
+}
+
+template <int CONTROLLER>
+__global__ __launch_bounds__(PNP_LANES) void step_pnp_kernel(Cfg C, View V, const mcg_model* __restrict__ Pg,
+                                                             const float* __restrict__ actions, mcg_step_out O) {
+  __shared__ real lds[PNP_SLOTS][PNP_LANES];
+  const PnpScratch MS{&lds[0][threadIdx.x]};
+  const ModelPtr P = as_model_ptr(Pg);
+  const int i = blockIdx.x * PNP_LANES + threadIdx.x;
+  if (i >= C.n) return;
+  EnvP E;
+  load_envp(V, i, E);
+  float act[7];
+  for (int k = 0; k < C.act_dim; k++) { float x = actions[(size_t)i * C.act_dim + k]; act[k] = fminf(fmaxf(x, -1.f), 1.f); }
+  if constexpr (CONTROLLER == MCG_CTRL_IK) {
+    EefPose X;
+    eef_forward(P, E.qlag6, X, true);
+    real tpos[3], tquat[4];
+    for (int k = 0; k < 3; k++) tpos[k] = X.pos[k] + (real)(act[k] * 0.2f);
+    if (C.fetch) { tquat[0] = 0; tquat[1] = -0.707; tquat[2] = 0; tquat[3] = 0.707; }
+    else {
+      real e[3], qr[4], cur[4];
+      for (int k = 0; k < 3; k++) e[k] = (real)(act[3 + k] * 0.5f);
+      euler2quat(e, qr); mat2quat(X.mat, cur); mulquat(qr, cur, tquat);
+    }
+    const real grip = C.grip_center + (real)act[C.act_dim - 1] * C.grip_range;
+    for (int c = 0; c < C.control_steps; c++) {
+      if (c > 0) eef_forward(P, E.qlag6, X, true);
+      real dq[6];
+      ik_delta(X, tpos, tquat, dq);
+      for (int k = 0; k < 6; k++) E.R.ctrl[k] += dq[k];
+      E.R.ctrl[6] = grip;
+      for (int s = 0; s < C.frame_skip; s++) { robot_substep(P, E.R, E.qlag6, MS); cube_substep(P, E.Cb, E.qlag7, E.dr, MS); }
+    }
+  } else {
+    for (int k = 0; k < 7; k++) E.R.ctrl[k] = (real)act[k];
+    for (int s = 0; s < C.frame_skip; s++) { robot_substep(P, E.R, E.qlag6, MS); cube_substep(P, E.Cb, E.qlag7, E.dr, MS); }
+  }
+  real obs[25], ag[3];
+  observe_pnp(C, P, E, obs, ag);
+  real dx = ag[0] - E.goal[0], dy = ag[1] - E.goal[1], dz = ag[2] - E.goal[2];
+  const real dist = sqrt(dx * dx + dy * dy + dz * dz);
+  const bool succ = dist < C.distance_threshold;
+  const real rew = C.reward_type == MCG_REWARD_SPARSE ? -(real)(float)(dist > C.distance_threshold) : -dist;
+  E.elapsed++; E.eplen++; E.epret += rew;
+  const bool term = succ, trunc = succ || (E.elapsed >= C.max_episode_steps);
+  if (O.reward) O.reward[i] = rew;
+  if (O.terminated) O.terminated[i] = term;
+  if (O.truncated) O.truncated[i] = trunc;
+  if (O.is_success) O.is_success[i] = succ;
+  if (O.ep_return) O.ep_return[i] = E.epret;
+  if (O.ep_length) O.ep_length[i] = E.eplen;
+  const bool done = (term || trunc) && C.auto_reset;
+  if (__any(done)) {
+    if (done) {
+      if (O.final_obs) for (int k = 0; k < 25; k++) O.final_obs[(size_t)i * 25 + k] = obs[k];
+      if (O.final_achieved) for (int k = 0; k < 3; k++) O.final_achieved[(size_t)i * 3 + k] = ag[k];
+      if (O.final_desired) for (int k = 0; k < 3; k++) O.final_desired[(size_t)i * 3 + k] = E.goal[k];
+    }
+    reset_envp(C, i, E, done);
+    real obs2[25], ag2[3];
+    observe_pnp(C, P, E, obs2, ag2);
+    for (int k = 0; k < 25; k++) obs[k] = done ? obs2[k] : obs[k];
+    for (int k = 0; k < 3; k++) ag[k] = done ? ag2[k] : ag[k];
+  }
+  write_obs(O, i, 25, obs, ag, E.goal);
+  store_envp(V, i, E);
+}
+
+__global__ __launch_bounds__(PNP_LANES) void reset_pnp_kernel(Cfg C, View V, const mcg_model* __restrict__ Pg,
+                                                              const uint8_t* __restrict__ mask, int reseed, mcg_step_out O) {
+  const int i = blockIdx.x * PNP_LANES + threadIdx.x;
+  if (i >= C.n) return;
+  const ModelPtr P = as_model_ptr(Pg);
+  EnvP E;
+  load_envp(V, i, E);
+  const bool doit = !mask || mask[i];
+  E.episode = (doit && reseed) ? 0 : E.episode;
+  reset_envp(C, i, E, doit);
+  store_envp(V, i, E);
+  real obs[25], ag[3];
+  observe_pnp(C, P, E, obs, ag);
+  write_obs(O, i, 25, obs, ag, E.goal);
+}
+
 // compute_reward on batched goals (mycobot.py:289-298) -- the HER entry point
 __global__ void reward_kernel(const double* __restrict__ ag, const double* __restrict__ dg, int n, int reward_type,
                               double thr, double* __restrict__ out) {
@@ -241,6 +425,7 @@ __global__ void copy_state_kernel(View V, mcg_state S, int to_engine) {
   const int n = V.n;
 #define CP(ptr, acc, cnt) if (S.ptr) for (int k = 0; k < cnt; k++) { if (to_engine) V.acc(k, i) = S.ptr[(size_t)k * n + i]; else S.ptr[(size_t)k * n + i] = V.acc(k, i); }
   CP(qpos, qpos, V.nq) CP(qvel, qvel, V.nv) CP(ctrl, ctrl, 7) CP(warm, warm, V.nv) CP(qpos_lag, qlag, V.nq) CP(goal, goal, 3)
+  CP(dr_scale, dr, 2)
 #undef CP
   if (S.elapsed) { if (to_engine) V.elapsed(i) = S.elapsed[i]; else S.elapsed[i] = V.elapsed(i); }
   if (S.episode) { if (to_engine) V.episode(i) = S.episode[i]; else S.episode[i] = V.episode(i); }
@@ -270,7 +455,6 @@ int mcg_default_model(int variant, mcg_model* out) {
 int mcg_create(const mcg_config* c, const mcg_model* model, int device, mcg_env** out) {
   if (!c || !out) return fail(MCG_ERR_ARG, "mcg_create: null argument%s");
   if (c->n_envs <= 0) return fail(MCG_ERR_ARG, "mcg_create: n_envs must be positive%s");
-  if (c->has_object) return fail(MCG_ERR_UNSUPPORTED, "mcg_create: PickAndPlace (has_object) is not built yet%s");
   if (c->controller != MCG_CTRL_JOINT && c->controller != MCG_CTRL_IK) return fail(MCG_ERR_ARG, "mcg_create: controller must be joint or IK%s");
   if (c->controller == MCG_CTRL_JOINT && c->fetch_env) return fail(MCG_ERR_ARG, "Joint controller not supported for Fetch env%s");  // mycobot.py:96
   if (c->reward_type == MCG_REWARD_SHAPING) return fail(MCG_ERR_UNSUPPORTED, "mcg_create: reward_shaping needs the contact stage (not built yet)%s");
@@ -306,6 +490,9 @@ int mcg_create(const mcg_config* c, const mcg_model* model, int device, mcg_env*
   memcpy(C.init_qvel, c->init_qvel, sizeof(C.init_qvel));
   memcpy(C.init_ctrl, c->init_ctrl, sizeof(C.init_ctrl));
   C.seed = c->seed; C.env_id_offset = c->env_id_offset;
+  C.dr_enable = c->dr_enable && c->has_object;
+  C.dr_mass[0] = c->dr_mass_range[0]; C.dr_mass[1] = c->dr_mass_range[1];
+  C.dr_fric[0] = c->dr_friction_range[0]; C.dr_fric[1] = c->dr_friction_range[1];
   e->device = device;
   e->view.n = C.n; e->view.nq = C.nq; e->view.nv = C.nv;
   size_t nd = (size_t)state_doubles(C.nq, C.nv) * C.n;
@@ -314,6 +501,10 @@ int mcg_create(const mcg_config* c, const mcg_model* model, int device, mcg_env*
   if (err == hipSuccess) err = hipMalloc(&e->d_model, sizeof(mcg_model));
   if (err == hipSuccess) err = hipMemset(e->view.d, 0, nd * sizeof(double));
   if (err == hipSuccess) err = hipMemset(e->view.i32, 0, (size_t)3 * C.n * sizeof(int32_t));
+  if (err == hipSuccess) {          // domain-randomisation scales start at 1
+    std::vector<double> ones((size_t)2 * C.n, 1.0);
+    err = hipMemcpy(e->view.d + (size_t)(2 * C.nq + 2 * C.nv + 11) * C.n, ones.data(), ones.size() * sizeof(double), hipMemcpyHostToDevice);
+  }
   if (err == hipSuccess) err = hipMemcpy(e->d_model, m, sizeof(mcg_model), hipMemcpyHostToDevice);
   if (err != hipSuccess) { mcg_destroy(e); return fail(MCG_ERR_HIP, "mcg_create: %s", hipGetErrorString(err)); }
   *out = e;
@@ -339,13 +530,26 @@ static mcg_step_out out_or_empty(const mcg_step_out* o) { mcg_step_out z; memset
 int mcg_reset(mcg_env* e, const uint8_t* mask, int reseed, uint64_t seed, const mcg_step_out* out, void* stream) {
   if (!e) return fail(MCG_ERR_ARG, "mcg_reset: null handle%s");
   if (reseed) e->cfg.seed = seed;
-  dim3 grid((e->cfg.n + 63) / 64), block(64);
-  hipLaunchKernelGGL(reset_reach_kernel, grid, block, 0, (hipStream_t)stream, e->cfg, e->view, e->d_model, mask, reseed, out_or_empty(out));
+  if (e->cfg.has_object) {
+    dim3 grid((e->cfg.n + PNP_LANES - 1) / PNP_LANES), block(PNP_LANES);
+    hipLaunchKernelGGL(reset_pnp_kernel, grid, block, 0, (hipStream_t)stream, e->cfg, e->view, e->d_model, mask, reseed, out_or_empty(out));
+  } else {
+    dim3 grid((e->cfg.n + 63) / 64), block(64);
+    hipLaunchKernelGGL(reset_reach_kernel, grid, block, 0, (hipStream_t)stream, e->cfg, e->view, e->d_model, mask, reseed, out_or_empty(out));
+  }
   HIP_OK(hipGetLastError());
   return MCG_OK;
 }
 
 static int launch_step(mcg_env* e, const float* actions, const mcg_step_out& o, hipStream_t s) {
+  if (e->cfg.has_object) {
+    dim3 grid((e->cfg.n + PNP_LANES - 1) / PNP_LANES), block(PNP_LANES);
+    if (e->cfg.controller == MCG_CTRL_IK)
+      hipLaunchKernelGGL(step_pnp_kernel<MCG_CTRL_IK>, grid, block, 0, s, e->cfg, e->view, e->d_model, actions, o);
+    else
+      hipLaunchKernelGGL(step_pnp_kernel<MCG_CTRL_JOINT>, grid, block, 0, s, e->cfg, e->view, e->d_model, actions, o);
+    return hipGetLastError() == hipSuccess ? MCG_OK : MCG_ERR_HIP;
+  }
   dim3 grid((e->cfg.n + 63) / 64), block(64);
   if (e->cfg.controller == MCG_CTRL_IK)
     hipLaunchKernelGGL(step_reach_kernel<MCG_CTRL_IK>, grid, block, 0, s, e->cfg, e->view, e->d_model, actions, o);

@@ -204,6 +204,9 @@ def specialize(m: dict) -> dict:
         bt = lambda g: biw[m["geom_body"][g]]
         out["contact_diag"] = np.array([[bt(ga)[0] + bt(gc)[0], bt(ga)[1] + bt(gc)[1]] for ga in (gt, gr, gl)])
         out["cube_invweight"] = np.array([diw[12], diw[15]])
+        out["geom_friction0"] = np.array([m["geom_friction"][gt][0], m["geom_friction"][gr][0], m["geom_friction"][gc][0]])
+        # structural facts the cube kernels rely on: CoM at the body origin, principal axes = body axes
+        assert np.allclose(mc[12], 0) and np.allclose(inertia[12][3:], 0), "cube: centred, axis-aligned inertia expected"
         out["geom_ids"] = {"table": gt, "cube": gc, "pad_r": gr, "pad_l": gl}
     return out
 

@@ -219,7 +219,8 @@ class MyCobotVecEnv:
                 "ctrl": torch.zeros(7, n, **f64), "warm": torch.zeros(self.nv, n, **f64),
                 "qpos_lag": torch.zeros(self.nq, n, **f64), "goal": torch.zeros(3, n, **f64),
                 "elapsed": torch.zeros(n, dtype=torch.int32, device=dev),
-                "episode": torch.zeros(n, dtype=torch.int32, device=dev)}
+                "episode": torch.zeros(n, dtype=torch.int32, device=dev),
+                "dr_scale": torch.ones(2, n, **f64)}
 
     def get_state(self) -> dict:
         """SoA tensors [dim, N] (the engine's layout): qpos qvel ctrl warm qpos_lag goal elapsed episode."""

@@ -34,7 +34,7 @@ extern "C" {
 #define MCO_MAXTEN 2
 #define MCO_MAXTENJ 4
 #define MCO_MAXEXCL 16
-#define MCO_MAXCON 32
+#define MCO_MAXCON 12      /* contacts kept per env; the HIP kernels use the same cap (MAXCON in mcg_cube.hpp) */
 #define MCO_MAXEFC 224
 
 enum { MCO_JNT_FREE = 0, MCO_JNT_HINGE = 3 };

@@ -1,0 +1,98 @@
+"""GPU parity for PickAndPlace (has_object): cube free joint, box/plane contacts, 25-number observation, object reset.
+
+Same method as tests/test_gpu_parity.py: sub-steps compared from identical state (teacher-forced) because free-running
+trajectories are chaotic; reset draws bit-exact.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_cuda(built):
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+@pytest.mark.parametrize("controller", ["joint", "IK"])
+def test_reset_bit_exact_with_object(torch_cuda, controller):
+    from tests.common import make_pair
+    envs, ora = make_pair(512, has_object=True, controller_type=controller, seed=21)
+    obs, _ = envs.reset(seed=21)
+    o_obs, o_ag, o_dg = ora.reset(seed=21)
+    assert obs["observation"].shape == (512, 25)
+    assert np.array_equal(obs["desired_goal"].cpu().numpy(), o_dg)
+    assert np.array_equal(obs["achieved_goal"].cpu().numpy(), o_ag)             # cube xy from the same Philox draws
+    assert np.abs(obs["observation"].cpu().numpy() - o_obs).max() < 1e-14
+    envs.close()
+
+
+def _substep_run(torch, n, steps, prepare=None, seed=5):
+    from tests.common import make_pair, sync_oracle_to, step_errors
+    kw = dict(has_object=True, controller_type="joint", reward_type="dense", seed=seed, frame_skip=1, max_episode_steps=10 ** 9)
+    envs, ora = make_pair(n, **kw)
+    envs.reset(seed=seed); ora.reset(seed=seed)
+    if prepare is not None:
+        prepare(ora)
+    rng = np.random.default_rng(3)
+    worst = dict(obs=0.0, qpos=0.0, qvel=0.0)
+    ncon_seen = set()
+    for t in range(steps):
+        if t % 20 == 0:
+            a = rng.uniform(-1, 1, (n, 7)).astype(np.float32)
+        sync_oracle_to(envs, ora)
+        e, flags_equal, o = step_errors(envs, ora, a)
+        assert flags_equal
+        st, so = envs.get_state(), ora.get_state()
+        worst["obs"] = max(worst["obs"], e.max())
+        worst["qpos"] = max(worst["qpos"], np.abs(st["qpos"].cpu().numpy().T - so["qpos"]).max())
+        worst["qvel"] = max(worst["qvel"], np.abs(st["qvel"].cpu().numpy().T - so["qvel"]).max())
+        for i in range(0, n, 8):
+            ncon_seen.add(int(ora.data(i).get("ncon", (1,), np.int32)[0]))
+    envs.close()
+    return worst, ncon_seen
+
+
+def test_substeps_cube_resting_on_table(torch_cuda):
+    worst, ncon = _substep_run(torch_cuda, 128, 400)
+    print(f"\nresting cube, 400 sub-steps x 128 envs: {worst}, contact counts seen {sorted(ncon)}")
+    assert 4 in ncon
+    assert worst["obs"] < 1e-9 and worst["qpos"] < 1e-9 and worst["qvel"] < 1e-7
+
+
+def test_substeps_cube_tumbling_onto_table(torch_cuda):
+    """Cubes dropped from 3 cm with random attitude and spin: vertex, edge and face contacts, make/break events."""
+    def prepare(ora):
+        s = ora.get_state()
+        rng = np.random.default_rng(11)
+        n = s["qpos"].shape[0]
+        q = rng.normal(size=(n, 4)); q /= np.linalg.norm(q, axis=1, keepdims=True)
+        s["qpos"][:, 14] = 0.24; s["qpos"][:, 15:19] = q
+        s["qvel"][:, 12:15] = rng.normal(size=(n, 3)) * 0.1; s["qvel"][:, 15:18] = rng.normal(size=(n, 3)) * 5.0
+        s["qpos_lag"] = s["qpos"].copy()
+        ora.set_state(**s)
+    worst, ncon = _substep_run(torch_cuda, 128, 500, prepare=prepare)
+    print(f"\ntumbling cube, 500 sub-steps x 128 envs: {worst}, contact counts seen {sorted(ncon)}")
+    assert len(ncon) >= 3
+    assert worst["obs"] < 1e-8 and worst["qpos"] < 1e-8 and worst["qvel"] < 1e-5
+
+
+def test_env_steps_with_object(torch_cuda):
+    from tests.common import make_pair, sync_oracle_to, step_errors
+    n = 128
+    for controller in ("joint", "IK"):
+        envs, ora = make_pair(n, has_object=True, controller_type=controller, reward_type="sparse", seed=2)
+        envs.reset(seed=2); ora.reset(seed=2)
+        rng = np.random.default_rng(8)
+        errs = []
+        for t in range(55):
+            sync_oracle_to(envs, ora)
+            e, flags_equal, o = step_errors(envs, ora, rng.uniform(-1, 1, (n, 7)).astype(np.float32))
+            assert flags_equal
+            errs.append(e)
+        errs = np.concatenate(errs)
+        print(f"\n[{controller}] PickAndPlace env-steps from identical state: median {np.median(errs):.2e} p99 {np.quantile(errs, 0.99):.2e}")
+        assert np.median(errs) < 1e-9
+        envs.close()
