@@ -22,7 +22,8 @@ constexpr int LDS_CON = LDS_SLOTS;
 constexpr int LDS_POLY = LDS_CON + MAXCON * CON_STRIDE;     // two clip polygons of 16 x 2
 constexpr int LDS_ROW = LDS_POLY + 64;                      // per pyramid row: r0, dr (line search)
 constexpr int LDS_ACT = LDS_ROW + MAXCON * 12;              // per contact: active-row bit mask (as a double)
-constexpr int PNP_SLOTS = LDS_ACT + MAXCON;
+constexpr int LDS_WJ = LDS_ACT + MAXCON;                    // world axis + anchor of the 10 joints in the pads' chains
+constexpr int PNP_SLOTS = LDS_WJ + 60;
 typedef LaneScratchT<PNP_LANES> PnpScratch;
 
 enum { PAIR_TABLE_CUBE = 0, PAIR_PADR_CUBE = 1, PAIR_PADL_CUBE = 2 };   // rows of mcg_model.contact_par / contact_diag
@@ -235,183 +236,462 @@ MCG_DEV void pyramid_row(const CubeRows& R, int r, const real* mu, real* j) {
   for (int d = 0; d < 6; d++) { const real jk = (k == 0) ? R.J1[d] : (k == 1) ? R.J2[d] : R.Jt[d]; j[d] = R.Jn[d] + m * jk; }
 }
 
-// One mj_step of the cube when no finger pad touches it (its dynamics then separates exactly from the robot's).
+// Robot-side entries of a pad-cube contact's rows, dofs (arm 0..5, gear, finger) of the pad's side.  The pad is geom1,
+// the cube geom2: J = J_cube - J_pad, so these enter with a minus sign.
+struct PadRows { real Jn[8], J1[8], J2[8], Jt[8]; };
+
+// The cube and its contacts for one sub-step: prepared before the robot's Newton solve, finished after it.
 template <class LS>
-MCG_DEV void cube_substep(ModelPtr Pm, Cube& Cb, real* qlag7, const real* dr, const LS S) {
-  ModelPtr Q = launder(Pm);
-  const real h = Q->timestep;
-  // mj_kinematics normalises the stored quaternion
-  {
-    const real nq = sqrt(Cb.quat[0]*Cb.quat[0] + Cb.quat[1]*Cb.quat[1] + Cb.quat[2]*Cb.quat[2] + Cb.quat[3]*Cb.quat[3]);
-    const bool tiny = nq < MINVAL;
-    for (int k = 0; k < 4; k++) Cb.quat[k] = tiny ? (k == 0 ? 1.0 : 0.0) : Cb.quat[k] / nq;
-  }
-  for (int k = 0; k < 3; k++) qlag7[k] = Cb.pos[k];
-  for (int k = 0; k < 4; k++) qlag7[3 + k] = Cb.quat[k];
-  real Rc[9]; quat_to_mat(Cb.quat, Rc);
-  // dr = per-env domain-randomisation scales (mass, sliding friction); (1, 1) when DR is off
-  const real mass = Q->body[12].mass * dr[0];
-  const real In[3] = {Q->body[12].inertia[0] * dr[0], Q->body[12].inertia[1] * dr[0], Q->body[12].inertia[2] * dr[0]};
-  real Md[6] = {mass, mass, mass, In[0], In[1], In[2]};
-  real damp[6]; ldc<6>(Q->cube_damping, damp);
-  // qfrc_smooth = passive - bias: gravity on the translation, gyroscopic term on the (body-frame) rotation
-  real gb[3]; ldc<3>(Q->gravity_base, gb);             // base frame is a rotation about z: the z component is world z
-  real fs[6];
-  const real* w = Cb.vel + 3;
-  const real Iw[3] = {In[0]*w[0], In[1]*w[1], In[2]*w[2]};
-  real gyro[3]; cross(w, Iw, gyro);
-  fs[0] = -damp[0]*Cb.vel[0]; fs[1] = -damp[1]*Cb.vel[1]; fs[2] = -damp[2]*Cb.vel[2] - mass * gb[2];
-  for (int k = 0; k < 3; k++) fs[3 + k] = -damp[3 + k]*w[k] - gyro[k];
+struct CubeSys {
+  static constexpr bool enabled = true;
+  const LS S; Cube& Cb; const real* dr;        // (the model pointer is passed in: it must stay a scalar register)
+  real h, Rc[9], Md[6], damp[6], fs[6];
+  real B_tc, B_pc, mu_tc[3], mu_pc[3];
+  int ncon; bool any_pad, solved;
+  real a_c[6], fc[6];
 
-  // ---- P4 collision: ground plane (only when low), table top
-  ContactList<LS> CL{S, 0};
-  real hc[3]; ldc<3>(Q->cube_half, hc);
-  if (__any(Cb.pos[2] < 0.05)) {
-    ContactList<LS> G{S, 0};
-    G.n = CL.n;
-    const bool low = Cb.pos[2] < 0.05;
-    real far[3] = {Cb.pos[0], Cb.pos[1], low ? Cb.pos[2] : 1.0};
-    ground_box(G, far, Rc, hc, PAIR_TABLE_CUBE);
-    CL.n = G.n;
-  }
-  {
-    real tp[3], th[3]; ldc<3>(Q->table_pos, tp); ldc<3>(Q->table_half, th);
-    const real Rt[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-    const real dx = Cb.pos[0] - tp[0], dy = Cb.pos[1] - tp[1], dz = Cb.pos[2] - tp[2];
-    const real rs = sqrt(dot3(th, th)) + sqrt(dot3(hc, hc));
-    const bool near = dx*dx + dy*dy + dz*dz <= rs*rs;
-    if (__any(near)) box_box(CL, near, tp, Rt, th, Cb.pos, Rc, hc, PAIR_TABLE_CUBE);
-  }
-  const int ncon = CL.n;
-
-  // ---- P5 per-contact solver numbers (all 6 pyramid rows share D and the position term)
-  real par[15]; ldc<15>(Q->contact_par[PAIR_TABLE_CUBE], par);
-  const real tran = Q->contact_diag[PAIR_TABLE_CUBE][0];
-  // sliding friction re-mixed (element-wise max) with the randomised cube friction; torsional friction as compiled
-  const real mu0 = fmax(Q->geom_friction0[0], Q->geom_friction0[2] * dr[1]);
-  const real mu[3] = {mu0, mu0, par[12]};
-  for (int c = 0; __any(c < ncon); c++) {
-    const int b = LDS_CON + c * CON_STRIDE;
-    const real dist = S.ld(b + 12);
-    const real imp = impedance(par, dist);
-    const real Rn = fmax(MINVAL, (1 - imp) * tran * (1 + mu[0]*mu[0]) / imp);
-    const real Rpy = fmax(MINVAL, 2 * mu[0]*mu[0] * Rn);
-    if (c < ncon) { S.st(b + 13, 1.0 / Rpy); S.st(b + 14, par[0] * imp * dist); }
-  }
-
-  // ---- P9 Newton on the 6 cube dofs; active set = pyramid rows with J a - aref < 0
-  real a[6];
-  for (int k = 0; k < 6; k++) a[k] = Cb.warm[k];
-  auto row_aref = [&](const real* j, real kterm) {       // aref = -B (J qvel) - K imp dist
-    real v = 0; for (int d = 0; d < 6; d++) v += j[d] * Cb.vel[d];
-    return -par[1] * v - kterm;
-  };
-  // initial active set from the warm start
-  for (int c = 0; __any(c < ncon); c++) {
-    CubeRows R; cube_rows(S, c, Rc, Cb.pos, R);
-    const real kterm = S.ld(LDS_CON + c * CON_STRIDE + 14);
-    int mask = 0;
-    for (int r = 0; r < 6; r++) {
-      real j[6]; pyramid_row(R, r, mu, j);
-      real ja = 0; for (int d = 0; d < 6; d++) ja += j[d] * a[d];
-      mask |= (ja - row_aref(j, kterm) < 0) ? (1 << r) : 0;
+  // ------------------------------------------------------------------------------------------------- prepare
+  MCG_DEV void prepare(ModelPtr Pm, const real* qr) {
+    ModelPtr Q = launder(Pm);
+    h = Q->timestep;
+    {   // mj_kinematics normalises the stored quaternion
+      const real nq = sqrt(Cb.quat[0]*Cb.quat[0] + Cb.quat[1]*Cb.quat[1] + Cb.quat[2]*Cb.quat[2] + Cb.quat[3]*Cb.quat[3]);
+      const bool tiny = nq < MINVAL;
+      for (int k = 0; k < 4; k++) Cb.quat[k] = tiny ? (k == 0 ? 1.0 : 0.0) : Cb.quat[k] / nq;
     }
-    if (c < ncon) S.st(LDS_ACT + c, (real)mask);
-  }
-  bool conv = false;
-  for (int it = 0; it < 50; it++) {
-    // H = M + sum_active D j j^T (packed lower 6x6), g = fs + sum_active D aref j
-    real H[21], g[6];
-    for (int k = 0; k < 21; k++) H[k] = 0;
-    for (int k = 0; k < 6; k++) { H[tri(k, k)] = Md[k]; g[k] = fs[k]; }
+    quat_to_mat(Cb.quat, Rc);
+    const real mass = Q->body[12].mass * dr[0];
+    const real In[3] = {Q->body[12].inertia[0] * dr[0], Q->body[12].inertia[1] * dr[0], Q->body[12].inertia[2] * dr[0]};
+    Md[0] = Md[1] = Md[2] = mass; Md[3] = In[0]; Md[4] = In[1]; Md[5] = In[2];
+    ldc<6>(Q->cube_damping, damp);
+    real gb[3]; ldc<3>(Q->gravity_base, gb);
+    const real* w = Cb.vel + 3;
+    const real Iw[3] = {In[0]*w[0], In[1]*w[1], In[2]*w[2]};
+    real gyro[3]; cross(w, Iw, gyro);
+    fs[0] = -damp[0]*Cb.vel[0]; fs[1] = -damp[1]*Cb.vel[1]; fs[2] = -damp[2]*Cb.vel[2] - mass * gb[2];
+    for (int k = 0; k < 3; k++) fs[3 + k] = -damp[3 + k]*w[k] - gyro[k];
+    solved = false;
+    for (int k = 0; k < 6; k++) { a_c[k] = Cb.warm[k]; fc[k] = 0; }
+
+    // friction after domain randomisation: element-wise max of the (scaled) geom frictions
+    const real ft = Q->geom_friction0[0], fp = Q->geom_friction0[1] * dr[1], fcb = Q->geom_friction0[2] * dr[1];
+    mu_tc[0] = mu_tc[1] = fmax(ft, fcb); mu_tc[2] = Q->contact_par[PAIR_TABLE_CUBE][12];
+    mu_pc[0] = mu_pc[1] = fmax(fp, fcb); mu_pc[2] = Q->contact_par[PAIR_PADR_CUBE][12];
+    B_tc = Q->contact_par[PAIR_TABLE_CUBE][1]; B_pc = Q->contact_par[PAIR_PADR_CUBE][1];
+
+    // ---- P4 collision, in the oracle's pair order: ground-cube, table-cube, right pad-cube, left pad-cube
+    ContactList<LS> CL{S, 0};
+    real hc[3]; ldc<3>(Q->cube_half, hc);
+    if (__any(Cb.pos[2] < 0.05)) {
+      const bool low = Cb.pos[2] < 0.05;
+      const real far[3] = {Cb.pos[0], Cb.pos[1], low ? Cb.pos[2] : 1.0};
+      ground_box(CL, far, Rc, hc, PAIR_TABLE_CUBE);
+    }
+    {
+      real tp[3], th[3]; ldc<3>(Q->table_pos, tp); ldc<3>(Q->table_half, th);
+      const real Rt[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+      const real dx = Cb.pos[0] - tp[0], dy = Cb.pos[1] - tp[1], dz = Cb.pos[2] - tp[2];
+      const real rs = sqrt(dot3(th, th)) + sqrt(dot3(hc, hc));
+      const bool near = dx*dx + dy*dy + dz*dz <= rs*rs;
+      if (__any(near)) box_box(CL, near, tp, Rt, th, Cb.pos, Rc, hc, PAIR_TABLE_CUBE);
+    }
+    // world frames of the arm joints and of the two gear / finger joints (mj_kinematics for the pads' chain)
+    {
+      const TrigC T = load_trig();
+      real R[9], p[3];
+      for (int k = 0; k < 9; k++) R[k] = Q->base_mat[k];
+      for (int k = 0; k < 3; k++) p[k] = Q->base_pos[k];
+      auto joint = [&](int slot, int K, int sg, const real* r, real ang, real* Rio, real* pio) {
+        for (int k = 0; k < 3; k++) pio[k] += Rio[3*k]*r[0] + Rio[3*k+1]*r[1] + Rio[3*k+2]*r[2];
+        for (int k = 0; k < 3; k++) { S.st(LDS_WJ + slot*6 + k, sg * Rio[3*k + K]); S.st(LDS_WJ + slot*6 + 3 + k, pio[k]); }
+        real sn_, cs_; sincos_cw(T, sg * ang, sn_, cs_);
+        const int A = (K + 1) % 3, B = (K + 2) % 3;
+        for (int k = 0; k < 3; k++) {
+          const real ca = Rio[3*k + A], cb = Rio[3*k + B];
+          Rio[3*k + A] = cs_ * ca + sn_ * cb; Rio[3*k + B] = -sn_ * ca + cs_ * cb;
+        }
+      };
+      static_for<6>([&](auto I) { constexpr int i = I; real r[3]; ldc<3>(Q->body[i].r, r); joint(i, AXK[i], AXS[i], r, qr[i], R, p); });
+      const real dxe = p[0] - Cb.pos[0], dye = p[1] - Cb.pos[1], dze = p[2] - Cb.pos[2];
+      const bool reach = dxe*dxe + dye*dye + dze*dze < 0.2 * 0.2;      // link6 origin within 20 cm of the cube
+      any_pad = false;
+      if (__any(reach)) {
+        static_for<2>([&](auto Sd) {
+          constexpr int sd = Sd; constexpr int g = 6 + 2 * sd, f = 7 + 2 * sd;
+          real Rs[9], ps[3];
+          for (int k = 0; k < 9; k++) Rs[k] = R[k];
+          for (int k = 0; k < 3; k++) ps[k] = p[k];
+          real r[3]; ldc<3>(Q->body[g].r, r); joint(g, 1, AXS[g], r, qr[g], Rs, ps);
+          ldc<3>(Q->body[f].r, r); joint(f, 1, AXS[f], r, qr[f], Rs, ps);
+          real pb[6]; ldc<6>(Q->pad_box[sd], pb);
+          real pc[3];
+          for (int k = 0; k < 3; k++) pc[k] = ps[k] + Rs[3*k]*pb[0] + Rs[3*k+1]*pb[1] + Rs[3*k+2]*pb[2];
+          const real dx = Cb.pos[0] - pc[0], dy = Cb.pos[1] - pc[1], dz = Cb.pos[2] - pc[2];
+          const real rs = sqrt(pb[3]*pb[3] + pb[4]*pb[4] + pb[5]*pb[5]) + sqrt(dot3(hc, hc));
+          const bool near = reach && (dx*dx + dy*dy + dz*dz <= rs*rs);
+          const int before = CL.n;
+          if (__any(near)) box_box(CL, near, pc, Rs, pb + 3, Cb.pos, Rc, hc, PAIR_PADR_CUBE + sd);
+          any_pad = any_pad || (CL.n > before);
+        });
+      }
+    }
+    ncon = CL.n;
+    // ---- P5 per-contact solver numbers (the 6 pyramid rows of a contact share D and the position term)
+    real par_t[15], par_p[15];
+    ldc<15>(Q->contact_par[PAIR_TABLE_CUBE], par_t); ldc<15>(Q->contact_par[PAIR_PADR_CUBE], par_p);
     for (int c = 0; __any(c < ncon); c++) {
-      CubeRows R; cube_rows(S, c, Rc, Cb.pos, R);
       const int b = LDS_CON + c * CON_STRIDE;
-      const real D = (c < ncon) ? S.ld(b + 13) : 0.0, kterm = S.ld(b + 14);
-      const int mask = (c < ncon) ? (int)S.ld(LDS_ACT + c) : 0;
-      for (int r = 0; r < 6; r++) {
-        real j[6]; pyramid_row(R, r, mu, j);
-        const real wgt = ((mask >> r) & 1) ? D : 0.0;
-        const real ar = row_aref(j, kterm);
-        for (int d = 0; d < 6; d++) { const real wj = wgt * j[d]; g[d] += wj * ar; for (int e = 0; e <= d; e++) H[tri(d, e)] += wj * j[e]; }
-      }
+      const real dist = S.ld(b + 12);
+      const int type = (c < ncon) ? (int)S.ld(b + 15) : 0;
+      const bool pad = type != PAIR_TABLE_CUBE;
+      const real imp = pad ? impedance(par_p, dist) : impedance(par_t, dist);
+      const real tran = pad ? (type == PAIR_PADR_CUBE ? Q->contact_diag[PAIR_PADR_CUBE][0] : Q->contact_diag[PAIR_PADL_CUBE][0])
+                            : Q->contact_diag[PAIR_TABLE_CUBE][0];
+      const real m0 = pad ? mu_pc[0] : mu_tc[0];
+      const real Rn = fmax(MINVAL, (1 - imp) * tran * (1 + m0*m0) / imp);
+      const real Rpy = fmax(MINVAL, 2 * m0*m0 * Rn);
+      if (c < ncon) { S.st(b + 13, 1.0 / Rpy); S.st(b + 14, (pad ? par_p[0] : par_t[0]) * imp * dist); }
     }
-    real x[6];
-    for (int k = 0; k < 6; k++) x[k] = g[k];
-    chol_factor<6>(H); chol_solve<6>(H, x);
-    // active set at x; r0 / dr per row for the line search
-    real p[6]; for (int k = 0; k < 6; k++) p[k] = x[k] - a[k];
-    bool same = true;
+  }
+
+  // rows of contact c in the cube's dofs / in the robot's dofs of the pad's side
+  MCG_DEV void rows_cube(int c, CubeRows& R) const { cube_rows(S, c, Rc, Cb.pos, R); }
+  MCG_DEV void rows_pad(int c, int side, PadRows& P) const {
+    const int b = LDS_CON + c * CON_STRIDE;
+    real pos[3], n[3], t1[3], t2[3];
+    for (int k = 0; k < 3; k++) { pos[k] = S.ld(b + k); n[k] = S.ld(b + 3 + k); t1[k] = S.ld(b + 6 + k); t2[k] = S.ld(b + 9 + k); }
+    for (int j = 0; j < 8; j++) {
+      const int slot = (j < 6) ? j : (6 + 2 * side + (j - 6));
+      real ax[3], an[3], lev[3], v[3];
+      for (int k = 0; k < 3; k++) { ax[k] = S.ld(LDS_WJ + slot*6 + k); an[k] = S.ld(LDS_WJ + slot*6 + 3 + k); lev[k] = pos[k] - an[k]; }
+      cross(ax, lev, v);
+      P.Jn[j] = -dot3(n, v); P.J1[j] = -dot3(t1, v); P.J2[j] = -dot3(t2, v); P.Jt[j] = -dot3(n, ax);
+    }
+  }
+  MCG_DEV static void pyr8(const PadRows& P, int r, const real* mu, real* j) {
+    const int k = r >> 1; const real m = ((r & 1) ? -1.0 : 1.0) * ((k == 0) ? mu[0] : (k == 1) ? mu[1] : mu[2]);
+    for (int d = 0; d < 8; d++) { const real jk = (k == 0) ? P.J1[d] : (k == 1) ? P.J2[d] : P.Jt[d]; j[d] = P.Jn[d] + m * jk; }
+  }
+
+  // ------------------------------------------------------------------------------------- cube alone (no pad contact)
+  MCG_DEV void solve_alone() {
+    const real* mu = mu_tc; const real Bc = B_tc;
+    real a[6];
+    for (int k = 0; k < 6; k++) a[k] = a_c[k];
+    auto row_aref = [&](const real* j, real kterm) { real v = 0; for (int d = 0; d < 6; d++) v += j[d] * Cb.vel[d]; return -Bc * v - kterm; };
     for (int c = 0; __any(c < ncon); c++) {
-      CubeRows R; cube_rows(S, c, Rc, Cb.pos, R);
+      CubeRows R; rows_cube(c, R);
       const real kterm = S.ld(LDS_CON + c * CON_STRIDE + 14);
-      const int mask = (int)S.ld(LDS_ACT + c);
+      int mask = 0;
       for (int r = 0; r < 6; r++) {
         real j[6]; pyramid_row(R, r, mu, j);
-        real ja = 0, jp = 0; for (int d = 0; d < 6; d++) { ja += j[d] * a[d]; jp += j[d] * p[d]; }
-        const real r0 = ja - row_aref(j, kterm);
-        if (c < ncon) { S.st(LDS_ROW + (c * 6 + r) * 2, r0); S.st(LDS_ROW + (c * 6 + r) * 2 + 1, jp); }
-        const bool now = (r0 + jp) < 0;
-        same = same && (c >= ncon || now == (((mask >> r) & 1) != 0));
+        real ja = 0; for (int d = 0; d < 6; d++) ja += j[d] * a[d];
+        mask |= (ja - row_aref(j, kterm) < 0) ? (1 << r) : 0;
       }
+      if (c < ncon) S.st(LDS_ACT + c, (real)mask);
     }
-    const bool finish = !conv && same;
-    for (int k = 0; k < 6; k++) a[k] = finish ? x[k] : a[k];
-    conv = conv || finish;
-    if (!__any(!conv)) break;
-    // Line search along p on phi'(alpha) = sum_k M_k (a_k - as_k + alpha p_k) p_k + sum_rows D min(0, r0 + alpha dr) dr.
-    // Any descent step that ends in a consistent active set gives the exact minimiser at the final full step, so a
-    // bisection (24 halvings of [0, 2]) is enough here; the oracle walks the breakpoints exactly.
-    real lin0 = 0, quad = 0;
-    for (int k = 0; k < 6; k++) { const real as = fs[k] / Md[k]; lin0 += Md[k] * (a[k] - as) * p[k]; quad += Md[k] * p[k] * p[k]; }
-    auto dphi = [&](real al) {
-      real s = lin0 + al * quad;
+    bool conv = false;
+    for (int it = 0; it < 50; it++) {
+      real H[21], g[6];
+      for (int k = 0; k < 21; k++) H[k] = 0;
+      for (int k = 0; k < 6; k++) { H[tri(k, k)] = Md[k]; g[k] = fs[k]; }
       for (int c = 0; __any(c < ncon); c++) {
-        const real D = (c < ncon) ? S.ld(LDS_CON + c * CON_STRIDE + 13) : 0.0;
+        CubeRows R; rows_cube(c, R);
+        const int b = LDS_CON + c * CON_STRIDE;
+        const real D = (c < ncon) ? S.ld(b + 13) : 0.0, kterm = S.ld(b + 14);
+        const int mask = (c < ncon) ? (int)S.ld(LDS_ACT + c) : 0;
         for (int r = 0; r < 6; r++) {
-          const real r0 = S.ld(LDS_ROW + (c * 6 + r) * 2), dr = S.ld(LDS_ROW + (c * 6 + r) * 2 + 1);
-          const real rr = r0 + al * dr;
-          s += (rr < 0) ? D * rr * dr : 0.0;
+          real j[6]; pyramid_row(R, r, mu, j);
+          const real wgt = ((mask >> r) & 1) ? D : 0.0;
+          const real ar = row_aref(j, kterm);
+          for (int d = 0; d < 6; d++) { const real wj = wgt * j[d]; g[d] += wj * ar; for (int e = 0; e <= d; e++) H[tri(d, e)] += wj * j[e]; }
         }
       }
-      return s;
-    };
+      real x[6];
+      for (int k = 0; k < 6; k++) x[k] = g[k];
+      chol_factor<6>(H); chol_solve<6>(H, x);
+      real p[6]; for (int k = 0; k < 6; k++) p[k] = x[k] - a[k];
+      bool same = true;
+      for (int c = 0; __any(c < ncon); c++) {
+        CubeRows R; rows_cube(c, R);
+        const real kterm = S.ld(LDS_CON + c * CON_STRIDE + 14);
+        const int mask = (int)S.ld(LDS_ACT + c);
+        for (int r = 0; r < 6; r++) {
+          real j[6]; pyramid_row(R, r, mu, j);
+          real ja = 0, jp = 0; for (int d = 0; d < 6; d++) { ja += j[d] * a[d]; jp += j[d] * p[d]; }
+          const real r0 = ja - row_aref(j, kterm);
+          if (c < ncon) { S.st(LDS_ROW + (c * 6 + r) * 2, r0); S.st(LDS_ROW + (c * 6 + r) * 2 + 1, jp); }
+          const bool now = (r0 + jp) < 0;
+          same = same && (c >= ncon || now == (((mask >> r) & 1) != 0));
+        }
+      }
+      const bool finish = !conv && same;
+      for (int k = 0; k < 6; k++) a[k] = finish ? x[k] : a[k];
+      conv = conv || finish;
+      if (!__any(!conv)) break;
+      // Line search along p.  Any descent step that ends in a consistent active set yields the exact minimiser at the
+      // final full step, so bisection of phi' on [0, 2] is enough (the oracle walks the breakpoints exactly).
+      real lin0 = 0, quad = 0;
+      for (int k = 0; k < 6; k++) { const real as = fs[k] / Md[k]; lin0 += Md[k] * (a[k] - as) * p[k]; quad += Md[k] * p[k] * p[k]; }
+      const real alpha = bisect(lin0, quad);
+      for (int k = 0; k < 6; k++) a[k] = conv ? a[k] : a[k] + alpha * p[k];
+      remask(alpha, conv);
+    }
+    for (int k = 0; k < 6; k++) { a_c[k] = a[k]; fc[k] = 0; }
+    for (int c = 0; __any(c < ncon); c++) {
+      CubeRows R; rows_cube(c, R);
+      const int b = LDS_CON + c * CON_STRIDE;
+      const real D = (c < ncon) ? S.ld(b + 13) : 0.0, kterm = S.ld(b + 14);
+      for (int r = 0; r < 6; r++) {
+        real j[6]; pyramid_row(R, r, mu, j);
+        real ja = 0; for (int d = 0; d < 6; d++) ja += j[d] * a[d];
+        const real jar = ja - row_aref(j, kterm);
+        const real f = (jar < 0) ? -D * jar : 0.0;
+        for (int d = 0; d < 6; d++) fc[d] += j[d] * f;
+      }
+    }
+    solved = true;
+  }
+
+  // phi'(alpha) = lin0 + alpha quad + sum_rows D min(0, r0 + alpha dr) dr over the contact rows stored at LDS_ROW
+  MCG_DEV real dphi_rows(real al) const {
+    real s = 0;
+    for (int c = 0; __any(c < ncon); c++) {
+      const real D = (c < ncon) ? S.ld(LDS_CON + c * CON_STRIDE + 13) : 0.0;
+      for (int r = 0; r < 6; r++) {
+        const real r0 = S.ld(LDS_ROW + (c * 6 + r) * 2), dr_ = S.ld(LDS_ROW + (c * 6 + r) * 2 + 1);
+        const real rr = r0 + al * dr_;
+        s += (rr < 0) ? D * rr * dr_ : 0.0;
+      }
+    }
+    return s;
+  }
+  MCG_DEV real bisect(real lin0, real quad) const {
     real lo = 0, hi = 2;
-    const bool beyond = dphi(hi) < 0;
-    for (int b = 0; b < 24; b++) { const real mid = 0.5 * (lo + hi); const bool neg = dphi(mid) < 0; lo = neg ? mid : lo; hi = neg ? hi : mid; }
-    const real alpha = beyond ? 2.0 : 0.5 * (lo + hi);
-    for (int k = 0; k < 6; k++) a[k] = conv ? a[k] : a[k] + alpha * p[k];
+    const bool beyond = lin0 + 2 * quad + dphi_rows(2.0) < 0;
+    for (int b = 0; b < 24; b++) {
+      const real mid = 0.5 * (lo + hi);
+      const bool neg = lin0 + mid * quad + dphi_rows(mid) < 0;
+      lo = neg ? mid : lo; hi = neg ? hi : mid;
+    }
+    return beyond ? 2.0 : 0.5 * (lo + hi);
+  }
+  MCG_DEV void remask(real alpha, bool conv) const {
     for (int c = 0; __any(c < ncon); c++) {
       int mask = 0;
       for (int r = 0; r < 6; r++) {
-        const real r0 = S.ld(LDS_ROW + (c * 6 + r) * 2), dr = S.ld(LDS_ROW + (c * 6 + r) * 2 + 1);
-        mask |= (r0 + alpha * dr < 0) ? (1 << r) : 0;
+        const real r0 = S.ld(LDS_ROW + (c * 6 + r) * 2), dr_ = S.ld(LDS_ROW + (c * 6 + r) * 2 + 1);
+        mask |= (r0 + alpha * dr_ < 0) ? (1 << r) : 0;
       }
       if (c < ncon && !conv) S.st(LDS_ACT + c, (real)mask);
     }
   }
 
-  // ---- constraint force, implicit-damping Euler (diagonal M), free-joint integration
-  real fc[6] = {0, 0, 0, 0, 0, 0};
-  for (int c = 0; __any(c < ncon); c++) {
-    CubeRows R; cube_rows(S, c, Rc, Cb.pos, R);
-    const int b = LDS_CON + c * CON_STRIDE;
-    const real D = (c < ncon) ? S.ld(b + 13) : 0.0, kterm = S.ld(b + 14);
-    for (int r = 0; r < 6; r++) {
-      real j[6]; pyramid_row(R, r, mu, j);
-      real ja = 0; for (int d = 0; d < 6; d++) ja += j[d] * a[d];
-      const real jar = ja - row_aref(j, kterm);
-      const real f = (jar < 0) ? -D * jar : 0.0;
-      for (int d = 0; d < 6; d++) fc[d] += j[d] * f;
+  // --------------------------------------------------------------- coupled robot + cube Newton (a pad touches the cube)
+  // Unknowns a_r (12) and a_c (6).  Per iteration the cube block is eliminated (Schur complement), so the robot
+  // system stays a sparse 12x12 (pattern PAT_G) in registers.  Rows: joint limits, table-cube and pad-cube pyramids.
+  template <class BuildH>
+  MCG_DEV void solve_coupled(BuildH& build_H, const real* g0, const real* Dl, const real* arefl, const real* sgl,
+                             const real* qdr, real* ar, real* extra) {
+    // dof slot of (side, j): arm j -> j; gear -> 6 + 2 side; finger -> 7 + 2 side.  Gather helpers with selects:
+    auto gather8 = [](const real* v, int side, real* o) {
+      for (int j = 0; j < 6; j++) o[j] = v[j];
+      o[6] = side ? v[8] : v[6]; o[7] = side ? v[9] : v[7];
+    };
+    auto contact_rows = [&](int c, CubeRows& RC, PadRows& RP, int& type, real& D, real& kterm) {
+      const int b = LDS_CON + c * CON_STRIDE;
+      type = (c < ncon) ? (int)S.ld(b + 15) : 0;
+      D = (c < ncon) ? S.ld(b + 13) : 0.0; kterm = S.ld(b + 14);
+      rows_cube(c, RC);
+      rows_pad(c, type == PAIR_PADL_CUBE ? 1 : 0, RP);
+      if (type == PAIR_TABLE_CUBE) for (int j = 0; j < 8; j++) { RP.Jn[j] = 0; RP.J1[j] = 0; RP.J2[j] = 0; RP.Jt[j] = 0; }
+    };
+    real ac[6];
+    for (int k = 0; k < 6; k++) ac[k] = a_c[k];
+    bool actl[10];
+    for (int j = 0; j < 10; j++) actl[j] = (sgl[j] != 0) && (sgl[j] * ar[j] - arefl[j] < 0);
+    bool any_lim = false;
+    for (int j = 0; j < 10; j++) any_lim = any_lim || (sgl[j] != 0);
+    // initial contact masks
+    for (int c = 0; __any(c < ncon); c++) {
+      CubeRows RC; PadRows RP; int type; real D, kterm;
+      contact_rows(c, RC, RP, type, D, kterm);
+      const int side = type == PAIR_PADL_CUBE ? 1 : 0;
+      const real* mu = type == PAIR_TABLE_CUBE ? mu_tc : mu_pc; const real Bc = type == PAIR_TABLE_CUBE ? B_tc : B_pc;
+      real a8[8], v8[8]; gather8(ar, side, a8); gather8(qdr, side, v8);
+      int mask = 0;
+      for (int r = 0; r < 6; r++) {
+        real jc[6], jr[8]; pyramid_row(RC, r, mu, jc); pyr8(RP, r, mu, jr);
+        real ja = 0, jv = 0;
+        for (int d = 0; d < 6; d++) { ja += jc[d] * ac[d]; jv += jc[d] * Cb.vel[d]; }
+        for (int d = 0; d < 8; d++) { ja += jr[d] * a8[d]; jv += jr[d] * v8[d]; }
+        mask |= (ja - (-Bc * jv - kterm) < 0) ? (1 << r) : 0;
+      }
+      if (c < ncon) S.st(LDS_ACT + c, (real)mask);
     }
+    bool conv = false;
+    real xr[NB], xc[6];
+    for (int it = 0; it < 50; it++) {
+      real G[NB * (NB + 1) / 2], dinv[NB], gr[NB];
+      {
+        real L[NB * (NB + 1) / 2];
+        build_H(L, actl);
+        static_for<NB>([&](auto I) { constexpr int i = I; static_for<i + 1>([&](auto Jj) { constexpr int j = Jj;
+          if constexpr (PAT_H.nz[i][j]) G[tri(i, j)] = L[tri(i, j)]; else if constexpr (PAT_G.nz[i][j]) G[tri(i, j)] = 0.0; }); });
+      }
+      for (int i = 0; i < NB; i++) gr[i] = g0[i];
+      for (int j = 0; j < 10; j++) gr[j] += actl[j] ? sgl[j] * Dl[j] * arefl[j] : 0.0;
+      real Hc[21], gc[6], Cm[10][6];                 // Cm rows: arm 0..5, gear R, finger R, gear L, finger L
+      for (int k = 0; k < 21; k++) Hc[k] = 0;
+      for (int k = 0; k < 6; k++) { Hc[tri(k, k)] = Md[k]; gc[k] = fs[k]; }
+      for (int i = 0; i < 10; i++) for (int d = 0; d < 6; d++) Cm[i][d] = 0;
+      for (int c = 0; __any(c < ncon); c++) {
+        CubeRows RC; PadRows RP; int type; real D, kterm;
+        contact_rows(c, RC, RP, type, D, kterm);
+        const int side = type == PAIR_PADL_CUBE ? 1 : 0;
+        const real* mu = type == PAIR_TABLE_CUBE ? mu_tc : mu_pc; const real Bc = type == PAIR_TABLE_CUBE ? B_tc : B_pc;
+        const int mask = (c < ncon) ? (int)S.ld(LDS_ACT + c) : 0;
+        real v8[8]; gather8(qdr, side, v8);
+        for (int r = 0; r < 6; r++) {
+          real jc[6], jr[8]; pyramid_row(RC, r, mu, jc); pyr8(RP, r, mu, jr);
+          real jv = 0;
+          for (int d = 0; d < 6; d++) jv += jc[d] * Cb.vel[d];
+          for (int d = 0; d < 8; d++) jv += jr[d] * v8[d];
+          const real aref = -Bc * jv - kterm;
+          const real w = ((mask >> r) & 1) ? D : 0.0;
+          const real wR = side ? 0.0 : w, wL = side ? w : 0.0;
+          for (int d = 0; d < 6; d++) { const real wj = w * jc[d]; gc[d] += wj * aref; for (int e = 0; e <= d; e++) Hc[tri(d, e)] += wj * jc[e]; }
+          // robot-robot block: arm x arm, arm x (gear, finger) of the side, (gear, finger) block; coupling Cm; g_r
+          static_for<6>([&](auto A_) { constexpr int a = A_;
+            const real wj = w * jr[a];
+            gr[a] += wj * aref;
+            static_for<a + 1>([&](auto B_) { constexpr int b = B_; G[tri(a, b)] += wj * jr[b]; });
+            for (int d = 0; d < 6; d++) Cm[a][d] += wj * jc[d]; });
+          {
+            const real gR = wR * jr[6], fR = wR * jr[7], gL = wL * jr[6], fL = wL * jr[7];
+            gr[6] += gR * aref; gr[7] += fR * aref; gr[8] += gL * aref; gr[9] += fL * aref;
+            static_for<6>([&](auto B_) { constexpr int b = B_;
+              G[tri(6, b)] += gR * jr[b]; G[tri(7, b)] += fR * jr[b]; G[tri(8, b)] += gL * jr[b]; G[tri(9, b)] += fL * jr[b]; });
+            G[tri(6, 6)] += gR * jr[6]; G[tri(7, 6)] += fR * jr[6]; G[tri(7, 7)] += fR * jr[7];
+            G[tri(8, 8)] += gL * jr[6]; G[tri(9, 8)] += fL * jr[6]; G[tri(9, 9)] += fL * jr[7];
+            for (int d = 0; d < 6; d++) { Cm[6][d] += gR * jc[d]; Cm[7][d] += fR * jc[d]; Cm[8][d] += gL * jc[d]; Cm[9][d] += fL * jc[d]; }
+          }
+        }
+      }
+      // Schur complement on the cube block: S = G - Cm Hc^-1 Cm^T, rhs = gr - Cm Hc^-1 gc
+      chol_factor<6>(Hc);
+      real T[10][6], ygc[6];
+      for (int d = 0; d < 6; d++) ygc[d] = gc[d];
+      chol_solve<6>(Hc, ygc);
+      static_for<10>([&](auto I) { constexpr int i = I;
+        for (int d = 0; d < 6; d++) T[i][d] = Cm[i][d];
+        chol_solve<6>(Hc, T[i]);
+        real sdot = 0; for (int d = 0; d < 6; d++) sdot += Cm[i][d] * ygc[d];
+        gr[i] -= sdot; });
+      static_for<10>([&](auto I) { constexpr int i = I; static_for<i + 1>([&](auto Jj) { constexpr int j = Jj;
+        real sdot = 0; for (int d = 0; d < 6; d++) sdot += Cm[i][d] * T[j][d];
+        G[tri(i, j)] -= sdot; }); });
+      for (int i = 0; i < NB; i++) xr[i] = gr[i];
+      ldl_factor<PAT_G>(G, dinv);
+      ldl_solve<PAT_G>(G, dinv, xr);
+      for (int d = 0; d < 6; d++) { real sdot = 0; static_for<10>([&](auto I) { constexpr int i = I; sdot += T[i][d] * xr[i]; }); xc[d] = ygc[d] - sdot; }
+      // consistency of the assumed active set at (xr, xc); r0 / dr of every contact row for the line search
+      real pr[NB], pc[6];
+      for (int i = 0; i < NB; i++) pr[i] = xr[i] - ar[i];
+      for (int d = 0; d < 6; d++) pc[d] = xc[d] - ac[d];
+      bool same = true;
+      for (int j = 0; j < 10; j++) { const bool now = (sgl[j] != 0) && (sgl[j] * xr[j] - arefl[j] < 0); same = same && (now == actl[j]); }
+      for (int c = 0; __any(c < ncon); c++) {
+        CubeRows RC; PadRows RP; int type; real D, kterm;
+        contact_rows(c, RC, RP, type, D, kterm);
+        const int side = type == PAIR_PADL_CUBE ? 1 : 0;
+        const real* mu = type == PAIR_TABLE_CUBE ? mu_tc : mu_pc; const real Bc = type == PAIR_TABLE_CUBE ? B_tc : B_pc;
+        const int mask = (int)S.ld(LDS_ACT + c);
+        real a8[8], v8[8], p8[8]; gather8(ar, side, a8); gather8(qdr, side, v8); gather8(pr, side, p8);
+        for (int r = 0; r < 6; r++) {
+          real jc[6], jr[8]; pyramid_row(RC, r, mu, jc); pyr8(RP, r, mu, jr);
+          real ja = 0, jv = 0, jp = 0;
+          for (int d = 0; d < 6; d++) { ja += jc[d] * ac[d]; jv += jc[d] * Cb.vel[d]; jp += jc[d] * pc[d]; }
+          for (int d = 0; d < 8; d++) { ja += jr[d] * a8[d]; jv += jr[d] * v8[d]; jp += jr[d] * p8[d]; }
+          const real r0 = ja - (-Bc * jv - kterm);
+          if (c < ncon) { S.st(LDS_ROW + (c * 6 + r) * 2, r0); S.st(LDS_ROW + (c * 6 + r) * 2 + 1, jp); }
+          same = same && (c >= ncon || ((r0 + jp) < 0) == (((mask >> r) & 1) != 0));
+        }
+      }
+      const bool finish = !conv && same;
+      for (int i = 0; i < NB; i++) ar[i] = finish ? xr[i] : ar[i];
+      for (int d = 0; d < 6; d++) ac[d] = finish ? xc[d] : ac[d];
+      conv = conv || finish;
+      if (!__any(!conv)) break;
+      // line search (bisection): smooth part = robot quadratic with H0 = M + equality rows (no limits), cube diag M
+      real lin0 = 0, quad = 0;
+      {
+        real L[NB * (NB + 1) / 2];
+        bool none[10]; for (int j = 0; j < 10; j++) none[j] = false;
+        build_H(L, none);
+        static_for<NB>([&](auto I) { constexpr int i = I; real ha = 0, hp = 0;
+          static_for<NB>([&](auto Jj) { constexpr int j = Jj;
+            if constexpr (PAT_H.nz[i > j ? i : j][i > j ? j : i]) { ha = fma(L[tri(i, j)], ar[j], ha); hp = fma(L[tri(i, j)], pr[j], hp); } });
+          lin0 += (ha - g0[i]) * pr[i]; quad += hp * pr[i]; });
+      }
+      for (int k = 0; k < 6; k++) { lin0 += (Md[k] * ac[k] - fs[k]) * pc[k]; quad += Md[k] * pc[k] * pc[k]; }
+      // limit rows join the piecewise part
+      real l_r0[10], l_dr[10];
+      for (int j = 0; j < 10; j++) { l_r0[j] = sgl[j] * ar[j] - arefl[j]; l_dr[j] = sgl[j] * pr[j]; }
+      auto dphi = [&](real al) {
+        real sacc = lin0 + al * quad + dphi_rows(al);
+        for (int j = 0; j < 10; j++) { const real rr = l_r0[j] + al * l_dr[j]; sacc += (sgl[j] != 0 && rr < 0) ? Dl[j] * rr * l_dr[j] : 0.0; }
+        return sacc;
+      };
+      real lo = 0, hi = 2;
+      const bool beyond = dphi(hi) < 0;
+      for (int b = 0; b < 24; b++) { const real mid = 0.5 * (lo + hi); const bool neg = dphi(mid) < 0; lo = neg ? mid : lo; hi = neg ? hi : mid; }
+      const real alpha = beyond ? 2.0 : 0.5 * (lo + hi);
+      for (int i = 0; i < NB; i++) ar[i] = conv ? ar[i] : ar[i] + alpha * pr[i];
+      for (int d = 0; d < 6; d++) ac[d] = conv ? ac[d] : ac[d] + alpha * pc[d];
+      for (int j = 0; j < 10; j++) { const bool now = (sgl[j] != 0) && (sgl[j] * ar[j] - arefl[j] < 0); actl[j] = conv ? actl[j] : now; }
+      remask(alpha, conv);
+    }
+    (void)any_lim;
+    // contact forces on both sides
+    for (int k = 0; k < 6; k++) { a_c[k] = ac[k]; fc[k] = 0; }
+    for (int c = 0; __any(c < ncon); c++) {
+      CubeRows RC; PadRows RP; int type; real D, kterm;
+      contact_rows(c, RC, RP, type, D, kterm);
+      const int side = type == PAIR_PADL_CUBE ? 1 : 0;
+      const real* mu = type == PAIR_TABLE_CUBE ? mu_tc : mu_pc; const real Bc = type == PAIR_TABLE_CUBE ? B_tc : B_pc;
+      real a8[8], v8[8]; gather8(ar, side, a8); gather8(qdr, side, v8);
+      for (int r = 0; r < 6; r++) {
+        real jc[6], jr[8]; pyramid_row(RC, r, mu, jc); pyr8(RP, r, mu, jr);
+        real ja = 0, jv = 0;
+        for (int d = 0; d < 6; d++) { ja += jc[d] * ac[d]; jv += jc[d] * Cb.vel[d]; }
+        for (int d = 0; d < 8; d++) { ja += jr[d] * a8[d]; jv += jr[d] * v8[d]; }
+        const real jar = ja - (-Bc * jv - kterm);
+        const real f = (jar < 0) ? -D * jar : 0.0;
+        for (int d = 0; d < 6; d++) fc[d] += jc[d] * f;
+        for (int d = 0; d < 6; d++) extra[d] += jr[d] * f;
+        extra[6] += side ? 0.0 : jr[6] * f; extra[7] += side ? 0.0 : jr[7] * f;
+        extra[8] += side ? jr[6] * f : 0.0; extra[9] += side ? jr[7] * f : 0.0;
+      }
+    }
+    solved = true;
   }
-  for (int k = 0; k < 6; k++) {
-    const real acc = (fs[k] + fc[k]) / (Md[k] + h * damp[k]);
-    Cb.vel[k] += h * acc;
-    Cb.warm[k] = a[k];
-  }
-  for (int k = 0; k < 3; k++) Cb.pos[k] += h * Cb.vel[k];
-  {   // mju_quatIntegrate with the body-frame angular velocity
+
+  // ------------------------------------------------------------------------------------------------- finish
+  // implicit-damping Euler on the diagonal cube inertia, free-joint integration (mj_Euler / mj_advance)
+  MCG_DEV void finish(real* qlag7) {
+    if (__any(!solved)) {
+      // lanes of a wave are either all coupled or all alone (the branch in robot_substep is wave-uniform)
+      solve_alone();
+    }
+    for (int k = 0; k < 3; k++) qlag7[k] = Cb.pos[k];
+    for (int k = 0; k < 4; k++) qlag7[3 + k] = Cb.quat[k];
+    for (int k = 0; k < 6; k++) {
+      const real acc = (fs[k] + fc[k]) / (Md[k] + h * damp[k]);
+      Cb.vel[k] += h * acc;
+      Cb.warm[k] = a_c[k];
+    }
+    for (int k = 0; k < 3; k++) Cb.pos[k] += h * Cb.vel[k];
     real ax[3] = {Cb.vel[3], Cb.vel[4], Cb.vel[5]};
     const real nw = sqrt(dot3(ax, ax));
     const bool tiny = nw < MINVAL;
@@ -422,7 +702,7 @@ MCG_DEV void cube_substep(ModelPtr Pm, Cube& Cb, real* qlag7, const real* dr, co
     real qn[4]; mulquat(Cb.quat, qr, qn);
     for (int k = 0; k < 4; k++) Cb.quat[k] = qn[k];
   }
-}
+};
 
 // rotations.mat2euler (gymnasium_robotics) as called at mycobot.py:355-357 [RECALL]
 MCG_DEV void mat2euler(const real* m, real* e) {

@@ -197,8 +197,18 @@ constexpr Pattern symbolic(bool with_constraints) {
       for (int j = 0; j <= i; j++) if (P.nz[k][j]) P.nz[i][j] = true;
   return P;
 }
+constexpr Pattern symbolic_grasp() {          // H plus the cross terms a cube pinched by both pads induces (Schur complement)
+  Pattern P = symbolic(true);
+  constexpr int gr[4] = {6, 7, 8, 9};
+  for (int a = 0; a < 4; a++) for (int b = 0; b < 4; b++) if (gr[a] >= gr[b]) P.nz[gr[a]][gr[b]] = true;
+  for (int k = NB - 1; k >= 0; k--)
+    for (int i = 0; i < k; i++) if (P.nz[k][i])
+      for (int j = 0; j <= i; j++) if (P.nz[k][j]) P.nz[i][j] = true;
+  return P;
+}
 constexpr Pattern PAT_M = symbolic(false);
 constexpr Pattern PAT_H = symbolic(true);
+constexpr Pattern PAT_G = symbolic_grasp();
 
 // in place on the packed lower triangle: A = L^T D L, L unit lower (stored below the diagonal), dinv = 1 / D
 template <const Pattern& PT>
@@ -280,8 +290,12 @@ struct LaneScratchT {
 typedef LaneScratchT<64> LaneScratch;
 
 // One physics sub-step (mj_step) of the 12-dof robot.  `qlag` receives the positions the forward pass used.
-template <class LS>
-MCG_DEV void robot_substep(ModelPtr Pm, Robot& S, real* qlag6, const LS MS) {
+// Coupling hook: PickAndPlace passes an object that, when a finger pad touches the cube, solves the robot and cube
+// accelerations together and returns the contact forces on the robot dofs.  Reach passes NoCoupling (compiled out).
+struct NoCoupling { static constexpr bool enabled = false; };
+
+template <class LS, class CPL = NoCoupling>
+MCG_DEV void robot_substep(ModelPtr Pm, Robot& S, real* qlag6, const LS MS, CPL* CP = nullptr) {
   const real h = launder(Pm)->timestep;
   real cs[NB], sn[NB];
   {
@@ -560,7 +574,15 @@ MCG_DEV void robot_substep(ModelPtr Pm, Robot& S, real* qlag6, const LS MS) {
   bool act[10];
   static_for<10>([&](auto I) { constexpr int j = I; act[j] = (sgl[j] != 0) && (sgl[j] * a[j] - arefl[j] < 0); });
   bool conv = false;
-  for (int it = 0; it < 50; it++) {
+  real extra[NB];                 // contact forces on the robot dofs (coupled PickAndPlace solve), else 0
+  static_for<NB>([&](auto I) { constexpr int i = I; extra[i] = 0; });
+  if constexpr (CPL::enabled) {
+    if (__any(CP->any_pad)) {     // wave-uniform: every lane of the wave takes the coupled path (same minimiser)
+      CP->solve_coupled(build_H, g0, Dl, arefl, sgl, S.qd, a, extra);
+      conv = true;
+    }
+  }
+  for (int it = 0; it < 50 && __any(!conv); it++) {
     real L[NB * (NB + 1) / 2], dinv[NB], x[NB];
     build_H(L, act);
     static_for<NB>([&](auto I) { constexpr int i = I; x[i] = g0[i]; });
@@ -632,6 +654,7 @@ MCG_DEV void robot_substep(ModelPtr Pm, Robot& S, real* qlag6, const LS MS) {
     });
   });
   { const real force = -Dj * (a[6] - a[8] - arefj); rhs[6] += force; rhs[8] -= force; }
+  static_for<NB>([&](auto I) { constexpr int i = I; rhs[i] += extra[i]; });
   static_for<10>([&](auto I) { constexpr int j = I;
     const real jar = sgl[j] * a[j] - arefl[j];
     rhs[j] += (sgl[j] != 0 && jar < 0) ? sgl[j] * (-Dl[j] * jar) : 0.0; });

@@ -325,6 +325,14 @@ __device__ void observe_pnp(const Cfg& C, ModelPtr P, const EnvP& E, real* obs, 
   obs[23] = E.R.qd[6] * C.dt; obs[24] = E.R.qd[8] * C.dt;
 }
 
+// one mj_step of robot + cube: collision first (needs both), then the robot's pipeline with the coupling hook, then the cube
+MCG_DEV void pnp_substep(ModelPtr P, EnvP& E, const PnpScratch MS) {
+  CubeSys<PnpScratch> CS{MS, E.Cb, E.dr};
+  CS.prepare(P, E.R.q);
+  robot_substep(P, E.R, E.qlag6, MS, &CS);
+  CS.finish(E.qlag7);
+}
+
 template <int CONTROLLER>
 __global__ __launch_bounds__(PNP_LANES) void step_pnp_kernel(Cfg C, View V, const mcg_model* __restrict__ Pg,
                                                              const float* __restrict__ actions, mcg_step_out O) {
@@ -355,11 +363,11 @@ __global__ __launch_bounds__(PNP_LANES) void step_pnp_kernel(Cfg C, View V, cons
       ik_delta(X, tpos, tquat, dq);
       for (int k = 0; k < 6; k++) E.R.ctrl[k] += dq[k];
       E.R.ctrl[6] = grip;
-      for (int s = 0; s < C.frame_skip; s++) { robot_substep(P, E.R, E.qlag6, MS); cube_substep(P, E.Cb, E.qlag7, E.dr, MS); }
+      for (int s = 0; s < C.frame_skip; s++) pnp_substep(P, E, MS);
     }
   } else {
     for (int k = 0; k < 7; k++) E.R.ctrl[k] = (real)act[k];
-    for (int s = 0; s < C.frame_skip; s++) { robot_substep(P, E.R, E.qlag6, MS); cube_substep(P, E.Cb, E.qlag7, E.dr, MS); }
+    for (int s = 0; s < C.frame_skip; s++) pnp_substep(P, E, MS);
   }
   real obs[25], ag[3];
   observe_pnp(C, P, E, obs, ag);

@@ -4,7 +4,9 @@
  * P4 `mj_collision` restated for the primitive geoms of the PickAndPlace scene: the cube, the table box, the two
  * finger-pad boxes and the ground plane (/root/reference/mycobotgym/envs/assets/mycobot280_main.xml:81,87,195-199,
  * 222-225,262).  The 28 mesh geoms (convex hulls in MuJoCo) are outside this build's scope and never
- * produce contacts here.
+ * produce contacts here.  With `collide_scope_geom` set (the build's configuration) only pairs involving the cube are
+ * tested: pads touching the table or each other would, in MuJoCo, be preceded by finger-mesh contacts that are out
+ * of scope anyway, so modelling them without the meshes is not closer to the reference than leaving them out.
  *
  * Pair filter [RECALL mj_collision]: both geoms' bodies welded to the world -> skip; same weld body -> skip;
  * parent-child weld bodies -> skip unless the parent is the world; `<exclude>` pairs -> skip;
@@ -217,6 +219,7 @@ void mco_collision(const mco_model* m, mco_data* d) {
   for (int g1 = 0; g1 < m->ngeom; g1++) for (int g2 = g1 + 1; g2 < m->ngeom; g2++) {
     int t1 = m->geom_type[g1], t2 = m->geom_type[g2];
     if (t1 == MCO_GEOM_MESH || t2 == MCO_GEOM_MESH) continue;           /* convex-mesh collision: out of scope */
+    if (m->collide_scope_geom >= 0 && g1 != m->collide_scope_geom && g2 != m->collide_scope_geom) continue;
     if (filtered(m, g1, g2)) continue;
     if (t1 == MCO_GEOM_PLANE && t2 == MCO_GEOM_BOX) plane_box(m, d, g1, g2);
     else if (t1 == MCO_GEOM_BOX && t2 == MCO_GEOM_BOX) {

@@ -46,6 +46,7 @@ typedef struct mco_model {
   int nbody, njnt, nq, nv, ngeom, nsite, nu, neq, ntendon, nexclude;
   double timestep, gravity[3], meaninertia;
   int enable_contact;            /* 0: collision stage skipped (Reach / free-space configs) */
+  int collide_scope_geom;        /* >= 0: only pairs that involve this geom collide (the build's scoped set: the cube) */
   /* bodies */
   int body_parent[MCO_MAXBODY], body_rootid[MCO_MAXBODY], body_weldid[MCO_MAXBODY];
   int body_dofadr[MCO_MAXBODY], body_dofnum[MCO_MAXBODY];

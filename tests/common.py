@@ -35,7 +35,8 @@ def make_oracle(n, has_object=False, controller_type="joint", fetch_env=False, r
     from oracle import pyoracle as po
     from mycobotgym_amd.vec_env import initial_state
     tab = table if table is not None else load_json(table_name(has_object, mesh_inertia))
-    model = po.OracleModel(tab, enable_contact=has_object)
+    # the build's scoped collision set: pairs involving the cube
+    model = po.OracleModel(tab, enable_contact=has_object, scope_geom=tab["geom_name"].index("object0") if has_object else -1)
     qpos, qvel, ctrl, igx, height = initial_state(has_object, fetch_env, mesh_inertia)
     cfg = po.EnvConfig()
     cfg.n_envs = n; cfg.has_object = int(has_object)

@@ -96,3 +96,50 @@ def test_env_steps_with_object(torch_cuda):
         print(f"\n[{controller}] PickAndPlace env-steps from identical state: median {np.median(errs):.2e} p99 {np.quantile(errs, 0.99):.2e}")
         assert np.median(errs) < 1e-9
         envs.close()
+
+
+def _grasp_state(ora, n):
+    """Oracle state with the cube between the open finger pads at the fetch keyframe and the gripper commanded shut."""
+    from tests.common import load_json
+    tab = load_json("mycobot280")
+    key = tab["keys"][0]
+    s = ora.get_state()
+    d0 = ora.data(0)
+    d0.set_state(qpos=key["qpos"]); d0.forward()
+    gn = tab["geom_name"]; gx = d0.get("geom_xpos", (48, 3))
+    mid = 0.5 * (gx[gn.index("right_finger_layer")] + gx[gn.index("left_finger_layer")])
+    rng = np.random.default_rng(7)
+    q = np.tile(np.asarray(key["qpos"], dtype=float), (n, 1))
+    q[:, 12:15] = mid + rng.normal(size=(n, 3)) * 0.002
+    quat = np.tile([1.0, 0, 0, 0], (n, 1)) + rng.normal(size=(n, 4)) * 0.05
+    q[:, 15:19] = quat / np.linalg.norm(quat, axis=1, keepdims=True)
+    s["qpos"] = q; s["qpos_lag"] = q.copy(); s["qvel"][:] = 0
+    s["ctrl"] = np.tile(np.asarray(key["ctrl"], dtype=float), (n, 1)); s["ctrl"][:, 6] = 1.0
+    ora.set_state(**s)
+
+
+def test_substeps_through_a_grasp(torch_cuda):
+    """Pads close on the cube: pad-cube contacts couple robot and cube (coupled Newton, Schur complement)."""
+    from tests.common import make_pair, sync_oracle_to, step_errors
+    n = 64
+    kw = dict(has_object=True, controller_type="joint", reward_type="dense", seed=5, frame_skip=1, max_episode_steps=10 ** 9)
+    envs, ora = make_pair(n, **kw)
+    envs.reset(seed=5); ora.reset(seed=5)
+    _grasp_state(ora, n)
+    a = np.tile(np.concatenate([ora.get_state()["ctrl"][0, :6], [1.0]]).astype(np.float32), (n, 1))
+    a = np.clip(a, -1, 1)
+    worst = dict(obs=0.0, qpos=0.0, qvel=0.0); ncon_seen = set(); iters = set()
+    for t in range(300):
+        sync_oracle_to(envs, ora)
+        e, flags_equal, o = step_errors(envs, ora, a)
+        assert flags_equal
+        st, so = envs.get_state(), ora.get_state()
+        worst["obs"] = max(worst["obs"], e.max())
+        worst["qpos"] = max(worst["qpos"], np.abs(st["qpos"].cpu().numpy().T - so["qpos"]).max())
+        worst["qvel"] = max(worst["qvel"], np.abs(st["qvel"].cpu().numpy().T - so["qvel"]).max())
+        for i in range(0, n, 4):
+            ncon_seen.add(int(ora.data(i).get("ncon", (1,), np.int32)[0])); iters.add(int(ora.data(i).get("solver_iter", (1,), np.int32)[0]))
+    print(f"\ngrasp, 300 sub-steps x {n} envs: {worst}; contact counts {sorted(ncon_seen)}; oracle Newton iterations {sorted(iters)}")
+    assert max(ncon_seen) >= 4 and max(iters) >= 2
+    assert worst["obs"] < 1e-7 and worst["qpos"] < 1e-7 and worst["qvel"] < 1e-4
+    envs.close()
