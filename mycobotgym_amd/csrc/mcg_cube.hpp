@@ -247,7 +247,7 @@ struct CubeSys {
   const LS S; Cube& Cb; const real* dr;        // (the model pointer is passed in: it must stay a scalar register)
   real h, Rc[9], Md[6], damp[6], fs[6];
   real B_tc, B_pc, mu_tc[3], mu_pc[3];
-  int ncon; bool any_pad, solved;
+  int ncon; bool any_pad, solved, touch[2];    // touch: this forward pass has a right / left pad-cube contact
   real a_c[6], fc[6];
 
   // ------------------------------------------------------------------------------------------------- prepare
@@ -314,7 +314,7 @@ struct CubeSys {
       static_for<6>([&](auto I) { constexpr int i = I; real r[3]; ldc<3>(Q->body[i].r, r); joint(i, AXK[i], AXS[i], r, qr[i], R, p); });
       const real dxe = p[0] - Cb.pos[0], dye = p[1] - Cb.pos[1], dze = p[2] - Cb.pos[2];
       const bool reach = dxe*dxe + dye*dye + dze*dze < 0.2 * 0.2;      // link6 origin within 20 cm of the cube
-      any_pad = false;
+      any_pad = false; touch[0] = touch[1] = false;
       if (__any(reach)) {
         static_for<2>([&](auto Sd) {
           constexpr int sd = Sd; constexpr int g = 6 + 2 * sd, f = 7 + 2 * sd;
@@ -331,7 +331,8 @@ struct CubeSys {
           const bool near = reach && (dx*dx + dy*dy + dz*dz <= rs*rs);
           const int before = CL.n;
           if (__any(near)) box_box(CL, near, pc, Rs, pb + 3, Cb.pos, Rc, hc, PAIR_PADR_CUBE + sd);
-          any_pad = any_pad || (CL.n > before);
+          touch[sd] = CL.n > before;
+          any_pad = any_pad || touch[sd];
         });
       }
     }

@@ -234,6 +234,7 @@ struct EnvP {
   Robot R; Cube Cb;
   real qlag6[6], qlag7[7], goal[3], epret, dr[2];
   int32_t elapsed, episode, eplen;
+  bool touch;       // both finger pads touched the cube in the last forward pass (stage_rewards' grasp test)
 };
 
 __device__ void load_envp(const View& V, int i, EnvP& E) {
@@ -329,6 +330,7 @@ __device__ void observe_pnp(const Cfg& C, ModelPtr P, const EnvP& E, real* obs, 
 MCG_DEV void pnp_substep(ModelPtr P, EnvP& E, const PnpScratch MS) {
   CubeSys<PnpScratch> CS{MS, E.Cb, E.dr};
   CS.prepare(P, E.R.q);
+  E.touch = CS.touch[0] && CS.touch[1];        // contacts of this forward pass: what check_contact sees after the step
   robot_substep(P, E.R, E.qlag6, MS, &CS);
   CS.finish(E.qlag7);
 }
@@ -343,6 +345,7 @@ __global__ __launch_bounds__(PNP_LANES) void step_pnp_kernel(Cfg C, View V, cons
   if (i >= C.n) return;
   EnvP E;
   load_envp(V, i, E);
+  E.touch = false;
   float act[7];
   for (int k = 0; k < C.act_dim; k++) { float x = actions[(size_t)i * C.act_dim + k]; act[k] = fminf(fmaxf(x, -1.f), 1.f); }
   if constexpr (CONTROLLER == MCG_CTRL_IK) {
@@ -374,7 +377,17 @@ __global__ __launch_bounds__(PNP_LANES) void step_pnp_kernel(Cfg C, View V, cons
   real dx = ag[0] - E.goal[0], dy = ag[1] - E.goal[1], dz = ag[2] - E.goal[2];
   const real dist = sqrt(dx * dx + dy * dy + dz * dz);
   const bool succ = dist < C.distance_threshold;
-  const real rew = C.reward_type == MCG_REWARD_SPARSE ? -(real)(float)(dist > C.distance_threshold) : -dist;
+  real rew = C.reward_type == MCG_REWARD_SPARSE ? -(real)(float)(dist > C.distance_threshold) : -dist;
+  if (C.reward_type == MCG_REWARD_SHAPING) {
+    // stage_rewards (mycobot.py:402-448): reach 0.2 (1 - tanh d), grasp 0.5 iff both pads touch the cube, lift
+    // 0.5 + 0.4 (1 - tanh d_obj,target); the target0 site stays at its MJCF position unless rendering (Appendix D-8)
+    const real gx = obs[0] - obs[3], gy = obs[1] - obs[4], gz = obs[2] - obs[5];
+    const real r_reach = (1 - tanh(sqrt(gx * gx + gy * gy + gz * gz))) * 0.2;
+    const real r_grasp = E.touch ? 0.5 : 0.0;
+    const real tx = obs[3] - -0.15, ty = obs[4] - 0.0, tz = obs[5] - 0.21;
+    const real r_lift = E.touch ? 0.5 + (1 - tanh(sqrt(tx * tx + ty * ty + tz * tz))) * (0.9 - 0.5) : 0.0;
+    rew = fmax(fmax(r_reach, r_grasp), r_lift) * 100;
+  }
   E.elapsed++; E.eplen++; E.epret += rew;
   const bool term = succ, trunc = succ || (E.elapsed >= C.max_episode_steps);
   if (O.reward) O.reward[i] = rew;
@@ -465,8 +478,8 @@ int mcg_create(const mcg_config* c, const mcg_model* model, int device, mcg_env*
   if (c->n_envs <= 0) return fail(MCG_ERR_ARG, "mcg_create: n_envs must be positive%s");
   if (c->controller != MCG_CTRL_JOINT && c->controller != MCG_CTRL_IK) return fail(MCG_ERR_ARG, "mcg_create: controller must be joint or IK%s");
   if (c->controller == MCG_CTRL_JOINT && c->fetch_env) return fail(MCG_ERR_ARG, "Joint controller not supported for Fetch env%s");  // mycobot.py:96
-  if (c->reward_type == MCG_REWARD_SHAPING) return fail(MCG_ERR_UNSUPPORTED, "mcg_create: reward_shaping needs the contact stage (not built yet)%s");
-  if (c->reward_type != MCG_REWARD_SPARSE && c->reward_type != MCG_REWARD_DENSE) return fail(MCG_ERR_ARG, "mcg_create: bad reward_type%s");
+  if (c->reward_type == MCG_REWARD_SHAPING && !c->has_object) return fail(MCG_ERR_UNSUPPORTED, "mcg_create: reward_shaping reads the cube, which the Reach engine drops (SURVEY D-7)%s");
+  if (c->reward_type < MCG_REWARD_SPARSE || c->reward_type > MCG_REWARD_SHAPING) return fail(MCG_ERR_ARG, "mcg_create: bad reward_type%s");
   {
     const mcg_model* mm = model ? model : &kDefaultModels[0];
     bool ok = true;

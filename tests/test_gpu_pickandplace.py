@@ -143,3 +143,43 @@ def test_substeps_through_a_grasp(torch_cuda):
     assert max(ncon_seen) >= 4 and max(iters) >= 2
     assert worst["obs"] < 1e-7 and worst["qpos"] < 1e-7 and worst["qvel"] < 1e-4
     envs.close()
+
+
+def test_reward_shaping_through_a_grasp(torch_cuda):
+    """stage_rewards: reach / grasp / lift stages against the oracle while the pads close on the cube."""
+    from tests.common import make_pair, sync_oracle_to, step_errors
+    n = 64
+    kw = dict(has_object=True, controller_type="joint", reward_type="reward_shaping", seed=5, frame_skip=4, max_episode_steps=10 ** 9)
+    envs, ora = make_pair(n, **kw)
+    envs.reset(seed=5); ora.reset(seed=5)
+    _grasp_state(ora, n)
+    a = np.clip(np.tile(np.concatenate([ora.get_state()["ctrl"][0, :6], [1.0]]).astype(np.float32), (n, 1)), -1, 1)
+    rewards = []
+    for t in range(60):
+        sync_oracle_to(envs, ora)
+        e, flags_equal, o = step_errors(envs, ora, a)
+        assert flags_equal and e.max() < 1e-7
+        rewards.append(o["reward"].copy())
+    rewards = np.concatenate(rewards)
+    print(f"\nshaped rewards seen: min {rewards.min():.2f} max {rewards.max():.2f}; grasp/lift stage fraction {(rewards >= 50).mean():.2f}")
+    assert rewards.max() >= 50 and rewards.min() < 50            # both the reach stage and the grasp / lift stages occurred
+    envs.close()
+
+
+def test_domain_randomisation_matches_oracle(torch_cuda):
+    """Per-reset cube mass / friction scales (build-defined R3): same Philox draws, same physics as the oracle."""
+    from tests.common import make_pair, sync_oracle_to, step_errors
+    n = 128
+    dr = {"mass": (0.5, 2.0), "friction": (0.5, 1.5)}
+    envs, ora = make_pair(n, has_object=True, controller_type="joint", reward_type="dense", seed=9, domain_randomization=dr)
+    envs.reset(seed=9); ora.reset(seed=9)
+    s = envs.get_state()["dr_scale"].cpu().numpy()
+    assert s[0].min() >= 0.5 and s[0].max() <= 2.0 and s[1].min() >= 0.5 and s[1].max() <= 1.5 and s[0].std() > 0.1
+    rng = np.random.default_rng(1)
+    for t in range(55):                                  # crosses the TimeLimit reset: new scales are drawn on both sides
+        sync_oracle_to(envs, ora)
+        e, flags_equal, o = step_errors(envs, ora, rng.uniform(-1, 1, (n, 7)).astype(np.float32))
+        assert flags_equal and np.median(e) < 1e-9
+    s2 = envs.get_state()["dr_scale"].cpu().numpy()
+    assert not np.array_equal(s, s2)
+    envs.close()
