@@ -60,6 +60,11 @@ def main():
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--controller", default="joint", choices=["joint", "IK"])
+    ap.add_argument("--task", default="reach", choices=["reach", "pnp"],
+                    help="reach = BASELINE configs[1] (the headline metric); pnp = configs[2], PickAndPlace with contacts")
+    ap.add_argument("--dr", action="store_true", help="PickAndPlace with per-reset domain randomisation (configs[4])")
+    ap.add_argument("--scripted-grasp", action="store_true",
+                    help="PickAndPlace from the 'gripper closing over the cube' state (pad contacts in the timed window)")
     ap.add_argument("--envs-per-gpu", type=int, default=N_ENVS_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
@@ -84,11 +89,20 @@ def main():
     K, W = args.steps, args.warmup
 
     def run(controller, steps, warmup):
-        envs = MyCobotVecEnv(n, has_object=False, controller_type=controller, reward_type="dense", device=dev,
-                             seed=0, env_id_offset=rank * n)
+        pnp = args.task == "pnp"
+        envs = MyCobotVecEnv(n, has_object=pnp, controller_type=controller, reward_type="dense", device=dev,
+                             seed=0, env_id_offset=rank * n,
+                             domain_randomization={"mass": (0.5, 2.0), "friction": (0.5, 1.5)} if (pnp and args.dr) else None,
+                             max_episode_steps=10 ** 9 if args.scripted_grasp else 50)
         envs.reset(seed=0)
         g = torch.Generator(device=dev); g.manual_seed(1234 + rank)
         pool = torch.rand(16, n, envs.action_dim, device=dev, generator=g) * 2 - 1     # resident action batches
+        if pnp and args.scripted_grasp and controller == "joint":
+            from mycobotgym_amd.scenarios import grasp_state
+            st = grasp_state(n, seed=rank)
+            act = torch.as_tensor(st.pop("action"), device=dev)
+            envs.set_state(**st)
+            pool = act.unsqueeze(0).repeat(16, 1, 1).contiguous()
         for t in range(warmup):
             envs.step_async(pool[t % 16])
         torch.cuda.synchronize(dev)
@@ -125,11 +139,15 @@ def main():
     value = total_envs * K / dt
     substeps = 20 if args.controller == "joint" else 100
     out = {
-        "metric": "env-steps/sec (whole node), MyCobot Reach, N_envs=8192/GPU",
+        "metric": "env-steps/sec (whole node), MyCobot Reach, N_envs=8192/GPU" if args.task == "reach" else
+                  "env-steps/sec (whole node), MyCobot PickAndPlace, N_envs=8192/GPU",
         "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
         "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"MyCobot Reach, {n} envs/GPU, no contacts (free-space dynamics), controller={args.controller}, "
+        "config": {"workload": (f"MyCobot Reach, {n} envs/GPU, no contacts (free-space dynamics), controller={args.controller}, "
+                                if args.task == "reach" else
+                                f"MyCobot PickAndPlace, {n} envs/GPU, contacts on (cube-table/ground/pads, pyramidal condim 4), "
+                                f"{'domain randomisation, ' if args.dr else ''}{'scripted grasp, ' if args.scripted_grasp else ''}controller={args.controller}, ") +
                                f"{substeps} physics sub-steps per env-step, dense reward, auto-reset, TimeLimit 50",
                    "envs_per_gpu": n, "total_envs": total_envs, "controller": args.controller,
                    "parallelism": f"env-sharded x{world}, no step-path collective"},
@@ -150,12 +168,17 @@ def main():
                            "kernel": "step_reach_kernel", "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": algo_bytes,
                            "note": "nominal roofline only: with all sub-steps fused the path moves ~1 KB per env-step and is "
                                    "bound by dependent FP64 VALU issue, not by HBM (SURVEY 8(d)); see DESIGN.md"}
-        if not args.no_secondary and world == 1:
+        if args.task == "pnp":
+            out["roofline"]["kernel"] = "step_pnp_kernel"
+            out["roofline"]["algorithmic_bytes_per_launch"] = 1363 * n       # PickAndPlace B = 1363 B per env-step
+            out["roofline"]["achieved"] = 1363 * n / (kernel_ms * 1e-3) / 1e9
+            out["roofline"]["frac"] = out["roofline"]["achieved"] / HBM_PEAK_GBPS
+        if not args.no_secondary and world == 1 and args.task == "reach":
             other = "IK" if args.controller == "joint" else "joint"
             dt2, k2, _ = run(other, max(K // 5, 20), max(W // 5, 5))
             out["secondary"] = {"controller": other, "env_steps_per_sec": n * max(K // 5, 20) / dt2, "kernel_ms": k2,
                                 "physics_substeps_per_sec": n * max(K // 5, 20) / dt2 * (100 if other == "IK" else 20)}
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and args.task == "reach":
             out["cpu_baseline"] = cpu_baseline(args.controller, 8192, 40)
         out["episode_stats"] = {"sum_return": stats[0], "sum_length": stats[1], "sum_success": stats[2]}
         print(json.dumps(out), flush=True)
