@@ -79,7 +79,7 @@ typedef struct mcg_config {
   int32_t target_in_the_air;   /*                                                  (mycobot.py:38) */
   int32_t auto_reset;          /* reset finished envs inside mcg_step */
   int32_t dr_enable;           /* per-reset domain randomisation (build-defined) */
-  int32_t reserved0;
+  int32_t block_gripper;       /* zero the two finger joints after every step      (mycobot.py:34,300-306) */
   double distance_threshold;   /* 0.01                                             (mycobot.py:39) */
   double height_offset;        /* z of site object0 at the initial state           (mycobot.py:470-472) */
   double initial_gripper_xpos[3];   /* EEF site at the initial state               (mycobot.py:464-466) */

@@ -65,7 +65,7 @@ class McgConfig(C.Structure):
         ("n_envs", C.c_int32), ("has_object", C.c_int32), ("controller", C.c_int32), ("fetch_env", C.c_int32),
         ("reward_type", C.c_int32), ("frame_skip", C.c_int32), ("control_steps", C.c_int32),
         ("max_episode_steps", C.c_int32), ("target_in_the_air", C.c_int32), ("auto_reset", C.c_int32),
-        ("dr_enable", C.c_int32), ("reserved0", C.c_int32),
+        ("dr_enable", C.c_int32), ("block_gripper", C.c_int32),
         ("distance_threshold", d), ("height_offset", d), ("initial_gripper_xpos", d * 3),
         ("init_qpos", d * 19), ("init_qvel", d * 18), ("init_ctrl", d * 7),
         ("dr_mass_range", d * 2), ("dr_friction_range", d * 2),

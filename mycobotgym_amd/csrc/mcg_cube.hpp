@@ -337,6 +337,15 @@ struct CubeSys {
       }
     }
     ncon = CL.n;
+    // Lanes with fewer contacts than their wave-mates still walk the longer list with zero weights: give them clean
+    // zeros to multiply (uninitialised LDS may hold NaN / inf, and 0 * NaN would poison the sums).
+    for (int c = 0; __any(c < ncon); c++) {
+      if (c >= ncon) {
+        for (int k = 0; k < CON_STRIDE; k++) S.st(LDS_CON + c * CON_STRIDE + k, 0.0);
+        for (int k = 0; k < 12; k++) S.st(LDS_ROW + c * 12 + k, 0.0);
+        S.st(LDS_ACT + c, 0.0);
+      }
+    }
     // ---- P5 per-contact solver numbers (the 6 pyramid rows of a contact share D and the position term)
     real par_t[15], par_p[15];
     ldc<15>(Q->contact_par[PAIR_TABLE_CUBE], par_t); ldc<15>(Q->contact_par[PAIR_PADR_CUBE], par_p);

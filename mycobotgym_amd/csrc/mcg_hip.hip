@@ -28,7 +28,7 @@ int fail(int code, const char* fmt, const char* a = "") { snprintf(g_err, sizeof
 // ------------------------------------------------------------------------------------------- device-side views
 struct Cfg {
   int n, has_object, controller, fetch, reward_type, frame_skip, control_steps, max_episode_steps;
-  int target_in_the_air, auto_reset, nq, nv, obs_dim, act_dim, dr_enable;
+  int target_in_the_air, auto_reset, nq, nv, obs_dim, act_dim, dr_enable, block_gripper;
   double dr_mass[2], dr_fric[2];
   double distance_threshold, height_offset, igx[3], dt, grip_center, grip_range;
   double init_qpos[19], init_qvel[18], init_ctrl[7];
@@ -180,6 +180,10 @@ __global__ __launch_bounds__(64) void step_reach_kernel(Cfg C, View V, const mcg
     for (int s = 0; s < C.frame_skip; s++) robot_substep(P, E.R, E.qlag6, MS);
   }
 
+  if (C.block_gripper) {       // _step_callback (mycobot.py:300-306): finger joints := 0, then mj_forward removes the lag
+    E.R.q[7] = 0; E.R.q[9] = 0;
+    for (int k = 0; k < 6; k++) E.qlag6[k] = E.R.q[k];
+  }
   real obs[10], ag[3];
   observe_reach(C, P, E, obs, ag);
   real dx = ag[0] - E.goal[0], dy = ag[1] - E.goal[1], dz = ag[2] - E.goal[2];
@@ -372,6 +376,15 @@ __global__ __launch_bounds__(PNP_LANES) void step_pnp_kernel(Cfg C, View V, cons
     for (int k = 0; k < 7; k++) E.R.ctrl[k] = (real)act[k];
     for (int s = 0; s < C.frame_skip; s++) pnp_substep(P, E, MS);
   }
+  if (C.block_gripper) {       // _step_callback: finger joints := 0, mj_forward (poses, contacts of the new state)
+    E.R.q[7] = 0; E.R.q[9] = 0;
+    for (int k = 0; k < 6; k++) E.qlag6[k] = E.R.q[k];
+    CubeSys<PnpScratch> CS{MS, E.Cb, E.dr};
+    CS.prepare(P, E.R.q);
+    for (int k = 0; k < 3; k++) E.qlag7[k] = E.Cb.pos[k];
+    for (int k = 0; k < 4; k++) E.qlag7[3 + k] = E.Cb.quat[k];
+    E.touch = CS.touch[0] && CS.touch[1];
+  }
   real obs[25], ag[3];
   observe_pnp(C, P, E, obs, ag);
   real dx = ag[0] - E.goal[0], dy = ag[1] - E.goal[1], dz = ag[2] - E.goal[2];
@@ -512,6 +525,7 @@ int mcg_create(const mcg_config* c, const mcg_model* model, int device, mcg_env*
   memcpy(C.init_ctrl, c->init_ctrl, sizeof(C.init_ctrl));
   C.seed = c->seed; C.env_id_offset = c->env_id_offset;
   C.dr_enable = c->dr_enable && c->has_object;
+  C.block_gripper = c->block_gripper;
   C.dr_mass[0] = c->dr_mass_range[0]; C.dr_mass[1] = c->dr_mass_range[1];
   C.dr_fric[0] = c->dr_friction_range[0]; C.dr_fric[1] = c->dr_friction_range[1];
   e->device = device;

@@ -78,8 +78,6 @@ class MyCobotVecEnv:
             raise ValueError(f"unknown reward_type {reward_type!r}")
         if controller_type == "joint" and fetch_env:
             raise AssertionError("Joint controller not supported for Fetch env")        # mycobot.py:96
-        if block_gripper:
-            raise NotImplementedError("block_gripper=True is off by default in the reference and not built")
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise _abi.McgError("MyCobotVecEnv runs on an AMD GPU only (device='cuda:N'); there is no CPU path")
@@ -102,6 +100,7 @@ class MyCobotVecEnv:
         cfg.reward_type = _REWARDS[reward_type]; cfg.frame_skip = self.frame_skip
         cfg.control_steps = self.control_steps; cfg.max_episode_steps = self.max_episode_steps
         cfg.target_in_the_air = int(target_in_the_air); cfg.auto_reset = int(auto_reset)
+        cfg.block_gripper = int(block_gripper)
         cfg.distance_threshold = self.distance_threshold; cfg.height_offset = height
         for k in range(3): cfg.initial_gripper_xpos[k] = igx[k]
         for k, v in enumerate(qpos): cfg.init_qpos[k] = v

@@ -289,6 +289,13 @@ void mco_envs_step(mco_envs* e, const float* actions, double* obs, double* achie
   for (int i = 0; i < n; i++) {
     env_t* v = &e->env[i];
     step_one(e, i, actions + (size_t)i * A);
+    if (e->cfg.block_gripper) {                 /* _step_callback: set_joint_qpos(finger joints, 0) + mj_forward */
+      const mco_model* mm = model_of(e, i);
+      v->d.qpos[mm->jnt_qposadr[e->cfg.finger_jnt[0]]] = 0.0;
+      v->d.qpos[mm->jnt_qposadr[e->cfg.finger_jnt[1]]] = 0.0;
+      mco_forward(mm, &v->d);
+      memcpy(v->qpos_lag, v->d.qpos, sizeof(double) * mm->nq);
+    }
     double o[32], ag[3], dg[3], r;
     get_obs(e, i, o, ag, dg);
     double dist = goal_distance(ag, dg);

@@ -34,6 +34,7 @@ typedef struct mco_env_config {
   int32_t frame_skip, control_steps, max_episode_steps, target_in_the_air, auto_reset;
   int32_t eef_site, obj_site, obj_jnt, grip_jnt[2], n_threads;
   int32_t dr_enable, pad_geom[2], obj_geom;
+  int32_t block_gripper, finger_jnt[2];      /* _step_callback: zero the two finger joints after every step (mycobot.py:300-306) */
   double distance_threshold, height_offset;
   double init_qpos[MCO_MAXNQ], init_qvel[MCO_MAXNV], init_ctrl[MCO_MAXU];
   double dr_mass_range[2], dr_friction_range[2];

@@ -31,7 +31,7 @@ def soften_gains(tab, scale=0.1):
 def make_oracle(n, has_object=False, controller_type="joint", fetch_env=False, reward_type="dense", seed=0,
                 env_id_offset=0, mesh_inertia="legacy", frame_skip=20, control_steps=5, max_episode_steps=50,
                 target_in_the_air=True, distance_threshold=0.01, auto_reset=True, n_threads=None, table=None,
-                domain_randomization=None):
+                domain_randomization=None, block_gripper=False):
     from oracle import pyoracle as po
     from mycobotgym_amd.vec_env import initial_state
     tab = table if table is not None else load_json(table_name(has_object, mesh_inertia))
@@ -49,6 +49,8 @@ def make_oracle(n, has_object=False, controller_type="joint", fetch_env=False, r
     cfg.obj_jnt = tab["jnt_name"].index("object0:joint") if has_object else -1
     cfg.grip_jnt[0] = tab["jnt_name"].index("robot0:right_gear_joint")
     cfg.grip_jnt[1] = tab["jnt_name"].index("robot0:left_gear_joint")
+    cfg.block_gripper = int(block_gripper)
+    cfg.finger_jnt[0] = tab["jnt_name"].index("right_finger_joint"); cfg.finger_jnt[1] = tab["jnt_name"].index("left_finger_joint")
     cfg.n_threads = n_threads or min(os.cpu_count() or 1, 16)
     cfg.pad_geom[0] = cfg.pad_geom[1] = cfg.obj_geom = -1
     if has_object:

@@ -124,3 +124,21 @@ def test_exact_mesh_variant_and_fetch(torch_cuda):
             assert flags; errs.append(e)
         assert np.median(np.concatenate(errs)) < 1e-9
         envs.close()
+
+
+def test_block_gripper(torch_cuda):
+    """S7 `_step_callback` (mycobot.py:300-306): finger joints forced to zero after every step, observations un-lagged."""
+    from tests.common import make_pair, sync_oracle_to, step_errors
+    rng = np.random.default_rng(0)
+    for has_object in (False, True):
+        envs, ora = make_pair(64, has_object=has_object, controller_type="joint", reward_type="dense", seed=6, block_gripper=True)
+        envs.reset(seed=6); ora.reset(seed=6)
+        errs = []
+        for t in range(8):
+            sync_oracle_to(envs, ora)
+            e, flags, _ = step_errors(envs, ora, rng.uniform(-1, 1, (64, 7)).astype(np.float32))
+            assert flags; errs.append(e)
+            q = envs.get_state()["qpos"]
+            assert (q[7] == 0).all() and (q[9] == 0).all()
+        assert np.median(np.concatenate(errs)) < 1e-9
+        envs.close()
