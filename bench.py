@@ -161,7 +161,7 @@ def main():
         if os.path.exists(pmc):
             with open(pmc) as f:
                 pj = json.load(f)
-            if pj.get("controller") == args.controller and pj.get("n_envs") == n:
+            if pj.get("controller") == args.controller and pj.get("n_envs") == n and pj.get("task", "reach") == args.task:
                 traffic = pj.get("hbm_bytes_per_launch"); src = "profiles/pmc_latest.json: " + pj.get("note", "")
         out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                            "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": src,

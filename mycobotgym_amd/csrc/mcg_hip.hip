@@ -29,7 +29,7 @@ int fail(int code, const char* fmt, const char* a = "") { snprintf(g_err, sizeof
 struct Cfg {
   int n, has_object, controller, fetch, reward_type, frame_skip, control_steps, max_episode_steps;
   int target_in_the_air, auto_reset, nq, nv, obs_dim, act_dim, dr_enable, block_gripper;
-  double dr_mass[2], dr_fric[2];
+  double dr_mass[2], dr_fric[2], qpos0_cube[7];
   double distance_threshold, height_offset, igx[3], dt, grip_center, grip_range;
   double init_qpos[19], init_qvel[18], init_ctrl[7];
   unsigned long long seed;
@@ -106,6 +106,18 @@ __device__ void reset_env(const Cfg& C, int i, Env& E, bool doit) {
   E.episode += doit ? 1 : 0;
 }
 
+// mj_checkPos / mj_checkVel [RECALL]: a non-finite or huge (> 1e10) coordinate makes MuJoCo call mj_resetData (qpos0,
+// zero velocity / ctrl / warm start) and carry on.  Here the check runs once per env-step instead of once per sub-step
+// (a diverged env is beyond parity anyway); it keeps one bad env from staying NaN until its next reset.
+__device__ bool bad_value(real x) { return !(x == x) || x > 1e10 || x < -1e10; }
+__device__ void guard_robot(Robot& R, real* qlag6) {
+  bool bad = false;
+  for (int k = 0; k < NB; k++) bad = bad || bad_value(R.q[k]) || bad_value(R.qd[k]) || bad_value(R.warm[k]);
+  for (int k = 0; k < NB; k++) { R.q[k] = bad ? 0.0 : R.q[k]; R.qd[k] = bad ? 0.0 : R.qd[k]; R.warm[k] = bad ? 0.0 : R.warm[k]; }
+  for (int k = 0; k < 7; k++) R.ctrl[k] = bad ? 0.0 : R.ctrl[k];
+  for (int k = 0; k < 6; k++) qlag6[k] = bad ? 0.0 : qlag6[k];
+}
+
 // _get_obs / generate_mujoco_observations for Reach (mycobot.py:245-283, 342-388): 10 numbers
 __device__ void observe_reach(const Cfg& C, ModelPtr P, const Env& E, real* obs, real* ag) {
   EefPose X;
@@ -180,6 +192,7 @@ __global__ __launch_bounds__(64) void step_reach_kernel(Cfg C, View V, const mcg
     for (int s = 0; s < C.frame_skip; s++) robot_substep(P, E.R, E.qlag6, MS);
   }
 
+  guard_robot(E.R, E.qlag6);
   if (C.block_gripper) {       // _step_callback (mycobot.py:300-306): finger joints := 0, then mj_forward removes the lag
     E.R.q[7] = 0; E.R.q[9] = 0;
     for (int k = 0; k < 6; k++) E.qlag6[k] = E.R.q[k];
@@ -376,6 +389,16 @@ __global__ __launch_bounds__(PNP_LANES) void step_pnp_kernel(Cfg C, View V, cons
     for (int k = 0; k < 7; k++) E.R.ctrl[k] = (real)act[k];
     for (int s = 0; s < C.frame_skip; s++) pnp_substep(P, E, MS);
   }
+  guard_robot(E.R, E.qlag6);
+  {   // same guard for the cube: back to its model pose at rest
+    bool bad = false;
+    for (int k = 0; k < 3; k++) bad = bad || bad_value(E.Cb.pos[k]);
+    for (int k = 0; k < 4; k++) bad = bad || bad_value(E.Cb.quat[k]);
+    for (int k = 0; k < 6; k++) bad = bad || bad_value(E.Cb.vel[k]) || bad_value(E.Cb.warm[k]);
+    for (int k = 0; k < 3; k++) { E.Cb.pos[k] = bad ? C.qpos0_cube[k] : E.Cb.pos[k]; E.qlag7[k] = bad ? C.qpos0_cube[k] : E.qlag7[k]; }
+    for (int k = 0; k < 4; k++) { E.Cb.quat[k] = bad ? C.qpos0_cube[3 + k] : E.Cb.quat[k]; E.qlag7[3 + k] = bad ? C.qpos0_cube[3 + k] : E.qlag7[3 + k]; }
+    for (int k = 0; k < 6; k++) { E.Cb.vel[k] = bad ? 0.0 : E.Cb.vel[k]; E.Cb.warm[k] = bad ? 0.0 : E.Cb.warm[k]; }
+  }
   if (C.block_gripper) {       // _step_callback: finger joints := 0, mj_forward (poses, contacts of the new state)
     E.R.q[7] = 0; E.R.q[9] = 0;
     for (int k = 0; k < 6; k++) E.qlag6[k] = E.R.q[k];
@@ -526,6 +549,8 @@ int mcg_create(const mcg_config* c, const mcg_model* model, int device, mcg_env*
   C.seed = c->seed; C.env_id_offset = c->env_id_offset;
   C.dr_enable = c->dr_enable && c->has_object;
   C.block_gripper = c->block_gripper;
+  for (int k = 0; k < 3; k++) C.qpos0_cube[k] = m->body[12].r[k];      // qpos0 of the free joint = the body's MJCF pose
+  C.qpos0_cube[3] = 1; C.qpos0_cube[4] = C.qpos0_cube[5] = C.qpos0_cube[6] = 0;
   C.dr_mass[0] = c->dr_mass_range[0]; C.dr_mass[1] = c->dr_mass_range[1];
   C.dr_fric[0] = c->dr_friction_range[0]; C.dr_fric[1] = c->dr_friction_range[1];
   e->device = device;

@@ -142,3 +142,22 @@ def test_block_gripper(torch_cuda):
             assert (q[7] == 0).all() and (q[9] == 0).all()
         assert np.median(np.concatenate(errs)) < 1e-9
         envs.close()
+
+
+def test_bad_state_recovers(torch_cuda):
+    """A NaN / huge state is reset like mj_checkPos does (qpos0, zero velocities) instead of poisoning the env forever."""
+    torch = torch_cuda
+    from mycobotgym_amd import MyCobotVecEnv
+    for has_object in (False, True):
+        envs = MyCobotVecEnv(64, has_object=has_object, controller_type="joint", reward_type="dense", seed=1)
+        envs.reset(seed=1)
+        s = envs.get_state()
+        s["qvel"][0, 3] = float("nan"); s["qpos"][2, 5] = 1e300
+        if has_object:
+            s["qvel"][14, 7] = float("inf")
+        envs.set_state(**s)
+        for _ in range(3):
+            obs, rew, term, trunc, info = envs.step(torch.zeros(64, 7, device="cuda"))
+        assert torch.isfinite(obs["observation"]).all() and torch.isfinite(rew).all()
+        assert all(torch.isfinite(v.double()).all() for v in envs.get_state().values())
+        envs.close()

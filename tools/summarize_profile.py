@@ -50,7 +50,7 @@ if "SQ_INSTS_VALU" in c and "SQ_WAVES" in c:
 os.makedirs(os.path.join(root, "profiles"), exist_ok=True)
 json.dump(summary, open(os.path.join(root, "profiles", f"{tag}_summary.json"), "w"), indent=1)
 if "hbm" in summary:
-    json.dump({"controller": "joint", "n_envs": n_envs, "hbm_bytes_per_launch": summary["hbm"]["bytes_per_launch_corrected"],
+    json.dump({"task": "reach", "controller": "joint", "n_envs": n_envs, "hbm_bytes_per_launch": summary["hbm"]["bytes_per_launch_corrected"],
                "note": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH_SIZE x2 (gfx950), tag {tag}"},
               open(os.path.join(root, "profiles", "pmc_latest.json"), "w"), indent=1)
 print(json.dumps(summary, indent=1))
