@@ -11,7 +11,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmycobot_hip.so")
+# MCG_LIB selects another build of the same library (kernel A/B timing, tools/ab_bench.py); default: the in-tree one
+LIB_PATH = os.environ.get("MCG_LIB") or os.path.join(_HERE, "libmycobot_hip.so")
 
 MCG_OK, MCG_ERR_ARG, MCG_ERR_HIP, MCG_ERR_UNSUPPORTED = 0, 1, 2, 3
 CTRL_JOINT, CTRL_IK = 0, 1

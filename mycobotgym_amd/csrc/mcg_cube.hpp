@@ -45,9 +45,9 @@ MCG_DEV void make_frame(const real* n, real* t1, real* t2) {
   const bool usey = (n[1] < 0.5 && n[1] > -0.5);
   real tmp[3] = {0.0, usey ? 1.0 : 0.0, usey ? 0.0 : 1.0};
   const real d = dot3(n, tmp);
-  for (int k = 0; k < 3; k++) t1[k] = tmp[k] - d * n[k];
+  _Pragma("unroll") for (int k = 0; k < 3; k++) t1[k] = tmp[k] - d * n[k];
   const real l = sqrt(dot3(t1, t1));
-  for (int k = 0; k < 3; k++) t1[k] /= l;
+  _Pragma("unroll") for (int k = 0; k < 3; k++) t1[k] /= l;
   cross(n, t1, t2);
 }
 
@@ -61,10 +61,10 @@ struct ContactList {
       const int b = LDS_CON + n * CON_STRIDE;
       real t1[3], t2[3];
       make_frame(normal, t1, t2);
-      for (int k = 0; k < 3; k++) { S.st(b + k, pos[k]); S.st(b + 3 + k, normal[k]); S.st(b + 6 + k, t1[k]); S.st(b + 9 + k, t2[k]); }
+      _Pragma("unroll") for (int k = 0; k < 3; k++) { S.st(b + k, pos[k]); S.st(b + 3 + k, normal[k]); S.st(b + 6 + k, t1[k]); S.st(b + 9 + k, t2[k]); }
       S.st(b + 12, dist); S.st(b + 15, (real)type);
     }
-    n += ok ? 1 : 0;
+    n += sel(ok, 1, 0);
   }
 };
 
@@ -72,10 +72,10 @@ struct ContactList {
 template <class LS>
 MCG_DEV void ground_box(ContactList<LS>& CL, const real* pb, const real* Rb, const real* hb, int type) {
   const real n[3] = {0, 0, 1};
-  for (int v = 0; v < 8; v++) {
-    const real lx = (v & 1) ? hb[0] : -hb[0], ly = (v & 2) ? hb[1] : -hb[1], lz = (v & 4) ? hb[2] : -hb[2];
+  _Pragma("unroll") for (int v = 0; v < 8; v++) {
+    const real lx = (v & 1) ? hb[0] : -hb[0], ly = (v & 2) ? hb[1] : -hb[1], lz = sel((v & 4), hb[2], -hb[2]);
     real w[3];
-    for (int k = 0; k < 3; k++) w[k] = pb[k] + Rb[3*k]*lx + Rb[3*k+1]*ly + Rb[3*k+2]*lz;
+    _Pragma("unroll") for (int k = 0; k < 3; k++) w[k] = pb[k] + Rb[3*k]*lx + Rb[3*k+1]*ly + Rb[3*k+2]*lz;
     const real dist = w[2];
     const real pos[3] = {w[0], w[1], w[2] - 0.5 * dist};
     CL.add(pos, n, dist, type);
@@ -90,27 +90,27 @@ MCG_DEV void box_box(ContactList<LS>& CL, bool live, const real* pa, const real*
                      const real* pb, const real* Rb, const real* hb, int type) {
   const LS& S = CL.S;
   real A[3][3], B[3][3], p[3] = {pb[0] - pa[0], pb[1] - pa[1], pb[2] - pa[2]};
-  for (int k = 0; k < 3; k++) for (int r = 0; r < 3; r++) { A[k][r] = Ra[3*r + k]; B[k][r] = Rb[3*r + k]; }
+  _Pragma("unroll") for (int k = 0; k < 3; k++) for (int r = 0; r < 3; r++) { A[k][r] = Ra[3*r + k]; B[k][r] = Rb[3*r + k]; }
   real Cm[3][3], Q[3][3];
-  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { Cm[i][j] = dot3(A[i], B[j]); Q[i][j] = fabs(Cm[i][j]); }
+  _Pragma("unroll") for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { Cm[i][j] = dot3(A[i], B[j]); Q[i][j] = fabs(Cm[i][j]); }
   const real pA[3] = {dot3(A[0], p), dot3(A[1], p), dot3(A[2], p)};
   const real pB[3] = {dot3(B[0], p), dot3(B[1], p), dot3(B[2], p)};
   real best = -INFINITY; int code = -1; real nrm[3] = {0, 0, 0}; bool invert = false; bool sep = !live;
-  for (int i = 0; i < 3; i++) {
+  _Pragma("unroll") for (int i = 0; i < 3; i++) {
     const real s = fabs(pA[i]) - (ha[i] + hb[0]*Q[i][0] + hb[1]*Q[i][1] + hb[2]*Q[i][2]);
     sep = sep || (s > 0);
     const bool tk = s > best;
-    best = tk ? s : best; code = tk ? i : code; invert = tk ? (pA[i] < 0) : invert;
-    for (int k = 0; k < 3; k++) nrm[k] = tk ? A[i][k] : nrm[k];
+    best = sel(tk, s, best); code = sel(tk, i, code); invert = sel(tk, (pA[i] < 0), invert);
+    _Pragma("unroll") for (int k = 0; k < 3; k++) nrm[k] = sel(tk, A[i][k], nrm[k]);
   }
-  for (int j = 0; j < 3; j++) {
+  _Pragma("unroll") for (int j = 0; j < 3; j++) {
     const real s = fabs(pB[j]) - (hb[j] + ha[0]*Q[0][j] + ha[1]*Q[1][j] + ha[2]*Q[2][j]);
     sep = sep || (s > 0);
     const bool tk = s > best;
-    best = tk ? s : best; code = tk ? 3 + j : code; invert = tk ? (pB[j] < 0) : invert;
-    for (int k = 0; k < 3; k++) nrm[k] = tk ? B[j][k] : nrm[k];
+    best = sel(tk, s, best); code = sel(tk, 3 + j, code); invert = sel(tk, (pB[j] < 0), invert);
+    _Pragma("unroll") for (int k = 0; k < 3; k++) nrm[k] = sel(tk, B[j][k], nrm[k]);
   }
-  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
+  _Pragma("unroll") for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
     const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
     const real expr = pA[i2]*Cm[i1][j] - pA[i1]*Cm[i2][j];
     const real len = sqrt(fmax(0.0, 1 - Cm[i][j]*Cm[i][j]));
@@ -119,27 +119,27 @@ MCG_DEV void box_box(ContactList<LS>& CL, bool live, const real* pa, const real*
     sep = sep || (valid && s > 0);
     const bool tk = valid && (s * 1.05 > best);
     real L[3]; cross(A[i], B[j], L);
-    best = tk ? s : best; code = tk ? 6 + 3*i + j : code; invert = tk ? (expr < 0) : invert;
-    for (int k = 0; k < 3; k++) nrm[k] = tk ? L[k] / len : nrm[k];
+    best = sel(tk, s, best); code = sel(tk, 6 + 3*i + j, code); invert = sel(tk, (expr < 0), invert);
+    _Pragma("unroll") for (int k = 0; k < 3; k++) nrm[k] = sel(tk, L[k] / len, nrm[k]);
   }
   const bool hit = !sep && code >= 0;
   if (!__any(hit)) return;
   real normal[3];
-  for (int k = 0; k < 3; k++) normal[k] = invert ? -nrm[k] : nrm[k];
+  _Pragma("unroll") for (int k = 0; k < 3; k++) normal[k] = sel(invert, -nrm[k], nrm[k]);
 
   // ---- edge-edge (rare): one point
   if (__any(hit && code >= 6)) {
-    const int ce = code >= 6 ? code - 6 : 0;
+    const int ce = sel(code >= 6, code - 6, 0);
     const int i = ce / 3, j = ce % 3;
     real ea[3], eb[3], Ai[3], Bj[3];
-    for (int k = 0; k < 3; k++) { ea[k] = pa[k]; eb[k] = pb[k]; Ai[k] = (i == 0) ? A[0][k] : (i == 1) ? A[1][k] : A[2][k]; Bj[k] = (j == 0) ? B[0][k] : (j == 1) ? B[1][k] : B[2][k]; }
-    for (int a = 0; a < 3; a++) { const real sg = (a == i) ? 0.0 : (dot3(normal, A[a]) > 0 ? 1.0 : -1.0); for (int k = 0; k < 3; k++) ea[k] += sg * ha[a] * A[a][k]; }
-    for (int b = 0; b < 3; b++) { const real sg = (b == j) ? 0.0 : (dot3(normal, B[b]) > 0 ? -1.0 : 1.0); for (int k = 0; k < 3; k++) eb[k] += sg * hb[b] * B[b][k]; }
+    _Pragma("unroll") for (int k = 0; k < 3; k++) { ea[k] = pa[k]; eb[k] = pb[k]; Ai[k] = sel3(i, A[0][k], A[1][k], A[2][k]); Bj[k] = sel3(j, B[0][k], B[1][k], B[2][k]); }
+    _Pragma("unroll") for (int a = 0; a < 3; a++) { const real sg = (a == i) ? 0.0 : (dot3(normal, A[a]) > 0 ? 1.0 : -1.0); _Pragma("unroll") for (int k = 0; k < 3; k++) ea[k] += sg * ha[a] * A[a][k]; }
+    _Pragma("unroll") for (int b = 0; b < 3; b++) { const real sg = (b == j) ? 0.0 : (dot3(normal, B[b]) > 0 ? -1.0 : 1.0); _Pragma("unroll") for (int k = 0; k < 3; k++) eb[k] += sg * hb[b] * B[b][k]; }
     const real w[3] = {eb[0] - ea[0], eb[1] - ea[1], eb[2] - ea[2]};
     const real uaub = dot3(Ai, Bj), q1 = dot3(Ai, w), q2 = -dot3(Bj, w), dd = 1 - uaub*uaub;
     const real s = dd <= 1e-12 ? 0.0 : (q1 + uaub*q2) / dd, t = dd <= 1e-12 ? 0.0 : (uaub*q1 + q2) / dd;
     real pos[3];
-    for (int k = 0; k < 3; k++) pos[k] = 0.5 * ((ea[k] + s*Ai[k]) + (eb[k] + t*Bj[k]));
+    _Pragma("unroll") for (int k = 0; k < 3; k++) pos[k] = 0.5 * ((ea[k] + s*Ai[k]) + (eb[k] + t*Bj[k]));
     CL.add(pos, normal, (hit && code >= 6) ? best : 1.0, type);
   }
   if (!__any(hit && code < 6)) return;
@@ -147,23 +147,23 @@ MCG_DEV void box_box(ContactList<LS>& CL, bool live, const real* pa, const real*
   // ---- face contact: clip the incident face against the reference face
   const bool face = hit && code < 6;
   const bool refA = code < 3;
-  const int ax = face ? code % 3 : 0;
+  const int ax = sel(face, code % 3, 0);
   real Rr[3][3], Ri[3][3], pr[3], pi[3], hr[3], hi[3], n2[3];
-  for (int k = 0; k < 3; k++) {
-    for (int r = 0; r < 3; r++) { Rr[k][r] = refA ? A[k][r] : B[k][r]; Ri[k][r] = refA ? B[k][r] : A[k][r]; }
-    pr[k] = refA ? pa[k] : pb[k]; pi[k] = refA ? pb[k] : pa[k]; hr[k] = refA ? ha[k] : hb[k]; hi[k] = refA ? hb[k] : ha[k];
-    n2[k] = refA ? normal[k] : -normal[k];
+  _Pragma("unroll") for (int k = 0; k < 3; k++) {
+    _Pragma("unroll") for (int r = 0; r < 3; r++) { Rr[k][r] = sel(refA, A[k][r], B[k][r]); Ri[k][r] = sel(refA, B[k][r], A[k][r]); }
+    pr[k] = sel(refA, pa[k], pb[k]); pi[k] = sel(refA, pb[k], pa[k]); hr[k] = sel(refA, ha[k], hb[k]); hi[k] = sel(refA, hb[k], ha[k]);
+    n2[k] = sel(refA, normal[k], -normal[k]);
   }
   const real nr[3] = {dot3(n2, Ri[0]), dot3(n2, Ri[1]), dot3(n2, Ri[2])};
   const int lan = fabs(nr[0]) > fabs(nr[1]) ? (fabs(nr[0]) > fabs(nr[2]) ? 0 : 2) : (fabs(nr[1]) > fabs(nr[2]) ? 1 : 2);
   const int a1 = (lan + 1) % 3, a2 = (lan + 2) % 3, c1 = (ax + 1) % 3, c2 = (ax + 2) % 3;
-  auto pick = [](const real (*M)[3], int idx, real* out) { for (int k = 0; k < 3; k++) out[k] = (idx == 0) ? M[0][k] : (idx == 1) ? M[1][k] : M[2][k]; };
-  auto pickv = [](const real* v, int idx) { return (idx == 0) ? v[0] : (idx == 1) ? v[1] : v[2]; };
+  auto pick = [](const real (*M)[3], int idx, real* out) { _Pragma("unroll") for (int k = 0; k < 3; k++) out[k] = sel3(idx, M[0][k], M[1][k], M[2][k]); };
+  auto pickv = [](const real* v, int idx) { return sel3(idx, v[0], v[1], v[2]); };
   real Rilan[3], Ria1[3], Ria2[3], Rrc1[3], Rrc2[3];
   pick(Ri, lan, Rilan); pick(Ri, a1, Ria1); pick(Ri, a2, Ria2); pick(Rr, c1, Rrc1); pick(Rr, c2, Rrc2);
   const real hilan = pickv(hi, lan), hia1 = pickv(hi, a1), hia2 = pickv(hi, a2), hrax = pickv(hr, ax);
   real center[3];
-  for (int k = 0; k < 3; k++) center[k] = pi[k] - pr[k] + (pickv(nr, lan) < 0 ? hilan : -hilan) * Rilan[k];
+  _Pragma("unroll") for (int k = 0; k < 3; k++) center[k] = pi[k] - pr[k] + (pickv(nr, lan) < 0 ? hilan : -hilan) * Rilan[k];
   const real cx = dot3(center, Rrc1), cy = dot3(center, Rrc2);
   const real m11 = dot3(Rrc1, Ria1), m12 = dot3(Rrc1, Ria2), m21 = dot3(Rrc2, Ria1), m22 = dot3(Rrc2, Ria2);
   const real k1 = m11*hia1, k2 = m21*hia1, k3 = m12*hia2, k4 = m22*hia2;
@@ -173,19 +173,19 @@ MCG_DEV void box_box(ContactList<LS>& CL, bool live, const real* pa, const real*
   S.st(LDS_POLY + 2, cx - k1 + k3); S.st(LDS_POLY + 3, cy - k2 + k4);
   S.st(LDS_POLY + 4, cx + k1 + k3); S.st(LDS_POLY + 5, cy + k2 + k4);
   S.st(LDS_POLY + 6, cx + k1 - k3); S.st(LDS_POLY + 7, cy + k2 - k4);
-  int np = face ? 4 : 0;
+  int np = sel(face, 4, 0);
   int src = LDS_POLY, dst = LDS_POLY + 32;
-  for (int dir = 0; dir < 2; dir++) for (int sgn = -1; sgn <= 1; sgn += 2) {
+  _Pragma("unroll") for (int dir = 0; dir < 2; dir++) for (int sgn = -1; sgn <= 1; sgn += 2) {
     int nq = 0;
-    const real lim = dir == 0 ? rect[0] : rect[1];
+    const real lim = sel(dir == 0, rect[0], rect[1]);
     for (int v = 0; __any(v < np); v++) {
       const bool on = v < np;
-      const int vn = (v + 1 < np) ? v + 1 : 0;
+      const int vn = sel((v + 1 < np), v + 1, 0);
       const real Pd = S.ld(src + 2*v + dir), Po = S.ld(src + 2*v + 1 - dir);
       const real Nd = S.ld(src + 2*vn + dir), No = S.ld(src + 2*vn + 1 - dir);
       const bool inP = sgn * Pd < lim, inN = sgn * Nd < lim;
       if (on && inP && nq < 15) { S.st(dst + 2*nq + dir, Pd); S.st(dst + 2*nq + 1 - dir, Po); }
-      nq += (on && inP && nq < 15) ? 1 : 0;
+      nq += sel((on && inP && nq < 15), 1, 0);
       const real tt = (sgn * lim - Pd) / (Nd - Pd);
       if (on && (inP != inN) && nq < 15) { S.st(dst + 2*nq + dir, sgn * lim); S.st(dst + 2*nq + 1 - dir, Po + tt * (No - Po)); }
       nq += (on && (inP != inN) && nq < 15) ? 1 : 0;
@@ -201,13 +201,13 @@ MCG_DEV void box_box(ContactList<LS>& CL, bool live, const real* pa, const real*
     const real qx = S.ld(src + 2*v) - cx, qy = S.ld(src + 2*v + 1) - cy;
     const real u1 = im11*qx + im12*qy, u2 = im21*qx + im22*qy;
     real pt[3];
-    for (int k = 0; k < 3; k++) pt[k] = center[k] + u1*Ria1[k] + u2*Ria2[k];
+    _Pragma("unroll") for (int k = 0; k < 3; k++) pt[k] = center[k] + u1*Ria1[k] + u2*Ria2[k];
     const real depth = hrax - dot3(n2, pt);
     real pos[3];
-    for (int k = 0; k < 3; k++) pos[k] = pr[k] + pt[k] + 0.5*depth*n2[k];
+    _Pragma("unroll") for (int k = 0; k < 3; k++) pos[k] = pr[k] + pt[k] + 0.5*depth*n2[k];
     const bool take = on && (depth > 0);
     CL.add(pos, normal, take ? -depth : 1.0, type);
-    kept += take ? 1 : 0;
+    kept += sel(take, 1, 0);
   }
 }
 
@@ -220,20 +220,20 @@ template <class LS>
 MCG_DEV void cube_rows(const LS& S, int c, const real* Rc, const real* cpos, CubeRows& R) {
   const int b = LDS_CON + c * CON_STRIDE;
   real pos[3], n[3], t1[3], t2[3], arm[3], x[3];
-  for (int k = 0; k < 3; k++) { pos[k] = S.ld(b + k); n[k] = S.ld(b + 3 + k); t1[k] = S.ld(b + 6 + k); t2[k] = S.ld(b + 9 + k); arm[k] = pos[k] - cpos[k]; }
+  _Pragma("unroll") for (int k = 0; k < 3; k++) { pos[k] = S.ld(b + k); n[k] = S.ld(b + 3 + k); t1[k] = S.ld(b + 6 + k); t2[k] = S.ld(b + 9 + k); arm[k] = pos[k] - cpos[k]; }
   auto fill = [&](const real* d, real* J) {
     cross(arm, d, x);
-    for (int k = 0; k < 3; k++) { J[k] = d[k]; J[3 + k] = Rc[k]*x[0] + Rc[3 + k]*x[1] + Rc[6 + k]*x[2]; }
+    _Pragma("unroll") for (int k = 0; k < 3; k++) { J[k] = d[k]; J[3 + k] = Rc[k]*x[0] + Rc[3 + k]*x[1] + Rc[6 + k]*x[2]; }
   };
   fill(n, R.Jn); fill(t1, R.J1); fill(t2, R.J2);
-  for (int k = 0; k < 3; k++) { R.Jt[k] = 0; R.Jt[3 + k] = Rc[k]*n[0] + Rc[3 + k]*n[1] + Rc[6 + k]*n[2]; }
+  _Pragma("unroll") for (int k = 0; k < 3; k++) { R.Jt[k] = 0; R.Jt[3 + k] = Rc[k]*n[0] + Rc[3 + k]*n[1] + Rc[6 + k]*n[2]; }
 }
 
 // pyramid row r (0..5) of a contact: Jn + sign * mu * Jk
 MCG_DEV void pyramid_row(const CubeRows& R, int r, const real* mu, real* j) {
-  const int k = r >> 1; const real sg = (r & 1) ? -1.0 : 1.0;
-  const real m = sg * ((k == 0) ? mu[0] : (k == 1) ? mu[1] : mu[2]);
-  for (int d = 0; d < 6; d++) { const real jk = (k == 0) ? R.J1[d] : (k == 1) ? R.J2[d] : R.Jt[d]; j[d] = R.Jn[d] + m * jk; }
+  const int k = r >> 1; const real sg = sel((r & 1), -1.0, 1.0);
+  const real m = sg * (sel3(k, mu[0], mu[1], mu[2]));
+  _Pragma("unroll") for (int d = 0; d < 6; d++) { const real jk = sel3(k, R.J1[d], R.J2[d], R.Jt[d]); j[d] = R.Jn[d] + m * jk; }
 }
 
 // Robot-side entries of a pad-cube contact's rows, dofs (arm 0..5, gear, finger) of the pad's side.  The pad is geom1,
@@ -244,21 +244,21 @@ struct PadRows { real Jn[8], J1[8], J2[8], Jt[8]; };
 template <class LS>
 struct CubeSys {
   static constexpr bool enabled = true;
-  const LS S; Cube& Cb; const real* dr;        // (the model pointer is passed in: it must stay a scalar register)
+  const LS S; Cube Cb; real dr[2];             // by value: a reference into the env struct pins that struct in memory
+                                               // (the model pointer is passed in: it must stay a scalar register)
+  unsigned long long pm_bits;                  // the model pointer's bits, for stages reached through the robot's hook
+  MCG_DEV CubeSys(const LS s_, const Cube& c, const real* d) : S(s_), Cb(c), pm_bits(0) { dr[0] = d[0]; dr[1] = d[1]; }
   real h, Rc[9], Md[6], damp[6], fs[6];
   real B_tc, B_pc, mu_tc[3], mu_pc[3];
   int ncon; bool any_pad, solved, touch[2];    // touch: this forward pass has a right / left pad-cube contact
   real a_c[6], fc[6];
 
   // ------------------------------------------------------------------------------------------------- prepare
-  MCG_DEV void prepare(ModelPtr Pm, const real* qr) {
+  // Cheap quantities of the current state (rotation, inertia, smooth force, friction): re-derived by each stage that
+  // needs them rather than kept live across the robot's pipeline (they would be spilled there).
+  MCG_DEV void derive(ModelPtr Pm) {
     ModelPtr Q = launder(Pm);
     h = Q->timestep;
-    {   // mj_kinematics normalises the stored quaternion
-      const real nq = sqrt(Cb.quat[0]*Cb.quat[0] + Cb.quat[1]*Cb.quat[1] + Cb.quat[2]*Cb.quat[2] + Cb.quat[3]*Cb.quat[3]);
-      const bool tiny = nq < MINVAL;
-      for (int k = 0; k < 4; k++) Cb.quat[k] = tiny ? (k == 0 ? 1.0 : 0.0) : Cb.quat[k] / nq;
-    }
     quat_to_mat(Cb.quat, Rc);
     const real mass = Q->body[12].mass * dr[0];
     const real In[3] = {Q->body[12].inertia[0] * dr[0], Q->body[12].inertia[1] * dr[0], Q->body[12].inertia[2] * dr[0]};
@@ -269,15 +269,29 @@ struct CubeSys {
     const real Iw[3] = {In[0]*w[0], In[1]*w[1], In[2]*w[2]};
     real gyro[3]; cross(w, Iw, gyro);
     fs[0] = -damp[0]*Cb.vel[0]; fs[1] = -damp[1]*Cb.vel[1]; fs[2] = -damp[2]*Cb.vel[2] - mass * gb[2];
-    for (int k = 0; k < 3; k++) fs[3 + k] = -damp[3 + k]*w[k] - gyro[k];
-    solved = false;
-    for (int k = 0; k < 6; k++) { a_c[k] = Cb.warm[k]; fc[k] = 0; }
-
+    _Pragma("unroll") for (int k = 0; k < 3; k++) fs[3 + k] = -damp[3 + k]*w[k] - gyro[k];
     // friction after domain randomisation: element-wise max of the (scaled) geom frictions
     const real ft = Q->geom_friction0[0], fp = Q->geom_friction0[1] * dr[1], fcb = Q->geom_friction0[2] * dr[1];
     mu_tc[0] = mu_tc[1] = fmax(ft, fcb); mu_tc[2] = Q->contact_par[PAIR_TABLE_CUBE][12];
     mu_pc[0] = mu_pc[1] = fmax(fp, fcb); mu_pc[2] = Q->contact_par[PAIR_PADR_CUBE][12];
     B_tc = Q->contact_par[PAIR_TABLE_CUBE][1]; B_pc = Q->contact_par[PAIR_PADR_CUBE][1];
+  }
+
+  MCG_DEV ModelPtr model() const {                // wave-uniform pointer rebuilt as a scalar
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)pm_bits), hi = __builtin_amdgcn_readfirstlane((unsigned)(pm_bits >> 32));
+    return (ModelPtr)(((unsigned long long)hi << 32) | lo);
+  }
+  MCG_DEV void prepare(ModelPtr Pm, const real* qr) {
+    pm_bits = (unsigned long long)Pm;
+    {   // mj_kinematics normalises the stored quaternion
+      const real nq = sqrt(Cb.quat[0]*Cb.quat[0] + Cb.quat[1]*Cb.quat[1] + Cb.quat[2]*Cb.quat[2] + Cb.quat[3]*Cb.quat[3]);
+      const bool tiny = nq < MINVAL;
+      _Pragma("unroll") for (int k = 0; k < 4; k++) Cb.quat[k] = sel(tiny, k == 0 ? 1.0 : 0.0, Cb.quat[k] / nq);
+    }
+    derive(Pm);
+    ModelPtr Q = launder(Pm);
+    solved = false;
+    _Pragma("unroll") for (int k = 0; k < 6; k++) { a_c[k] = Cb.warm[k]; fc[k] = 0; }
 
     // ---- P4 collision, in the oracle's pair order: ground-cube, table-cube, right pad-cube, left pad-cube
     ContactList<LS> CL{S, 0};
@@ -299,14 +313,14 @@ struct CubeSys {
     {
       const TrigC T = load_trig();
       real R[9], p[3];
-      for (int k = 0; k < 9; k++) R[k] = Q->base_mat[k];
-      for (int k = 0; k < 3; k++) p[k] = Q->base_pos[k];
+      _Pragma("unroll") for (int k = 0; k < 9; k++) R[k] = Q->base_mat[k];
+      _Pragma("unroll") for (int k = 0; k < 3; k++) p[k] = Q->base_pos[k];
       auto joint = [&](int slot, int K, int sg, const real* r, real ang, real* Rio, real* pio) {
-        for (int k = 0; k < 3; k++) pio[k] += Rio[3*k]*r[0] + Rio[3*k+1]*r[1] + Rio[3*k+2]*r[2];
-        for (int k = 0; k < 3; k++) { S.st(LDS_WJ + slot*6 + k, sg * Rio[3*k + K]); S.st(LDS_WJ + slot*6 + 3 + k, pio[k]); }
+        _Pragma("unroll") for (int k = 0; k < 3; k++) pio[k] += Rio[3*k]*r[0] + Rio[3*k+1]*r[1] + Rio[3*k+2]*r[2];
+        _Pragma("unroll") for (int k = 0; k < 3; k++) { S.st(LDS_WJ + slot*6 + k, sg * Rio[3*k + K]); S.st(LDS_WJ + slot*6 + 3 + k, pio[k]); }
         real sn_, cs_; sincos_cw(T, sg * ang, sn_, cs_);
         const int A = (K + 1) % 3, B = (K + 2) % 3;
-        for (int k = 0; k < 3; k++) {
+        _Pragma("unroll") for (int k = 0; k < 3; k++) {
           const real ca = Rio[3*k + A], cb = Rio[3*k + B];
           Rio[3*k + A] = cs_ * ca + sn_ * cb; Rio[3*k + B] = -sn_ * ca + cs_ * cb;
         }
@@ -319,13 +333,13 @@ struct CubeSys {
         static_for<2>([&](auto Sd) {
           constexpr int sd = Sd; constexpr int g = 6 + 2 * sd, f = 7 + 2 * sd;
           real Rs[9], ps[3];
-          for (int k = 0; k < 9; k++) Rs[k] = R[k];
-          for (int k = 0; k < 3; k++) ps[k] = p[k];
+          _Pragma("unroll") for (int k = 0; k < 9; k++) Rs[k] = R[k];
+          _Pragma("unroll") for (int k = 0; k < 3; k++) ps[k] = p[k];
           real r[3]; ldc<3>(Q->body[g].r, r); joint(g, 1, AXS[g], r, qr[g], Rs, ps);
           ldc<3>(Q->body[f].r, r); joint(f, 1, AXS[f], r, qr[f], Rs, ps);
           real pb[6]; ldc<6>(Q->pad_box[sd], pb);
           real pc[3];
-          for (int k = 0; k < 3; k++) pc[k] = ps[k] + Rs[3*k]*pb[0] + Rs[3*k+1]*pb[1] + Rs[3*k+2]*pb[2];
+          _Pragma("unroll") for (int k = 0; k < 3; k++) pc[k] = ps[k] + Rs[3*k]*pb[0] + Rs[3*k+1]*pb[1] + Rs[3*k+2]*pb[2];
           const real dx = Cb.pos[0] - pc[0], dy = Cb.pos[1] - pc[1], dz = Cb.pos[2] - pc[2];
           const real rs = sqrt(pb[3]*pb[3] + pb[4]*pb[4] + pb[5]*pb[5]) + sqrt(dot3(hc, hc));
           const bool near = reach && (dx*dx + dy*dy + dz*dz <= rs*rs);
@@ -342,7 +356,7 @@ struct CubeSys {
     for (int c = 0; __any(c < ncon); c++) {
       if (c >= ncon) {
         for (int k = 0; k < CON_STRIDE; k++) S.st(LDS_CON + c * CON_STRIDE + k, 0.0);
-        for (int k = 0; k < 12; k++) S.st(LDS_ROW + c * 12 + k, 0.0);
+        _Pragma("unroll") for (int k = 0; k < 12; k++) S.st(LDS_ROW + c * 12 + k, 0.0);
         S.st(LDS_ACT + c, 0.0);
       }
     }
@@ -352,12 +366,12 @@ struct CubeSys {
     for (int c = 0; __any(c < ncon); c++) {
       const int b = LDS_CON + c * CON_STRIDE;
       const real dist = S.ld(b + 12);
-      const int type = (c < ncon) ? (int)S.ld(b + 15) : 0;
+      const int type = sel((c < ncon), (int)S.ld(b + 15), 0);
       const bool pad = type != PAIR_TABLE_CUBE;
-      const real imp = pad ? impedance(par_p, dist) : impedance(par_t, dist);
+      const real imp = sel(pad, impedance(par_p, dist), impedance(par_t, dist));
       const real tran = pad ? (type == PAIR_PADR_CUBE ? Q->contact_diag[PAIR_PADR_CUBE][0] : Q->contact_diag[PAIR_PADL_CUBE][0])
                             : Q->contact_diag[PAIR_TABLE_CUBE][0];
-      const real m0 = pad ? mu_pc[0] : mu_tc[0];
+      const real m0 = sel(pad, mu_pc[0], mu_tc[0]);
       const real Rn = fmax(MINVAL, (1 - imp) * tran * (1 + m0*m0) / imp);
       const real Rpy = fmax(MINVAL, 2 * m0*m0 * Rn);
       if (c < ncon) { S.st(b + 13, 1.0 / Rpy); S.st(b + 14, (pad ? par_p[0] : par_t[0]) * imp * dist); }
@@ -369,97 +383,97 @@ struct CubeSys {
   MCG_DEV void rows_pad(int c, int side, PadRows& P) const {
     const int b = LDS_CON + c * CON_STRIDE;
     real pos[3], n[3], t1[3], t2[3];
-    for (int k = 0; k < 3; k++) { pos[k] = S.ld(b + k); n[k] = S.ld(b + 3 + k); t1[k] = S.ld(b + 6 + k); t2[k] = S.ld(b + 9 + k); }
-    for (int j = 0; j < 8; j++) {
-      const int slot = (j < 6) ? j : (6 + 2 * side + (j - 6));
+    _Pragma("unroll") for (int k = 0; k < 3; k++) { pos[k] = S.ld(b + k); n[k] = S.ld(b + 3 + k); t1[k] = S.ld(b + 6 + k); t2[k] = S.ld(b + 9 + k); }
+    _Pragma("unroll") for (int j = 0; j < 8; j++) {
+      const int slot = sel((j < 6), j, (6 + 2 * side + (j - 6)));
       real ax[3], an[3], lev[3], v[3];
-      for (int k = 0; k < 3; k++) { ax[k] = S.ld(LDS_WJ + slot*6 + k); an[k] = S.ld(LDS_WJ + slot*6 + 3 + k); lev[k] = pos[k] - an[k]; }
+      _Pragma("unroll") for (int k = 0; k < 3; k++) { ax[k] = S.ld(LDS_WJ + slot*6 + k); an[k] = S.ld(LDS_WJ + slot*6 + 3 + k); lev[k] = pos[k] - an[k]; }
       cross(ax, lev, v);
       P.Jn[j] = -dot3(n, v); P.J1[j] = -dot3(t1, v); P.J2[j] = -dot3(t2, v); P.Jt[j] = -dot3(n, ax);
     }
   }
   MCG_DEV static void pyr8(const PadRows& P, int r, const real* mu, real* j) {
-    const int k = r >> 1; const real m = ((r & 1) ? -1.0 : 1.0) * ((k == 0) ? mu[0] : (k == 1) ? mu[1] : mu[2]);
-    for (int d = 0; d < 8; d++) { const real jk = (k == 0) ? P.J1[d] : (k == 1) ? P.J2[d] : P.Jt[d]; j[d] = P.Jn[d] + m * jk; }
+    const int k = r >> 1; const real m = ((r & 1) ? -1.0 : 1.0) * (sel3(k, mu[0], mu[1], mu[2]));
+    _Pragma("unroll") for (int d = 0; d < 8; d++) { const real jk = sel3(k, P.J1[d], P.J2[d], P.Jt[d]); j[d] = P.Jn[d] + m * jk; }
   }
 
   // ------------------------------------------------------------------------------------- cube alone (no pad contact)
+  // Two passes over the contact list per Newton iteration: (A) active mask (from the warm start on the first
+  // iteration) + assembly of H and g; (B) consistency of the mask at the solution x, the constraint forces at x and the
+  // line-search data.  When the mask is consistent -- the usual case -- x is the minimiser and B's forces are final.
   MCG_DEV void solve_alone() {
+    derive(model());
     const real* mu = mu_tc; const real Bc = B_tc;
     real a[6];
-    for (int k = 0; k < 6; k++) a[k] = a_c[k];
-    auto row_aref = [&](const real* j, real kterm) { real v = 0; for (int d = 0; d < 6; d++) v += j[d] * Cb.vel[d]; return -Bc * v - kterm; };
-    for (int c = 0; __any(c < ncon); c++) {
-      CubeRows R; rows_cube(c, R);
-      const real kterm = S.ld(LDS_CON + c * CON_STRIDE + 14);
-      int mask = 0;
-      for (int r = 0; r < 6; r++) {
-        real j[6]; pyramid_row(R, r, mu, j);
-        real ja = 0; for (int d = 0; d < 6; d++) ja += j[d] * a[d];
-        mask |= (ja - row_aref(j, kterm) < 0) ? (1 << r) : 0;
-      }
-      if (c < ncon) S.st(LDS_ACT + c, (real)mask);
-    }
+    _Pragma("unroll") for (int k = 0; k < 6; k++) a[k] = a_c[k];
+    // a pyramid row is Jn + m Jk (m = +-mu_k), so every J.v is (Jn.v) + m (Jk.v): four dot products per contact, not six
+    auto dots = [](const CubeRows& R, const real* v, real* o) {
+      o[0] = o[1] = o[2] = o[3] = 0;
+      _Pragma("unroll") for (int d = 0; d < 6; d++) { o[0] += R.Jn[d] * v[d]; o[1] += R.J1[d] * v[d]; o[2] += R.J2[d] * v[d]; o[3] += R.Jt[d] * v[d]; }
+    };
+    auto rowval = [&](const real* o, int r) { const int k = r >> 1; const real m = ((r & 1) ? -1.0 : 1.0) * (sel3(k, mu[0], mu[1], mu[2]));
+                                               return o[0] + m * (sel3(k, o[1], o[2], o[3])); };
     bool conv = false;
+    real fcx[6];
     for (int it = 0; it < 50; it++) {
+      MCG_COUNT(CN_CUBE_IT);
       real H[21], g[6];
-      for (int k = 0; k < 21; k++) H[k] = 0;
-      for (int k = 0; k < 6; k++) { H[tri(k, k)] = Md[k]; g[k] = fs[k]; }
-      for (int c = 0; __any(c < ncon); c++) {
+      _Pragma("unroll") for (int k = 0; k < 21; k++) H[k] = 0;
+      _Pragma("unroll") for (int k = 0; k < 6; k++) { H[tri(k, k)] = Md[k]; g[k] = fs[k]; }
+      for (int c = 0; __any(c < ncon); c++) {                    // pass A: mask (first iteration) + assembly
         CubeRows R; rows_cube(c, R);
         const int b = LDS_CON + c * CON_STRIDE;
-        const real D = (c < ncon) ? S.ld(b + 13) : 0.0, kterm = S.ld(b + 14);
-        const int mask = (c < ncon) ? (int)S.ld(LDS_ACT + c) : 0;
-        for (int r = 0; r < 6; r++) {
+        const real D = sel((c < ncon), S.ld(b + 13), 0.0), kterm = S.ld(b + 14);
+        const int mask = (int)S.ld(LDS_ACT + c);
+        real dv[4], da[4]; dots(R, Cb.vel, dv); dots(R, a, da);
+        int m0 = 0;
+        _Pragma("unroll") for (int r = 0; r < 6; r++) {
+          const real ar = -Bc * rowval(dv, r) - kterm;
+          m0 |= (rowval(da, r) - ar < 0) ? (1 << r) : 0;
+          const int mk = sel((it == 0), m0, mask);
+          const real wgt = ((mk >> r) & 1) ? D : 0.0;
           real j[6]; pyramid_row(R, r, mu, j);
-          const real wgt = ((mask >> r) & 1) ? D : 0.0;
-          const real ar = row_aref(j, kterm);
-          for (int d = 0; d < 6; d++) { const real wj = wgt * j[d]; g[d] += wj * ar; for (int e = 0; e <= d; e++) H[tri(d, e)] += wj * j[e]; }
+          _Pragma("unroll") for (int d = 0; d < 6; d++) { const real wj = wgt * j[d]; g[d] += wj * ar; for (int e = 0; e <= d; e++) H[tri(d, e)] += wj * j[e]; }
         }
+        if (it == 0 && c < ncon) S.st(LDS_ACT + c, (real)m0);
       }
       real x[6];
-      for (int k = 0; k < 6; k++) x[k] = g[k];
+      _Pragma("unroll") for (int k = 0; k < 6; k++) x[k] = g[k];
       chol_factor<6>(H); chol_solve<6>(H, x);
-      real p[6]; for (int k = 0; k < 6; k++) p[k] = x[k] - a[k];
+      real p[6]; _Pragma("unroll") for (int k = 0; k < 6; k++) { p[k] = x[k] - a[k]; fcx[k] = 0; }
       bool same = true;
-      for (int c = 0; __any(c < ncon); c++) {
+      for (int c = 0; __any(c < ncon); c++) {                    // pass B: consistency at x, forces at x, line-search data
         CubeRows R; rows_cube(c, R);
-        const real kterm = S.ld(LDS_CON + c * CON_STRIDE + 14);
+        const int b = LDS_CON + c * CON_STRIDE;
+        const real D = sel((c < ncon), S.ld(b + 13), 0.0), kterm = S.ld(b + 14);
         const int mask = (int)S.ld(LDS_ACT + c);
-        for (int r = 0; r < 6; r++) {
-          real j[6]; pyramid_row(R, r, mu, j);
-          real ja = 0, jp = 0; for (int d = 0; d < 6; d++) { ja += j[d] * a[d]; jp += j[d] * p[d]; }
-          const real r0 = ja - row_aref(j, kterm);
+        real dv[4], da[4], dp[4]; dots(R, Cb.vel, dv); dots(R, a, da); dots(R, p, dp);
+        real fb[4] = {0, 0, 0, 0};              // force on the basis vectors: f_n = sum f_r, f_k = sum m_r f_r
+        _Pragma("unroll") for (int r = 0; r < 6; r++) {
+          const real r0 = rowval(da, r) - (-Bc * rowval(dv, r) - kterm), jp = rowval(dp, r);
           if (c < ncon) { S.st(LDS_ROW + (c * 6 + r) * 2, r0); S.st(LDS_ROW + (c * 6 + r) * 2 + 1, jp); }
-          const bool now = (r0 + jp) < 0;
-          same = same && (c >= ncon || now == (((mask >> r) & 1) != 0));
+          const real rx = r0 + jp;
+          same = same && (c >= ncon || (rx < 0) == (((mask >> r) & 1) != 0));
+          const real f = sel((rx < 0), -D * rx, 0.0);
+          const int k = r >> 1; const real m = ((r & 1) ? -1.0 : 1.0) * (sel3(k, mu[0], mu[1], mu[2]));
+          fb[0] += f; fb[1] += sel((k == 0), m * f, 0.0); fb[2] += sel((k == 1), m * f, 0.0); fb[3] += sel((k == 2), m * f, 0.0);
         }
+        _Pragma("unroll") for (int d = 0; d < 6; d++) fcx[d] += R.Jn[d] * fb[0] + R.J1[d] * fb[1] + R.J2[d] * fb[2] + R.Jt[d] * fb[3];
       }
       const bool finish = !conv && same;
-      for (int k = 0; k < 6; k++) a[k] = finish ? x[k] : a[k];
+      _Pragma("unroll") for (int k = 0; k < 6; k++) { a[k] = sel(finish, x[k], a[k]); fc[k] = sel(finish, fcx[k], fc[k]); }
       conv = conv || finish;
       if (!__any(!conv)) break;
       // Line search along p.  Any descent step that ends in a consistent active set yields the exact minimiser at the
       // final full step, so bisection of phi' on [0, 2] is enough (the oracle walks the breakpoints exactly).
       real lin0 = 0, quad = 0;
-      for (int k = 0; k < 6; k++) { const real as = fs[k] / Md[k]; lin0 += Md[k] * (a[k] - as) * p[k]; quad += Md[k] * p[k] * p[k]; }
+      _Pragma("unroll") for (int k = 0; k < 6; k++) { const real as = fs[k] / Md[k]; lin0 += Md[k] * (a[k] - as) * p[k]; quad += Md[k] * p[k] * p[k]; }
+      MCG_COUNT(CN_CUBE_LS);
       const real alpha = bisect(lin0, quad);
-      for (int k = 0; k < 6; k++) a[k] = conv ? a[k] : a[k] + alpha * p[k];
+      _Pragma("unroll") for (int k = 0; k < 6; k++) a[k] = sel(conv, a[k], a[k] + alpha * p[k]);
       remask(alpha, conv);
     }
-    for (int k = 0; k < 6; k++) { a_c[k] = a[k]; fc[k] = 0; }
-    for (int c = 0; __any(c < ncon); c++) {
-      CubeRows R; rows_cube(c, R);
-      const int b = LDS_CON + c * CON_STRIDE;
-      const real D = (c < ncon) ? S.ld(b + 13) : 0.0, kterm = S.ld(b + 14);
-      for (int r = 0; r < 6; r++) {
-        real j[6]; pyramid_row(R, r, mu, j);
-        real ja = 0; for (int d = 0; d < 6; d++) ja += j[d] * a[d];
-        const real jar = ja - row_aref(j, kterm);
-        const real f = (jar < 0) ? -D * jar : 0.0;
-        for (int d = 0; d < 6; d++) fc[d] += j[d] * f;
-      }
-    }
+    _Pragma("unroll") for (int k = 0; k < 6; k++) a_c[k] = a[k];
     solved = true;
   }
 
@@ -467,11 +481,11 @@ struct CubeSys {
   MCG_DEV real dphi_rows(real al) const {
     real s = 0;
     for (int c = 0; __any(c < ncon); c++) {
-      const real D = (c < ncon) ? S.ld(LDS_CON + c * CON_STRIDE + 13) : 0.0;
-      for (int r = 0; r < 6; r++) {
+      const real D = sel((c < ncon), S.ld(LDS_CON + c * CON_STRIDE + 13), 0.0);
+      _Pragma("unroll") for (int r = 0; r < 6; r++) {
         const real r0 = S.ld(LDS_ROW + (c * 6 + r) * 2), dr_ = S.ld(LDS_ROW + (c * 6 + r) * 2 + 1);
         const real rr = r0 + al * dr_;
-        s += (rr < 0) ? D * rr * dr_ : 0.0;
+        s += sel((rr < 0), D * rr * dr_, 0.0);
       }
     }
     return s;
@@ -482,16 +496,16 @@ struct CubeSys {
     for (int b = 0; b < 24; b++) {
       const real mid = 0.5 * (lo + hi);
       const bool neg = lin0 + mid * quad + dphi_rows(mid) < 0;
-      lo = neg ? mid : lo; hi = neg ? hi : mid;
+      lo = sel(neg, mid, lo); hi = sel(neg, hi, mid);
     }
     return beyond ? 2.0 : 0.5 * (lo + hi);
   }
   MCG_DEV void remask(real alpha, bool conv) const {
     for (int c = 0; __any(c < ncon); c++) {
       int mask = 0;
-      for (int r = 0; r < 6; r++) {
+      _Pragma("unroll") for (int r = 0; r < 6; r++) {
         const real r0 = S.ld(LDS_ROW + (c * 6 + r) * 2), dr_ = S.ld(LDS_ROW + (c * 6 + r) * 2 + 1);
-        mask |= (r0 + alpha * dr_ < 0) ? (1 << r) : 0;
+        mask |= sel((r0 + alpha * dr_ < 0), (1 << r), 0);
       }
       if (c < ncon && !conv) S.st(LDS_ACT + c, (real)mask);
     }
@@ -503,38 +517,39 @@ struct CubeSys {
   template <class BuildH>
   MCG_DEV void solve_coupled(BuildH& build_H, const real* g0, const real* Dl, const real* arefl, const real* sgl,
                              const real* qdr, real* ar, real* extra) {
+    derive(model());
     // dof slot of (side, j): arm j -> j; gear -> 6 + 2 side; finger -> 7 + 2 side.  Gather helpers with selects:
     auto gather8 = [](const real* v, int side, real* o) {
-      for (int j = 0; j < 6; j++) o[j] = v[j];
-      o[6] = side ? v[8] : v[6]; o[7] = side ? v[9] : v[7];
+      _Pragma("unroll") for (int j = 0; j < 6; j++) o[j] = v[j];
+      o[6] = sel(side, v[8], v[6]); o[7] = sel(side, v[9], v[7]);
     };
     auto contact_rows = [&](int c, CubeRows& RC, PadRows& RP, int& type, real& D, real& kterm) {
       const int b = LDS_CON + c * CON_STRIDE;
-      type = (c < ncon) ? (int)S.ld(b + 15) : 0;
-      D = (c < ncon) ? S.ld(b + 13) : 0.0; kterm = S.ld(b + 14);
+      type = sel((c < ncon), (int)S.ld(b + 15), 0);
+      D = sel((c < ncon), S.ld(b + 13), 0.0); kterm = S.ld(b + 14);
       rows_cube(c, RC);
       rows_pad(c, type == PAIR_PADL_CUBE ? 1 : 0, RP);
-      if (type == PAIR_TABLE_CUBE) for (int j = 0; j < 8; j++) { RP.Jn[j] = 0; RP.J1[j] = 0; RP.J2[j] = 0; RP.Jt[j] = 0; }
+      if (type == PAIR_TABLE_CUBE) _Pragma("unroll") for (int j = 0; j < 8; j++) { RP.Jn[j] = 0; RP.J1[j] = 0; RP.J2[j] = 0; RP.Jt[j] = 0; }
     };
     real ac[6];
-    for (int k = 0; k < 6; k++) ac[k] = a_c[k];
+    _Pragma("unroll") for (int k = 0; k < 6; k++) ac[k] = a_c[k];
     bool actl[10];
-    for (int j = 0; j < 10; j++) actl[j] = (sgl[j] != 0) && (sgl[j] * ar[j] - arefl[j] < 0);
+    _Pragma("unroll") for (int j = 0; j < 10; j++) actl[j] = (sgl[j] != 0) && (sgl[j] * ar[j] - arefl[j] < 0);
     bool any_lim = false;
-    for (int j = 0; j < 10; j++) any_lim = any_lim || (sgl[j] != 0);
+    _Pragma("unroll") for (int j = 0; j < 10; j++) any_lim = any_lim || (sgl[j] != 0);
     // initial contact masks
     for (int c = 0; __any(c < ncon); c++) {
       CubeRows RC; PadRows RP; int type; real D, kterm;
       contact_rows(c, RC, RP, type, D, kterm);
-      const int side = type == PAIR_PADL_CUBE ? 1 : 0;
-      const real* mu = type == PAIR_TABLE_CUBE ? mu_tc : mu_pc; const real Bc = type == PAIR_TABLE_CUBE ? B_tc : B_pc;
+      const int side = sel(type == PAIR_PADL_CUBE, 1, 0);
+      const bool tb_ = type == PAIR_TABLE_CUBE; const real mu[3] = {sel(tb_, mu_tc[0], mu_pc[0]), sel(tb_, mu_tc[1], mu_pc[1]), sel(tb_, mu_tc[2], mu_pc[2])}; const real Bc = sel(type == PAIR_TABLE_CUBE, B_tc, B_pc);
       real a8[8], v8[8]; gather8(ar, side, a8); gather8(qdr, side, v8);
       int mask = 0;
-      for (int r = 0; r < 6; r++) {
+      _Pragma("unroll") for (int r = 0; r < 6; r++) {
         real jc[6], jr[8]; pyramid_row(RC, r, mu, jc); pyr8(RP, r, mu, jr);
         real ja = 0, jv = 0;
-        for (int d = 0; d < 6; d++) { ja += jc[d] * ac[d]; jv += jc[d] * Cb.vel[d]; }
-        for (int d = 0; d < 8; d++) { ja += jr[d] * a8[d]; jv += jr[d] * v8[d]; }
+        _Pragma("unroll") for (int d = 0; d < 6; d++) { ja += jc[d] * ac[d]; jv += jc[d] * Cb.vel[d]; }
+        _Pragma("unroll") for (int d = 0; d < 8; d++) { ja += jr[d] * a8[d]; jv += jr[d] * v8[d]; }
         mask |= (ja - (-Bc * jv - kterm) < 0) ? (1 << r) : 0;
       }
       if (c < ncon) S.st(LDS_ACT + c, (real)mask);
@@ -550,33 +565,33 @@ struct CubeSys {
           if constexpr (PAT_H.nz[i][j]) G[tri(i, j)] = L[tri(i, j)]; else if constexpr (PAT_G.nz[i][j]) G[tri(i, j)] = 0.0; }); });
       }
       for (int i = 0; i < NB; i++) gr[i] = g0[i];
-      for (int j = 0; j < 10; j++) gr[j] += actl[j] ? sgl[j] * Dl[j] * arefl[j] : 0.0;
+      _Pragma("unroll") for (int j = 0; j < 10; j++) gr[j] += actl[j] ? sgl[j] * Dl[j] * arefl[j] : 0.0;
       real Hc[21], gc[6], Cm[10][6];                 // Cm rows: arm 0..5, gear R, finger R, gear L, finger L
-      for (int k = 0; k < 21; k++) Hc[k] = 0;
-      for (int k = 0; k < 6; k++) { Hc[tri(k, k)] = Md[k]; gc[k] = fs[k]; }
-      for (int i = 0; i < 10; i++) for (int d = 0; d < 6; d++) Cm[i][d] = 0;
+      _Pragma("unroll") for (int k = 0; k < 21; k++) Hc[k] = 0;
+      _Pragma("unroll") for (int k = 0; k < 6; k++) { Hc[tri(k, k)] = Md[k]; gc[k] = fs[k]; }
+      _Pragma("unroll") for (int i = 0; i < 10; i++) for (int d = 0; d < 6; d++) Cm[i][d] = 0;
       for (int c = 0; __any(c < ncon); c++) {
         CubeRows RC; PadRows RP; int type; real D, kterm;
         contact_rows(c, RC, RP, type, D, kterm);
-        const int side = type == PAIR_PADL_CUBE ? 1 : 0;
-        const real* mu = type == PAIR_TABLE_CUBE ? mu_tc : mu_pc; const real Bc = type == PAIR_TABLE_CUBE ? B_tc : B_pc;
-        const int mask = (c < ncon) ? (int)S.ld(LDS_ACT + c) : 0;
+        const int side = sel(type == PAIR_PADL_CUBE, 1, 0);
+        const bool tb_ = type == PAIR_TABLE_CUBE; const real mu[3] = {sel(tb_, mu_tc[0], mu_pc[0]), sel(tb_, mu_tc[1], mu_pc[1]), sel(tb_, mu_tc[2], mu_pc[2])}; const real Bc = sel(type == PAIR_TABLE_CUBE, B_tc, B_pc);
+        const int mask = sel((c < ncon), (int)S.ld(LDS_ACT + c), 0);
         real v8[8]; gather8(qdr, side, v8);
-        for (int r = 0; r < 6; r++) {
+        _Pragma("unroll") for (int r = 0; r < 6; r++) {
           real jc[6], jr[8]; pyramid_row(RC, r, mu, jc); pyr8(RP, r, mu, jr);
           real jv = 0;
-          for (int d = 0; d < 6; d++) jv += jc[d] * Cb.vel[d];
-          for (int d = 0; d < 8; d++) jv += jr[d] * v8[d];
+          _Pragma("unroll") for (int d = 0; d < 6; d++) jv += jc[d] * Cb.vel[d];
+          _Pragma("unroll") for (int d = 0; d < 8; d++) jv += jr[d] * v8[d];
           const real aref = -Bc * jv - kterm;
           const real w = ((mask >> r) & 1) ? D : 0.0;
-          const real wR = side ? 0.0 : w, wL = side ? w : 0.0;
-          for (int d = 0; d < 6; d++) { const real wj = w * jc[d]; gc[d] += wj * aref; for (int e = 0; e <= d; e++) Hc[tri(d, e)] += wj * jc[e]; }
+          const real wR = side ? 0.0 : w, wL = sel(side, w, 0.0);
+          _Pragma("unroll") for (int d = 0; d < 6; d++) { const real wj = w * jc[d]; gc[d] += wj * aref; for (int e = 0; e <= d; e++) Hc[tri(d, e)] += wj * jc[e]; }
           // robot-robot block: arm x arm, arm x (gear, finger) of the side, (gear, finger) block; coupling Cm; g_r
           static_for<6>([&](auto A_) { constexpr int a = A_;
             const real wj = w * jr[a];
             gr[a] += wj * aref;
             static_for<a + 1>([&](auto B_) { constexpr int b = B_; G[tri(a, b)] += wj * jr[b]; });
-            for (int d = 0; d < 6; d++) Cm[a][d] += wj * jc[d]; });
+            _Pragma("unroll") for (int d = 0; d < 6; d++) Cm[a][d] += wj * jc[d]; });
           {
             const real gR = wR * jr[6], fR = wR * jr[7], gL = wL * jr[6], fL = wL * jr[7];
             gr[6] += gR * aref; gr[7] += fR * aref; gr[8] += gL * aref; gr[9] += fL * aref;
@@ -584,104 +599,104 @@ struct CubeSys {
               G[tri(6, b)] += gR * jr[b]; G[tri(7, b)] += fR * jr[b]; G[tri(8, b)] += gL * jr[b]; G[tri(9, b)] += fL * jr[b]; });
             G[tri(6, 6)] += gR * jr[6]; G[tri(7, 6)] += fR * jr[6]; G[tri(7, 7)] += fR * jr[7];
             G[tri(8, 8)] += gL * jr[6]; G[tri(9, 8)] += fL * jr[6]; G[tri(9, 9)] += fL * jr[7];
-            for (int d = 0; d < 6; d++) { Cm[6][d] += gR * jc[d]; Cm[7][d] += fR * jc[d]; Cm[8][d] += gL * jc[d]; Cm[9][d] += fL * jc[d]; }
+            _Pragma("unroll") for (int d = 0; d < 6; d++) { Cm[6][d] += gR * jc[d]; Cm[7][d] += fR * jc[d]; Cm[8][d] += gL * jc[d]; Cm[9][d] += fL * jc[d]; }
           }
         }
       }
       // Schur complement on the cube block: S = G - Cm Hc^-1 Cm^T, rhs = gr - Cm Hc^-1 gc
       chol_factor<6>(Hc);
       real T[10][6], ygc[6];
-      for (int d = 0; d < 6; d++) ygc[d] = gc[d];
+      _Pragma("unroll") for (int d = 0; d < 6; d++) ygc[d] = gc[d];
       chol_solve<6>(Hc, ygc);
       static_for<10>([&](auto I) { constexpr int i = I;
-        for (int d = 0; d < 6; d++) T[i][d] = Cm[i][d];
+        _Pragma("unroll") for (int d = 0; d < 6; d++) T[i][d] = Cm[i][d];
         chol_solve<6>(Hc, T[i]);
-        real sdot = 0; for (int d = 0; d < 6; d++) sdot += Cm[i][d] * ygc[d];
+        real sdot = 0; _Pragma("unroll") for (int d = 0; d < 6; d++) sdot += Cm[i][d] * ygc[d];
         gr[i] -= sdot; });
       static_for<10>([&](auto I) { constexpr int i = I; static_for<i + 1>([&](auto Jj) { constexpr int j = Jj;
-        real sdot = 0; for (int d = 0; d < 6; d++) sdot += Cm[i][d] * T[j][d];
+        real sdot = 0; _Pragma("unroll") for (int d = 0; d < 6; d++) sdot += Cm[i][d] * T[j][d];
         G[tri(i, j)] -= sdot; }); });
       for (int i = 0; i < NB; i++) xr[i] = gr[i];
       ldl_factor<PAT_G>(G, dinv);
       ldl_solve<PAT_G>(G, dinv, xr);
-      for (int d = 0; d < 6; d++) { real sdot = 0; static_for<10>([&](auto I) { constexpr int i = I; sdot += T[i][d] * xr[i]; }); xc[d] = ygc[d] - sdot; }
+      _Pragma("unroll") for (int d = 0; d < 6; d++) { real sdot = 0; static_for<10>([&](auto I) { constexpr int i = I; sdot += T[i][d] * xr[i]; }); xc[d] = ygc[d] - sdot; }
       // consistency of the assumed active set at (xr, xc); r0 / dr of every contact row for the line search
       real pr[NB], pc[6];
       for (int i = 0; i < NB; i++) pr[i] = xr[i] - ar[i];
-      for (int d = 0; d < 6; d++) pc[d] = xc[d] - ac[d];
+      _Pragma("unroll") for (int d = 0; d < 6; d++) pc[d] = xc[d] - ac[d];
       bool same = true;
-      for (int j = 0; j < 10; j++) { const bool now = (sgl[j] != 0) && (sgl[j] * xr[j] - arefl[j] < 0); same = same && (now == actl[j]); }
+      _Pragma("unroll") for (int j = 0; j < 10; j++) { const bool now = (sgl[j] != 0) && (sgl[j] * xr[j] - arefl[j] < 0); same = same && (now == actl[j]); }
       for (int c = 0; __any(c < ncon); c++) {
         CubeRows RC; PadRows RP; int type; real D, kterm;
         contact_rows(c, RC, RP, type, D, kterm);
-        const int side = type == PAIR_PADL_CUBE ? 1 : 0;
-        const real* mu = type == PAIR_TABLE_CUBE ? mu_tc : mu_pc; const real Bc = type == PAIR_TABLE_CUBE ? B_tc : B_pc;
+        const int side = sel(type == PAIR_PADL_CUBE, 1, 0);
+        const bool tb_ = type == PAIR_TABLE_CUBE; const real mu[3] = {sel(tb_, mu_tc[0], mu_pc[0]), sel(tb_, mu_tc[1], mu_pc[1]), sel(tb_, mu_tc[2], mu_pc[2])}; const real Bc = sel(type == PAIR_TABLE_CUBE, B_tc, B_pc);
         const int mask = (int)S.ld(LDS_ACT + c);
         real a8[8], v8[8], p8[8]; gather8(ar, side, a8); gather8(qdr, side, v8); gather8(pr, side, p8);
-        for (int r = 0; r < 6; r++) {
+        _Pragma("unroll") for (int r = 0; r < 6; r++) {
           real jc[6], jr[8]; pyramid_row(RC, r, mu, jc); pyr8(RP, r, mu, jr);
           real ja = 0, jv = 0, jp = 0;
-          for (int d = 0; d < 6; d++) { ja += jc[d] * ac[d]; jv += jc[d] * Cb.vel[d]; jp += jc[d] * pc[d]; }
-          for (int d = 0; d < 8; d++) { ja += jr[d] * a8[d]; jv += jr[d] * v8[d]; jp += jr[d] * p8[d]; }
+          _Pragma("unroll") for (int d = 0; d < 6; d++) { ja += jc[d] * ac[d]; jv += jc[d] * Cb.vel[d]; jp += jc[d] * pc[d]; }
+          _Pragma("unroll") for (int d = 0; d < 8; d++) { ja += jr[d] * a8[d]; jv += jr[d] * v8[d]; jp += jr[d] * p8[d]; }
           const real r0 = ja - (-Bc * jv - kterm);
           if (c < ncon) { S.st(LDS_ROW + (c * 6 + r) * 2, r0); S.st(LDS_ROW + (c * 6 + r) * 2 + 1, jp); }
           same = same && (c >= ncon || ((r0 + jp) < 0) == (((mask >> r) & 1) != 0));
         }
       }
       const bool finish = !conv && same;
-      for (int i = 0; i < NB; i++) ar[i] = finish ? xr[i] : ar[i];
-      for (int d = 0; d < 6; d++) ac[d] = finish ? xc[d] : ac[d];
+      for (int i = 0; i < NB; i++) ar[i] = sel(finish, xr[i], ar[i]);
+      _Pragma("unroll") for (int d = 0; d < 6; d++) ac[d] = sel(finish, xc[d], ac[d]);
       conv = conv || finish;
       if (!__any(!conv)) break;
       // line search (bisection): smooth part = robot quadratic with H0 = M + equality rows (no limits), cube diag M
       real lin0 = 0, quad = 0;
       {
         real L[NB * (NB + 1) / 2];
-        bool none[10]; for (int j = 0; j < 10; j++) none[j] = false;
+        bool none[10]; _Pragma("unroll") for (int j = 0; j < 10; j++) none[j] = false;
         build_H(L, none);
         static_for<NB>([&](auto I) { constexpr int i = I; real ha = 0, hp = 0;
           static_for<NB>([&](auto Jj) { constexpr int j = Jj;
             if constexpr (PAT_H.nz[i > j ? i : j][i > j ? j : i]) { ha = fma(L[tri(i, j)], ar[j], ha); hp = fma(L[tri(i, j)], pr[j], hp); } });
           lin0 += (ha - g0[i]) * pr[i]; quad += hp * pr[i]; });
       }
-      for (int k = 0; k < 6; k++) { lin0 += (Md[k] * ac[k] - fs[k]) * pc[k]; quad += Md[k] * pc[k] * pc[k]; }
+      _Pragma("unroll") for (int k = 0; k < 6; k++) { lin0 += (Md[k] * ac[k] - fs[k]) * pc[k]; quad += Md[k] * pc[k] * pc[k]; }
       // limit rows join the piecewise part
       real l_r0[10], l_dr[10];
-      for (int j = 0; j < 10; j++) { l_r0[j] = sgl[j] * ar[j] - arefl[j]; l_dr[j] = sgl[j] * pr[j]; }
+      _Pragma("unroll") for (int j = 0; j < 10; j++) { l_r0[j] = sgl[j] * ar[j] - arefl[j]; l_dr[j] = sgl[j] * pr[j]; }
       auto dphi = [&](real al) {
         real sacc = lin0 + al * quad + dphi_rows(al);
-        for (int j = 0; j < 10; j++) { const real rr = l_r0[j] + al * l_dr[j]; sacc += (sgl[j] != 0 && rr < 0) ? Dl[j] * rr * l_dr[j] : 0.0; }
+        _Pragma("unroll") for (int j = 0; j < 10; j++) { const real rr = l_r0[j] + al * l_dr[j]; sacc += sel((sgl[j] != 0 && rr < 0), Dl[j] * rr * l_dr[j], 0.0); }
         return sacc;
       };
       real lo = 0, hi = 2;
       const bool beyond = dphi(hi) < 0;
-      for (int b = 0; b < 24; b++) { const real mid = 0.5 * (lo + hi); const bool neg = dphi(mid) < 0; lo = neg ? mid : lo; hi = neg ? hi : mid; }
-      const real alpha = beyond ? 2.0 : 0.5 * (lo + hi);
-      for (int i = 0; i < NB; i++) ar[i] = conv ? ar[i] : ar[i] + alpha * pr[i];
-      for (int d = 0; d < 6; d++) ac[d] = conv ? ac[d] : ac[d] + alpha * pc[d];
-      for (int j = 0; j < 10; j++) { const bool now = (sgl[j] != 0) && (sgl[j] * ar[j] - arefl[j] < 0); actl[j] = conv ? actl[j] : now; }
+      for (int b = 0; b < 24; b++) { const real mid = 0.5 * (lo + hi); const bool neg = dphi(mid) < 0; lo = sel(neg, mid, lo); hi = sel(neg, hi, mid); }
+      const real alpha = sel(beyond, 2.0, 0.5 * (lo + hi));
+      for (int i = 0; i < NB; i++) ar[i] = sel(conv, ar[i], ar[i] + alpha * pr[i]);
+      _Pragma("unroll") for (int d = 0; d < 6; d++) ac[d] = sel(conv, ac[d], ac[d] + alpha * pc[d]);
+      _Pragma("unroll") for (int j = 0; j < 10; j++) { const bool now = (sgl[j] != 0) && (sgl[j] * ar[j] - arefl[j] < 0); actl[j] = sel(conv, actl[j], now); }
       remask(alpha, conv);
     }
     (void)any_lim;
     // contact forces on both sides
-    for (int k = 0; k < 6; k++) { a_c[k] = ac[k]; fc[k] = 0; }
+    _Pragma("unroll") for (int k = 0; k < 6; k++) { a_c[k] = ac[k]; fc[k] = 0; }
     for (int c = 0; __any(c < ncon); c++) {
       CubeRows RC; PadRows RP; int type; real D, kterm;
       contact_rows(c, RC, RP, type, D, kterm);
-      const int side = type == PAIR_PADL_CUBE ? 1 : 0;
-      const real* mu = type == PAIR_TABLE_CUBE ? mu_tc : mu_pc; const real Bc = type == PAIR_TABLE_CUBE ? B_tc : B_pc;
+      const int side = sel(type == PAIR_PADL_CUBE, 1, 0);
+      const bool tb_ = type == PAIR_TABLE_CUBE; const real mu[3] = {sel(tb_, mu_tc[0], mu_pc[0]), sel(tb_, mu_tc[1], mu_pc[1]), sel(tb_, mu_tc[2], mu_pc[2])}; const real Bc = sel(type == PAIR_TABLE_CUBE, B_tc, B_pc);
       real a8[8], v8[8]; gather8(ar, side, a8); gather8(qdr, side, v8);
-      for (int r = 0; r < 6; r++) {
+      _Pragma("unroll") for (int r = 0; r < 6; r++) {
         real jc[6], jr[8]; pyramid_row(RC, r, mu, jc); pyr8(RP, r, mu, jr);
         real ja = 0, jv = 0;
-        for (int d = 0; d < 6; d++) { ja += jc[d] * ac[d]; jv += jc[d] * Cb.vel[d]; }
-        for (int d = 0; d < 8; d++) { ja += jr[d] * a8[d]; jv += jr[d] * v8[d]; }
+        _Pragma("unroll") for (int d = 0; d < 6; d++) { ja += jc[d] * ac[d]; jv += jc[d] * Cb.vel[d]; }
+        _Pragma("unroll") for (int d = 0; d < 8; d++) { ja += jr[d] * a8[d]; jv += jr[d] * v8[d]; }
         const real jar = ja - (-Bc * jv - kterm);
-        const real f = (jar < 0) ? -D * jar : 0.0;
-        for (int d = 0; d < 6; d++) fc[d] += jc[d] * f;
-        for (int d = 0; d < 6; d++) extra[d] += jr[d] * f;
-        extra[6] += side ? 0.0 : jr[6] * f; extra[7] += side ? 0.0 : jr[7] * f;
-        extra[8] += side ? jr[6] * f : 0.0; extra[9] += side ? jr[7] * f : 0.0;
+        const real f = sel((jar < 0), -D * jar, 0.0);
+        _Pragma("unroll") for (int d = 0; d < 6; d++) fc[d] += jc[d] * f;
+        _Pragma("unroll") for (int d = 0; d < 6; d++) extra[d] += jr[d] * f;
+        extra[6] += sel(side, 0.0, jr[6] * f); extra[7] += sel(side, 0.0, jr[7] * f);
+        extra[8] += sel(side, jr[6] * f, 0.0); extra[9] += sel(side, jr[7] * f, 0.0);
       }
     }
     solved = true;
@@ -690,27 +705,24 @@ struct CubeSys {
   // ------------------------------------------------------------------------------------------------- finish
   // implicit-damping Euler on the diagonal cube inertia, free-joint integration (mj_Euler / mj_advance)
   MCG_DEV void finish(real* qlag7) {
-    if (__any(!solved)) {
-      // lanes of a wave are either all coupled or all alone (the branch in robot_substep is wave-uniform)
-      solve_alone();
-    }
-    for (int k = 0; k < 3; k++) qlag7[k] = Cb.pos[k];
-    for (int k = 0; k < 4; k++) qlag7[3 + k] = Cb.quat[k];
-    for (int k = 0; k < 6; k++) {
+    derive(model());
+    _Pragma("unroll") for (int k = 0; k < 3; k++) qlag7[k] = Cb.pos[k];
+    _Pragma("unroll") for (int k = 0; k < 4; k++) qlag7[3 + k] = Cb.quat[k];
+    _Pragma("unroll") for (int k = 0; k < 6; k++) {
       const real acc = (fs[k] + fc[k]) / (Md[k] + h * damp[k]);
       Cb.vel[k] += h * acc;
       Cb.warm[k] = a_c[k];
     }
-    for (int k = 0; k < 3; k++) Cb.pos[k] += h * Cb.vel[k];
+    _Pragma("unroll") for (int k = 0; k < 3; k++) Cb.pos[k] += h * Cb.vel[k];
     real ax[3] = {Cb.vel[3], Cb.vel[4], Cb.vel[5]};
     const real nw = sqrt(dot3(ax, ax));
     const bool tiny = nw < MINVAL;
-    for (int k = 0; k < 3; k++) ax[k] = tiny ? (k == 0 ? 1.0 : 0.0) : ax[k] / nw;
+    _Pragma("unroll") for (int k = 0; k < 3; k++) ax[k] = sel(tiny, k == 0 ? 1.0 : 0.0, ax[k] / nw);
     const real ang = h * nw;
     real sh, ch; sincos(0.5 * ang, &sh, &ch);
     const real qr[4] = {ch, ax[0]*sh, ax[1]*sh, ax[2]*sh};
     real qn[4]; mulquat(Cb.quat, qr, qn);
-    for (int k = 0; k < 4; k++) Cb.quat[k] = qn[k];
+    _Pragma("unroll") for (int k = 0; k < 4; k++) Cb.quat[k] = qn[k];
   }
 };
 
@@ -718,9 +730,9 @@ struct CubeSys {
 MCG_DEV void mat2euler(const real* m, real* e) {
   const real cy = sqrt(m[8]*m[8] + m[5]*m[5]);
   const bool ok = cy > 4 * 2.220446049250313e-16;
-  e[2] = ok ? -atan2(m[1], m[0]) : -atan2(-m[3], m[4]);
+  e[2] = sel(ok, -atan2(m[1], m[0]), -atan2(-m[3], m[4]));
   e[1] = -atan2(-m[2], cy);
-  e[0] = ok ? -atan2(m[5], m[8]) : 0.0;
+  e[0] = sel(ok, -atan2(m[5], m[8]), 0.0);
 }
 
 }  // namespace mcg

@@ -16,6 +16,7 @@
 // reads are wave-uniform and become scalar loads.
 #pragma once
 
+#include <type_traits>
 #include <hip/hip_runtime.h>
 #include "mcg.h"
 
@@ -32,6 +33,27 @@ constexpr real MINVAL = 1e-15, MINIMP = 1e-4, MAXIMP = 0.9999;
 #define MCG_DEV __device__ __forceinline__
 
 // ------------------------------------------------------------------------------------------------ helpers
+// Opt-in stage clocks (-DMCG_STAGE_CLOCKS, development builds only; tools/stage_clocks.py): lane 0 of each wave
+// accumulates shader-clock deltas per pipeline stage in LDS and adds them to a device-global table at kernel end.
+enum { ST_LOAD = 0, ST_CTRL, ST_TRIG, ST_RNE, ST_ACT, ST_CRB, ST_ROWS, ST_G0, ST_NEWTON, ST_EULER, ST_COLLIDE, ST_CUBE,
+       ST_COUPLED, ST_CUBE_FIN, ST_POST, ST_N_BUILD, ST_N_FACTOR, ST_N_SOLVE, ST_N_CHECK, ST_E_RHS, ST_COUNT,
+       CN_SUBSTEP = 0, CN_NEWTON_IT, CN_LINESEARCH, CN_CUBE_IT, CN_CUBE_LS, CN_COUNT };
+#ifdef MCG_STAGE_CLOCKS
+__device__ unsigned long long g_stage_clocks[ST_COUNT + CN_COUNT];      // stage clocks, then event counts (per wave)
+__shared__ unsigned long long sh_stage[ST_COUNT + 1 + CN_COUNT];
+#define MCG_TICK_INIT() do { if (threadIdx.x == 0) { for (int k_ = 0; k_ < ST_COUNT + 1 + CN_COUNT; k_++) sh_stage[k_] = 0; sh_stage[ST_COUNT] = __builtin_readcyclecounter(); } } while (0)
+#define MCG_TICK(k) do { if (threadIdx.x == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); sh_stage[k] += t_ - sh_stage[ST_COUNT]; sh_stage[ST_COUNT] = t_; } } while (0)
+#define MCG_TICK_FLUSH() do { if (threadIdx.x == 0) { for (int k_ = 0; k_ < ST_COUNT; k_++) atomicAdd(&g_stage_clocks[k_], sh_stage[k_]); for (int k_ = 0; k_ < CN_COUNT; k_++) atomicAdd(&g_stage_clocks[ST_COUNT + k_], sh_stage[ST_COUNT + 1 + k_]); } } while (0)
+#define MCG_COUNT(k) do { if (threadIdx.x == 0) sh_stage[ST_COUNT + 1 + (k)] += 1; } while (0)
+// a stage's results must exist before its tick: arithmetic is otherwise sunk past the clock read towards its uses
+#define MCG_TICK_PIN(arr, n) do { for (int k_ = 0; k_ < (n); k_++) asm volatile("" : "+v"((arr)[k_])); } while (0)
+#else
+#define MCG_TICK_INIT() do {} while (0)
+#define MCG_TICK(k) do {} while (0)
+#define MCG_TICK_FLUSH() do {} while (0)
+#define MCG_COUNT(k) do {} while (0)
+#define MCG_TICK_PIN(arr, n) do {} while (0)
+#endif
 template <int... Is, class F>
 MCG_DEV void static_for_impl(std::integer_sequence<int, Is...>, F&& f) { (f(std::integral_constant<int, Is>{}), ...); }
 template <int N, class F>
@@ -90,7 +112,11 @@ MCG_DEV void sym_rot_up(real c, real s, real* I) {
 typedef const __attribute__((address_space(4))) mcg_model* ModelPtr;
 typedef const __attribute__((address_space(4))) real* CRealPtr;
 MCG_DEV ModelPtr as_model_ptr(const mcg_model* p) { return (ModelPtr)p; }
+#ifdef MCG_BAKED_MODEL      // timing experiment only: the default model folded into the code as literals
+MCG_DEV ModelPtr launder(ModelPtr p) { return p; }
+#else
 MCG_DEV ModelPtr launder(ModelPtr p) { asm volatile("" : "+s"(p)); return p; }
+#endif
 // Scheduling fence between body blocks / stages: without it the machine scheduler clusters the scalar loads of a
 // whole unrolled pass at the top of the (several-thousand-instruction) block and spills hundreds of SGPRs.
 #define MCG_FENCE() __builtin_amdgcn_sched_barrier(0)
@@ -281,9 +307,24 @@ struct Robot {
 // ds_read_b64 / ds_write_b64 with immediate offsets).  The joint-space inertia M is kept here between the stages
 // that consume it, so that only one 12x12 system occupies registers at a time.
 constexpr int LDS_SLOTS = NB * (NB + 1) / 2;
+// The lane's LDS column.  The pointer carries the LDS address space explicitly: passed through structs as a generic
+// pointer the accesses degrade to flat_load/flat_store with 64-bit address arithmetic instead of ds_read/ds_write
+// with immediate offsets.
+// Value selects.  Written `c ? a[k] : b[k]` inside a loop, the two arm loads are merged into ONE load through a selected
+// pointer before the loop is unrolled, which pins both arrays in scratch memory; evaluating both operands first (function
+// arguments) keeps the select on values and the arrays in registers.
+template <class A, class B> MCG_DEV std::common_type_t<A, B> sel(bool c, A a, B b) { return c ? a : b; }
+template <class T> MCG_DEV T sel3(int idx, T a, T b, T c) { return idx == 0 ? a : (idx == 1 ? b : c); }
+
+#ifdef MCG_GENERIC_LDS
+typedef real* LdsPtr;
+#else
+typedef __attribute__((address_space(3))) real* LdsPtr;
+#endif
 template <int STRIDE>
 struct LaneScratchT {
-  real* base;
+  LdsPtr base;
+  MCG_DEV explicit LaneScratchT(real* shared_column) : base((LdsPtr)shared_column) {}
   MCG_DEV real ld(int k) const { return base[k * STRIDE]; }
   MCG_DEV void st(int k, real v) const { base[k * STRIDE] = v; }
 };
@@ -296,6 +337,7 @@ struct NoCoupling { static constexpr bool enabled = false; };
 
 template <class LS, class CPL = NoCoupling>
 MCG_DEV void robot_substep(ModelPtr Pm, Robot& S, real* qlag6, const LS MS, CPL* CP = nullptr) {
+  MCG_COUNT(CN_SUBSTEP);
   const real h = launder(Pm)->timestep;
   real cs[NB], sn[NB];
   {
@@ -306,6 +348,7 @@ MCG_DEV void robot_substep(ModelPtr Pm, Robot& S, real* qlag6, const LS MS, CPL*
   static_for<NB>([&](auto I) { constexpr int i = I; pin(sn[i]); pin(cs[i]); });
   MCG_FENCE();
 
+  MCG_TICK(ST_TRIG);
   // ---- P6 recursive Newton-Euler, q'' = 0: bias = Coriolis + centrifugal + gravity        (mj_rne, flg_acc=0)
   real F[NB][3], Nn[NB][3];                 // net force / moment about the body origin, body frame
   real w[NB][3], al[NB][3], ac[NB][3];      // angular velocity, angular acceleration, linear acceleration of the origin
@@ -356,6 +399,7 @@ MCG_DEV void robot_substep(ModelPtr Pm, Robot& S, real* qlag6, const LS MS, CPL*
     MCG_FENCE();
   });
 
+  MCG_TICK(ST_RNE);
   // ---- P7 actuation                                                             (mj_fwdActuation)
   {
     ModelPtr Q = launder(Pm);
@@ -375,6 +419,7 @@ MCG_DEV void robot_substep(ModelPtr Pm, Robot& S, real* qlag6, const LS MS, CPL*
   static_for<NB>([&](auto I) { constexpr int i = I; pin(fs[i]); });
   MCG_FENCE();
 
+  MCG_TICK(ST_ACT);
   // ---- P3 composite rigid bodies -> joint-space inertia M (packed lower triangle, in LDS)      (mj_crb)
   {
     real cm[NB], cmc[NB][3], cI[NB][6];
@@ -449,6 +494,7 @@ MCG_DEV void robot_substep(ModelPtr Pm, Robot& S, real* qlag6, const LS MS, CPL*
     });
   }
 
+  MCG_TICK(ST_CRB);
   // ---- P5 constraint rows                                                   (mj_makeConstraint)
   // arm joint axes expressed in the link6 frame (for the tiny arm columns of the connect rows)
   real ax5[6][3];
@@ -534,6 +580,7 @@ MCG_DEV void robot_substep(ModelPtr Pm, Robot& S, real* qlag6, const LS MS, CPL*
   static_for<10>([&](auto I) { constexpr int j = I; pin(Dl[j]); pin(arefl[j]); pin(sgl[j]); });
   MCG_FENCE();
 
+  MCG_TICK(ST_ROWS);
   // ---- P8/P9: g0 = qfrc_smooth + J^T D aref over the equality rows                          (Newton system)
   real g0[NB];
   static_for<NB>([&](auto I) { constexpr int i = I; g0[i] = fs[i]; });
@@ -567,6 +614,8 @@ MCG_DEV void robot_substep(ModelPtr Pm, Robot& S, real* qlag6, const LS MS, CPL*
     static_for<10>([&](auto I) { constexpr int j = I; H[tri(j, j)] += act_[j] ? Dl[j] : 0.0; });
   };
 
+  MCG_TICK_PIN(g0, NB);
+  MCG_TICK(ST_G0);
   // ---- Newton iterations over the limit rows' active set, exact line search               (mj_fwdConstraint)
   // Wave-uniform loop; a lane that has converged keeps recomputing its own (unchanged) system and commits nothing.
   real a[NB];
@@ -578,17 +627,28 @@ MCG_DEV void robot_substep(ModelPtr Pm, Robot& S, real* qlag6, const LS MS, CPL*
   static_for<NB>([&](auto I) { constexpr int i = I; extra[i] = 0; });
   if constexpr (CPL::enabled) {
     if (__any(CP->any_pad)) {     // wave-uniform: every lane of the wave takes the coupled path (same minimiser)
+      MCG_TICK(ST_G0);
       CP->solve_coupled(build_H, g0, Dl, arefl, sgl, S.qd, a, extra);
       conv = true;
+      MCG_TICK(ST_COUPLED);
     }
   }
   for (int it = 0; it < 50 && __any(!conv); it++) {
+    MCG_COUNT(CN_NEWTON_IT);
     real L[NB * (NB + 1) / 2], dinv[NB], x[NB];
+    MCG_TICK_PIN(a, NB);
+  MCG_TICK(ST_NEWTON);
     build_H(L, act);
     static_for<NB>([&](auto I) { constexpr int i = I; x[i] = g0[i]; });
     static_for<10>([&](auto I) { constexpr int j = I; x[j] += act[j] ? sgl[j] * Dl[j] * arefl[j] : 0.0; });
+    MCG_TICK_PIN(L, 0); MCG_TICK_PIN(x, NB);
+    MCG_TICK(ST_N_BUILD);
     ldl_factor<PAT_H>(L, dinv);
+    MCG_TICK_PIN(dinv, NB);
+    MCG_TICK(ST_N_FACTOR);
     ldl_solve<PAT_H>(L, dinv, x);
+    MCG_TICK_PIN(x, NB);
+    MCG_TICK(ST_N_SOLVE);
     bool same = true;            // does the minimiser of this quadratic piece keep the assumed active set?
     static_for<10>([&](auto I) { constexpr int j = I;
       const bool now = (sgl[j] != 0) && (sgl[j] * x[j] - arefl[j] < 0);
@@ -596,9 +656,12 @@ MCG_DEV void robot_substep(ModelPtr Pm, Robot& S, real* qlag6, const LS MS, CPL*
     const bool finish = !conv && (!any_limit || same);
     static_for<NB>([&](auto I) { constexpr int i = I; a[i] = finish ? x[i] : a[i]; });
     conv = conv || finish;
+    MCG_TICK_PIN(a, NB);
+    MCG_TICK(ST_N_CHECK);
     if (!__any(!conv)) break;
     // some lane crossed a breakpoint: exact line search from a along p = x - a (committed where !conv only);
     // phi'(alpha) = (alpha - 1) p^T H p on the first piece, its slope changes by +-D p_j^2 at each breakpoint
+    MCG_COUNT(CN_LINESEARCH);
     real p[NB], Hp[NB];
     static_for<NB>([&](auto I) { constexpr int i = I; p[i] = x[i] - a[i]; });
     build_H(L, act);
@@ -639,6 +702,8 @@ MCG_DEV void robot_substep(ModelPtr Pm, Robot& S, real* qlag6, const LS MS, CPL*
       act[j] = conv ? act[j] : now; });
   }
 
+  MCG_TICK_PIN(a, NB);
+  MCG_TICK(ST_NEWTON);
   // ---- constraint forces -> qfrc_constraint; P10 implicit-damping Euler                  (mj_Euler, mj_advance)
   real rhs[NB];
   static_for<NB>([&](auto I) { constexpr int i = I; rhs[i] = fs[i]; });
@@ -658,6 +723,8 @@ MCG_DEV void robot_substep(ModelPtr Pm, Robot& S, real* qlag6, const LS MS, CPL*
   static_for<10>([&](auto I) { constexpr int j = I;
     const real jar = sgl[j] * a[j] - arefl[j];
     rhs[j] += (sgl[j] != 0 && jar < 0) ? sgl[j] * (-Dl[j] * jar) : 0.0; });
+  MCG_TICK_PIN(rhs, NB);
+  MCG_TICK(ST_E_RHS);
   {
     real Mh[NB * (NB + 1) / 2], dinv[NB];
     static_for<NB>([&](auto I) { constexpr int i = I;
@@ -670,6 +737,8 @@ MCG_DEV void robot_substep(ModelPtr Pm, Robot& S, real* qlag6, const LS MS, CPL*
     S.qd[i] = fma(h, rhs[i], S.qd[i]);
     S.q[i] = fma(h, S.qd[i], S.q[i]);
     S.warm[i] = a[i]; });
+  MCG_TICK_PIN(S.q, NB); MCG_TICK_PIN(S.qd, NB);
+  MCG_TICK(ST_EULER);
 }
 
 // ---------------------------------------------------------------------------------- world-frame arm kinematics

@@ -17,6 +17,9 @@
 #include "mcg_cube.hpp"
 #include "model_gen.h"
 
+#ifdef MCG_BAKED_MODEL
+#include "../../ab/baked_model.h"
+#endif
 using namespace mcg;
 
 namespace {
@@ -59,7 +62,7 @@ struct Env {            // one lane's working set
 };
 
 // ------------------------------------------------------------------------------------------------- sampling
-__device__ void rng_pair(const Cfg& C, int i, int32_t episode, uint32_t draw, uint32_t stream, real& u0, real& u1) {
+MCG_DEV void rng_pair(const Cfg& C, int i, int32_t episode, uint32_t draw, uint32_t stream, real& u0, real& u1) {
   unsigned long long gid = (unsigned long long)(C.env_id_offset + i);
   uint32_t r[4];
   philox4x32_10((uint32_t)gid, (uint32_t)episode, draw, stream ^ ((uint32_t)(gid >> 32) << 8),
@@ -69,7 +72,7 @@ __device__ void rng_pair(const Cfg& C, int i, int32_t episode, uint32_t draw, ui
 }
 
 // _sample_goal (mycobot.py:238-243) with generate_random_point_inside_rectangle (utils.py:14-21); uses draws d, d+1
-__device__ void sample_goal(const Cfg& C, int i, int32_t episode, uint32_t draw, real* g) {
+MCG_DEV void sample_goal(const Cfg& C, int i, int32_t episode, uint32_t draw, real* g) {
   real ux, uy, uc, uz;
   rng_pair(C, i, episode, draw, 0, ux, uy);
   rng_pair(C, i, episode, draw + 1, 0, uc, uz);
@@ -77,13 +80,13 @@ __device__ void sample_goal(const Cfg& C, int i, int32_t episode, uint32_t draw,
   g[0] = fma(0.12 - -0.12, ux, -0.12);
   g[1] = fma(0.06 - -0.06, uy, -0.06);
   const real air = fma(0.1 - 0.0, uz, C.height_offset);
-  g[2] = (C.target_in_the_air && uc < 0.5) ? air : C.height_offset;
+  g[2] = sel((C.target_in_the_air && uc < 0.5), air, C.height_offset);
 }
 
 // reset_model (mycobot.py:207-236), Reach: the object position stays the initial gripper xy.
 // Every lane of the wave computes a fresh episode; it is committed where `doit`.  The rejection loop is
 // wave-uniform (__any) with per-lane selects -- see the compiler hazard note in mcg_dynamics.hpp.
-__device__ void reset_env(const Cfg& C, int i, Env& E, bool doit) {
+MCG_DEV void reset_env(const Cfg& C, int i, Env& E, bool doit) {
   const real ox = C.igx[0], oy = C.igx[1];
   real goal[3] = {0, 0, 0};
   uint32_t draw = 0;
@@ -93,33 +96,33 @@ __device__ void reset_env(const Cfg& C, int i, Env& E, bool doit) {
     real g[3];
     sample_goal(C, i, E.episode, draw, g);
     const bool rej = sqrt((g[0] - ox) * (g[0] - ox) + (g[1] - oy) * (g[1] - oy)) < 0.1;
-    for (int k = 0; k < 3; k++) goal[k] = need ? g[k] : goal[k];
-    draw += need ? 2u : 0u;
+    for (int k = 0; k < 3; k++) goal[k] = sel(need, g[k], goal[k]);
+    draw += sel(need, 2u, 0u);
     need = need && rej && (tries < 1000);
     tries++;
   } while (__any(need));
-  for (int k = 0; k < NB; k++) { E.R.q[k] = doit ? C.init_qpos[k] : E.R.q[k]; E.R.qd[k] = doit ? C.init_qvel[k] : E.R.qd[k]; }
-  for (int k = 0; k < 7; k++) E.R.ctrl[k] = doit ? C.init_ctrl[k] : E.R.ctrl[k];
-  for (int k = 0; k < 6; k++) E.qlag6[k] = doit ? C.init_qpos[k] : E.qlag6[k];
-  for (int k = 0; k < 3; k++) E.goal[k] = doit ? goal[k] : E.goal[k];
-  E.elapsed = doit ? 0 : E.elapsed; E.epret = doit ? 0.0 : E.epret; E.eplen = doit ? 0 : E.eplen;
-  E.episode += doit ? 1 : 0;
+  for (int k = 0; k < NB; k++) { E.R.q[k] = sel(doit, C.init_qpos[k], E.R.q[k]); E.R.qd[k] = sel(doit, C.init_qvel[k], E.R.qd[k]); }
+  for (int k = 0; k < 7; k++) E.R.ctrl[k] = sel(doit, C.init_ctrl[k], E.R.ctrl[k]);
+  for (int k = 0; k < 6; k++) E.qlag6[k] = sel(doit, C.init_qpos[k], E.qlag6[k]);
+  for (int k = 0; k < 3; k++) E.goal[k] = sel(doit, goal[k], E.goal[k]);
+  E.elapsed = sel(doit, 0, E.elapsed); E.epret = sel(doit, 0.0, E.epret); E.eplen = sel(doit, 0, E.eplen);
+  E.episode += sel(doit, 1, 0);
 }
 
 // mj_checkPos / mj_checkVel [RECALL]: a non-finite or huge (> 1e10) coordinate makes MuJoCo call mj_resetData (qpos0,
 // zero velocity / ctrl / warm start) and carry on.  Here the check runs once per env-step instead of once per sub-step
 // (a diverged env is beyond parity anyway); it keeps one bad env from staying NaN until its next reset.
-__device__ bool bad_value(real x) { return !(x == x) || x > 1e10 || x < -1e10; }
-__device__ void guard_robot(Robot& R, real* qlag6) {
+MCG_DEV bool bad_value(real x) { return !(x == x) || x > 1e10 || x < -1e10; }
+MCG_DEV void guard_robot(Robot& R, real* qlag6) {
   bool bad = false;
   for (int k = 0; k < NB; k++) bad = bad || bad_value(R.q[k]) || bad_value(R.qd[k]) || bad_value(R.warm[k]);
-  for (int k = 0; k < NB; k++) { R.q[k] = bad ? 0.0 : R.q[k]; R.qd[k] = bad ? 0.0 : R.qd[k]; R.warm[k] = bad ? 0.0 : R.warm[k]; }
-  for (int k = 0; k < 7; k++) R.ctrl[k] = bad ? 0.0 : R.ctrl[k];
-  for (int k = 0; k < 6; k++) qlag6[k] = bad ? 0.0 : qlag6[k];
+  for (int k = 0; k < NB; k++) { R.q[k] = sel(bad, 0.0, R.q[k]); R.qd[k] = sel(bad, 0.0, R.qd[k]); R.warm[k] = sel(bad, 0.0, R.warm[k]); }
+  for (int k = 0; k < 7; k++) R.ctrl[k] = sel(bad, 0.0, R.ctrl[k]);
+  for (int k = 0; k < 6; k++) qlag6[k] = sel(bad, 0.0, qlag6[k]);
 }
 
 // _get_obs / generate_mujoco_observations for Reach (mycobot.py:245-283, 342-388): 10 numbers
-__device__ void observe_reach(const Cfg& C, ModelPtr P, const Env& E, real* obs, real* ag) {
+MCG_DEV void observe_reach(const Cfg& C, ModelPtr P, const Env& E, real* obs, real* ag) {
   EefPose X;
   eef_forward(P, E.qlag6, X, true);
   for (int k = 0; k < 3; k++) {
@@ -131,14 +134,14 @@ __device__ void observe_reach(const Cfg& C, ModelPtr P, const Env& E, real* obs,
   obs[8] = E.R.qd[6] * C.dt; obs[9] = E.R.qd[8] * C.dt;
 }
 
-__device__ void load_env(const View& V, int i, Env& E) {
+MCG_DEV void load_env(const View& V, int i, Env& E) {
   for (int k = 0; k < NB; k++) { E.R.q[k] = V.qpos(k, i); E.R.qd[k] = V.qvel(k, i); E.R.warm[k] = V.warm(k, i); }
   for (int k = 0; k < 7; k++) E.R.ctrl[k] = V.ctrl(k, i);
   for (int k = 0; k < 6; k++) E.qlag6[k] = V.qlag(k, i);
   for (int k = 0; k < 3; k++) E.goal[k] = V.goal(k, i);
   E.epret = V.epret(i); E.elapsed = V.elapsed(i); E.episode = V.episode(i); E.eplen = V.eplen(i);
 }
-__device__ void store_env(const View& V, int i, const Env& E) {
+MCG_DEV void store_env(const View& V, int i, const Env& E) {
   for (int k = 0; k < NB; k++) { V.qpos(k, i) = E.R.q[k]; V.qvel(k, i) = E.R.qd[k]; V.warm(k, i) = E.R.warm[k]; }
   for (int k = 0; k < 7; k++) V.ctrl(k, i) = E.R.ctrl[k];
   for (int k = 0; k < 6; k++) V.qlag(k, i) = E.qlag6[k];
@@ -146,7 +149,7 @@ __device__ void store_env(const View& V, int i, const Env& E) {
   V.epret(i) = E.epret; V.elapsed(i) = E.elapsed; V.episode(i) = E.episode; V.eplen(i) = E.eplen;
 }
 
-__device__ void write_obs(const mcg_step_out& O, int i, int D, const real* obs, const real* ag, const real* goal) {
+MCG_DEV void write_obs(const mcg_step_out& O, int i, int D, const real* obs, const real* ag, const real* goal) {
   if (O.obs) for (int k = 0; k < D; k++) O.obs[(size_t)i * D + k] = obs[k];
   if (O.achieved_goal) for (int k = 0; k < 3; k++) O.achieved_goal[(size_t)i * 3 + k] = ag[k];
   if (O.desired_goal) for (int k = 0; k < 3; k++) O.desired_goal[(size_t)i * 3 + k] = goal[k];
@@ -158,14 +161,23 @@ template <int CONTROLLER>
 __global__ __launch_bounds__(64) void step_reach_kernel(Cfg C, View V, const mcg_model* __restrict__ Pg,
                                                         const float* __restrict__ actions, mcg_step_out O) {
   __shared__ real lds[LDS_SLOTS][64];
-  const LaneScratch MS{&lds[0][threadIdx.x]};
+  const LaneScratch MS(&lds[0][threadIdx.x]);
+#ifdef MCG_BAKED_MODEL
+  const ModelPtr P = as_model_ptr(&kBakedModels[0]);
+#else
   const ModelPtr P = as_model_ptr(Pg);
+#endif
   const int i = blockIdx.x * 64 + threadIdx.x;
   if (i >= C.n) return;
+  MCG_TICK_INIT();
   Env E;
   load_env(V, i, E);
+  MCG_TICK(ST_LOAD);
   float act[7];
-  for (int k = 0; k < C.act_dim; k++) { float x = actions[(size_t)i * C.act_dim + k]; act[k] = fminf(fmaxf(x, -1.f), 1.f); }
+  _Pragma("unroll") for (int k = 0; k < 7; k++) {   // act_dim is 7 or 4 (fetch IK): static indices keep the array in registers
+    const float x = (k < 4 || C.act_dim == 7) ? actions[(size_t)i * C.act_dim + (k < C.act_dim ? k : 0)] : 0.f;
+    act[k] = fminf(fmaxf(x, -1.f), 1.f);
+  }
 
   if constexpr (CONTROLLER == MCG_CTRL_IK) {
     EefPose X;
@@ -178,17 +190,19 @@ __global__ __launch_bounds__(64) void step_reach_kernel(Cfg C, View V, const mcg
       for (int k = 0; k < 3; k++) e[k] = (real)(act[3 + k] * 0.5f);
       euler2quat(e, qr); mat2quat(X.mat, cur); mulquat(qr, cur, tquat);
     }
-    const real grip = C.grip_center + (real)act[C.act_dim - 1] * C.grip_range;
+    const real grip = C.grip_center + (real)(C.act_dim == 7 ? act[6] : act[3]) * C.grip_range;
     for (int c = 0; c < C.control_steps; c++) {
       if (c > 0) eef_forward(P, E.qlag6, X, true);
       real dq[6];
       ik_delta(X, tpos, tquat, dq);
       for (int k = 0; k < 6; k++) E.R.ctrl[k] += dq[k];
       E.R.ctrl[6] = grip;
+      MCG_TICK(ST_CTRL);
       for (int s = 0; s < C.frame_skip; s++) robot_substep(P, E.R, E.qlag6, MS);
     }
   } else {
     for (int k = 0; k < 7; k++) E.R.ctrl[k] = (real)act[k];
+    MCG_TICK(ST_CTRL);
     for (int s = 0; s < C.frame_skip; s++) robot_substep(P, E.R, E.qlag6, MS);
   }
 
@@ -202,7 +216,7 @@ __global__ __launch_bounds__(64) void step_reach_kernel(Cfg C, View V, const mcg
   real dx = ag[0] - E.goal[0], dy = ag[1] - E.goal[1], dz = ag[2] - E.goal[2];
   const real dist = sqrt(dx * dx + dy * dy + dz * dz);                       // goal_distance, utils.py:24-26
   const bool succ = dist < C.distance_threshold;                            // _is_success, mycobot.py:285-287
-  const real rew = C.reward_type == MCG_REWARD_SPARSE ? -(real)(float)(dist > C.distance_threshold) : -dist;
+  const real rew = sel(C.reward_type == MCG_REWARD_SPARSE, -(real)(float)(dist > C.distance_threshold), -dist);
   E.elapsed++; E.eplen++; E.epret += rew;
   const bool term = succ;                                                   // compute_terminated, :390-394
   const bool trunc = succ || (E.elapsed >= C.max_episode_steps);            // compute_truncated :396-400 | TimeLimit
@@ -222,22 +236,28 @@ __global__ __launch_bounds__(64) void step_reach_kernel(Cfg C, View V, const mcg
     reset_env(C, i, E, done);
     real obs2[10], ag2[3];
     observe_reach(C, P, E, obs2, ag2);
-    for (int k = 0; k < 10; k++) obs[k] = done ? obs2[k] : obs[k];
-    for (int k = 0; k < 3; k++) ag[k] = done ? ag2[k] : ag[k];
+    for (int k = 0; k < 10; k++) obs[k] = sel(done, obs2[k], obs[k]);
+    for (int k = 0; k < 3; k++) ag[k] = sel(done, ag2[k], ag[k]);
   }
   write_obs(O, i, 10, obs, ag, E.goal);
   store_env(V, i, E);
+  MCG_TICK(ST_POST);
+  MCG_TICK_FLUSH();
 }
 
 __global__ __launch_bounds__(64) void reset_reach_kernel(Cfg C, View V, const mcg_model* __restrict__ Pg,
                                                          const uint8_t* __restrict__ mask, int reseed, mcg_step_out O) {
   const int i = blockIdx.x * 64 + threadIdx.x;
   if (i >= C.n) return;
+#ifdef MCG_BAKED_MODEL
+  const ModelPtr P = as_model_ptr(&kBakedModels[0]);
+#else
   const ModelPtr P = as_model_ptr(Pg);
+#endif
   Env E;
   load_env(V, i, E);
   const bool doit = !mask || mask[i];
-  E.episode = (doit && reseed) ? 0 : E.episode;
+  E.episode = sel((doit && reseed), 0, E.episode);
   reset_env(C, i, E, doit);
   store_env(V, i, E);
   real obs[10], ag[3];
@@ -254,7 +274,7 @@ struct EnvP {
   bool touch;       // both finger pads touched the cube in the last forward pass (stage_rewards' grasp test)
 };
 
-__device__ void load_envp(const View& V, int i, EnvP& E) {
+MCG_DEV void load_envp(const View& V, int i, EnvP& E) {
   for (int k = 0; k < NB; k++) { E.R.q[k] = V.qpos(k, i); E.R.qd[k] = V.qvel(k, i); E.R.warm[k] = V.warm(k, i); }
   for (int k = 0; k < 7; k++) E.R.ctrl[k] = V.ctrl(k, i);
   for (int k = 0; k < 3; k++) E.Cb.pos[k] = V.qpos(12 + k, i);
@@ -265,7 +285,7 @@ __device__ void load_envp(const View& V, int i, EnvP& E) {
   E.dr[0] = V.dr(0, i); E.dr[1] = V.dr(1, i);
   E.epret = V.epret(i); E.elapsed = V.elapsed(i); E.episode = V.episode(i); E.eplen = V.eplen(i);
 }
-__device__ void store_envp(const View& V, int i, const EnvP& E) {
+MCG_DEV void store_envp(const View& V, int i, const EnvP& E) {
   for (int k = 0; k < NB; k++) { V.qpos(k, i) = E.R.q[k]; V.qvel(k, i) = E.R.qd[k]; V.warm(k, i) = E.R.warm[k]; }
   for (int k = 0; k < 7; k++) V.ctrl(k, i) = E.R.ctrl[k];
   for (int k = 0; k < 3; k++) V.qpos(12 + k, i) = E.Cb.pos[k];
@@ -279,7 +299,7 @@ __device__ void store_envp(const View& V, int i, const EnvP& E) {
 
 // reset_model with an object (mycobot.py:207-236): cube xy resampled until >= 0.1 from the initial gripper xy,
 // goal until >= 0.1 from the cube; per-reset domain randomisation (build-defined) on its own stream.
-__device__ void reset_envp(const Cfg& C, int i, EnvP& E, bool doit) {
+MCG_DEV void reset_envp(const Cfg& C, int i, EnvP& E, bool doit) {
   real drs[2] = {1.0, 1.0};
   if (C.dr_enable) {
     real um, uf; rng_pair(C, i, E.episode, 0, 1, um, uf);
@@ -292,8 +312,8 @@ __device__ void reset_envp(const Cfg& C, int i, EnvP& E, bool doit) {
   do {                                              // object position (mycobot.py:217-219)
     real g[3]; sample_goal(C, i, E.episode, draw, g);
     const bool rej = sqrt((g[0] - C.igx[0]) * (g[0] - C.igx[0]) + (g[1] - C.igx[1]) * (g[1] - C.igx[1])) < 0.1;
-    oxy[0] = need ? g[0] : oxy[0]; oxy[1] = need ? g[1] : oxy[1];
-    draw += need ? 2u : 0u;
+    oxy[0] = sel(need, g[0], oxy[0]); oxy[1] = sel(need, g[1], oxy[1]);
+    draw += sel(need, 2u, 0u);
     need = need && rej && (tries + 1 < 1000);
     tries++;
   } while (__any(need));
@@ -301,30 +321,30 @@ __device__ void reset_envp(const Cfg& C, int i, EnvP& E, bool doit) {
   do {                                              // goal (mycobot.py:231-233)
     real g[3]; sample_goal(C, i, E.episode, draw, g);
     const bool rej = sqrt((g[0] - oxy[0]) * (g[0] - oxy[0]) + (g[1] - oxy[1]) * (g[1] - oxy[1])) < 0.1;
-    for (int k = 0; k < 3; k++) goal[k] = need ? g[k] : goal[k];
-    draw += need ? 2u : 0u;
+    for (int k = 0; k < 3; k++) goal[k] = sel(need, g[k], goal[k]);
+    draw += sel(need, 2u, 0u);
     need = need && rej && (tries < 1000);
     tries++;
   } while (__any(need));
-  for (int k = 0; k < NB; k++) { E.R.q[k] = doit ? C.init_qpos[k] : E.R.q[k]; E.R.qd[k] = doit ? C.init_qvel[k] : E.R.qd[k]; }
-  for (int k = 0; k < 7; k++) E.R.ctrl[k] = doit ? C.init_ctrl[k] : E.R.ctrl[k];
-  for (int k = 0; k < 6; k++) { E.qlag6[k] = doit ? C.init_qpos[k] : E.qlag6[k]; E.Cb.vel[k] = doit ? C.init_qvel[12 + k] : E.Cb.vel[k]; }
-  E.Cb.pos[0] = doit ? oxy[0] : E.Cb.pos[0]; E.Cb.pos[1] = doit ? oxy[1] : E.Cb.pos[1]; E.Cb.pos[2] = doit ? C.init_qpos[14] : E.Cb.pos[2];
+  for (int k = 0; k < NB; k++) { E.R.q[k] = sel(doit, C.init_qpos[k], E.R.q[k]); E.R.qd[k] = sel(doit, C.init_qvel[k], E.R.qd[k]); }
+  for (int k = 0; k < 7; k++) E.R.ctrl[k] = sel(doit, C.init_ctrl[k], E.R.ctrl[k]);
+  for (int k = 0; k < 6; k++) { E.qlag6[k] = sel(doit, C.init_qpos[k], E.qlag6[k]); E.Cb.vel[k] = sel(doit, C.init_qvel[12 + k], E.Cb.vel[k]); }
+  E.Cb.pos[0] = sel(doit, oxy[0], E.Cb.pos[0]); E.Cb.pos[1] = sel(doit, oxy[1], E.Cb.pos[1]); E.Cb.pos[2] = sel(doit, C.init_qpos[14], E.Cb.pos[2]);
   {   // mj_forward normalises the stored quaternion
     real q[4] = {C.init_qpos[15], C.init_qpos[16], C.init_qpos[17], C.init_qpos[18]};
     const real nq = sqrt(q[0]*q[0] + q[1]*q[1] + q[2]*q[2] + q[3]*q[3]);
-    for (int k = 0; k < 4; k++) E.Cb.quat[k] = doit ? q[k] / nq : E.Cb.quat[k];
+    for (int k = 0; k < 4; k++) E.Cb.quat[k] = sel(doit, q[k] / nq, E.Cb.quat[k]);
   }
-  for (int k = 0; k < 3; k++) E.qlag7[k] = doit ? E.Cb.pos[k] : E.qlag7[k];
-  for (int k = 0; k < 4; k++) E.qlag7[3 + k] = doit ? E.Cb.quat[k] : E.qlag7[3 + k];
-  for (int k = 0; k < 3; k++) E.goal[k] = doit ? goal[k] : E.goal[k];
-  E.dr[0] = doit ? drs[0] : E.dr[0]; E.dr[1] = doit ? drs[1] : E.dr[1];
-  E.elapsed = doit ? 0 : E.elapsed; E.epret = doit ? 0.0 : E.epret; E.eplen = doit ? 0 : E.eplen;
-  E.episode += doit ? 1 : 0;
+  for (int k = 0; k < 3; k++) E.qlag7[k] = sel(doit, E.Cb.pos[k], E.qlag7[k]);
+  for (int k = 0; k < 4; k++) E.qlag7[3 + k] = sel(doit, E.Cb.quat[k], E.qlag7[3 + k]);
+  for (int k = 0; k < 3; k++) E.goal[k] = sel(doit, goal[k], E.goal[k]);
+  E.dr[0] = sel(doit, drs[0], E.dr[0]); E.dr[1] = sel(doit, drs[1], E.dr[1]);
+  E.elapsed = sel(doit, 0, E.elapsed); E.epret = sel(doit, 0.0, E.epret); E.eplen = sel(doit, 0, E.eplen);
+  E.episode += sel(doit, 1, 0);
 }
 
 // _get_obs with an object (mycobot.py:245-283, 342-388): 25 numbers, Appendix A.6 order
-__device__ void observe_pnp(const Cfg& C, ModelPtr P, const EnvP& E, real* obs, real* ag) {
+MCG_DEV void observe_pnp(const Cfg& C, ModelPtr P, const EnvP& E, real* obs, real* ag) {
   EefPose X;
   eef_forward(P, E.qlag6, X, true);
   real gv[3];
@@ -345,26 +365,44 @@ __device__ void observe_pnp(const Cfg& C, ModelPtr P, const EnvP& E, real* obs, 
 
 // one mj_step of robot + cube: collision first (needs both), then the robot's pipeline with the coupling hook, then the cube
 MCG_DEV void pnp_substep(ModelPtr P, EnvP& E, const PnpScratch MS) {
-  CubeSys<PnpScratch> CS{MS, E.Cb, E.dr};
+  CubeSys<PnpScratch> CS(MS, E.Cb, E.dr);
   CS.prepare(P, E.R.q);
+  MCG_TICK(ST_COLLIDE);
   E.touch = CS.touch[0] && CS.touch[1];        // contacts of this forward pass: what check_contact sees after the step
-  robot_substep(P, E.R, E.qlag6, MS, &CS);
-  CS.finish(E.qlag7);
+  const bool coupled = __any(CS.any_pad);      // wave-uniform
+  if (!coupled) {                              // the cost separates: finish the cube first, so that none of its
+    CS.solve_alone();                          // working set is live (and spilled) across the robot's pipeline
+    MCG_TICK(ST_CUBE);
+    CS.finish(E.qlag7);
+    MCG_TICK(ST_CUBE_FIN);
+  }
+  robot_substep(P, E.R, E.qlag6, MS, &CS);     // its hook runs the coupled solve when a pad touches the cube
+  if (coupled) { CS.finish(E.qlag7); MCG_TICK(ST_CUBE_FIN); }
+  E.Cb = CS.Cb;
 }
 
 template <int CONTROLLER>
 __global__ __launch_bounds__(PNP_LANES) void step_pnp_kernel(Cfg C, View V, const mcg_model* __restrict__ Pg,
                                                              const float* __restrict__ actions, mcg_step_out O) {
   __shared__ real lds[PNP_SLOTS][PNP_LANES];
-  const PnpScratch MS{&lds[0][threadIdx.x]};
+  const PnpScratch MS(&lds[0][threadIdx.x]);
+#ifdef MCG_BAKED_MODEL
+  const ModelPtr P = as_model_ptr(&kBakedModels[0]);
+#else
   const ModelPtr P = as_model_ptr(Pg);
+#endif
   const int i = blockIdx.x * PNP_LANES + threadIdx.x;
   if (i >= C.n) return;
+  MCG_TICK_INIT();
   EnvP E;
   load_envp(V, i, E);
+  MCG_TICK(ST_LOAD);
   E.touch = false;
   float act[7];
-  for (int k = 0; k < C.act_dim; k++) { float x = actions[(size_t)i * C.act_dim + k]; act[k] = fminf(fmaxf(x, -1.f), 1.f); }
+  _Pragma("unroll") for (int k = 0; k < 7; k++) {   // act_dim is 7 or 4 (fetch IK): static indices keep the array in registers
+    const float x = (k < 4 || C.act_dim == 7) ? actions[(size_t)i * C.act_dim + (k < C.act_dim ? k : 0)] : 0.f;
+    act[k] = fminf(fmaxf(x, -1.f), 1.f);
+  }
   if constexpr (CONTROLLER == MCG_CTRL_IK) {
     EefPose X;
     eef_forward(P, E.qlag6, X, true);
@@ -376,17 +414,19 @@ __global__ __launch_bounds__(PNP_LANES) void step_pnp_kernel(Cfg C, View V, cons
       for (int k = 0; k < 3; k++) e[k] = (real)(act[3 + k] * 0.5f);
       euler2quat(e, qr); mat2quat(X.mat, cur); mulquat(qr, cur, tquat);
     }
-    const real grip = C.grip_center + (real)act[C.act_dim - 1] * C.grip_range;
+    const real grip = C.grip_center + (real)(C.act_dim == 7 ? act[6] : act[3]) * C.grip_range;
     for (int c = 0; c < C.control_steps; c++) {
       if (c > 0) eef_forward(P, E.qlag6, X, true);
       real dq[6];
       ik_delta(X, tpos, tquat, dq);
       for (int k = 0; k < 6; k++) E.R.ctrl[k] += dq[k];
       E.R.ctrl[6] = grip;
+      MCG_TICK(ST_CTRL);
       for (int s = 0; s < C.frame_skip; s++) pnp_substep(P, E, MS);
     }
   } else {
     for (int k = 0; k < 7; k++) E.R.ctrl[k] = (real)act[k];
+    MCG_TICK(ST_CTRL);
     for (int s = 0; s < C.frame_skip; s++) pnp_substep(P, E, MS);
   }
   guard_robot(E.R, E.qlag6);
@@ -395,15 +435,16 @@ __global__ __launch_bounds__(PNP_LANES) void step_pnp_kernel(Cfg C, View V, cons
     for (int k = 0; k < 3; k++) bad = bad || bad_value(E.Cb.pos[k]);
     for (int k = 0; k < 4; k++) bad = bad || bad_value(E.Cb.quat[k]);
     for (int k = 0; k < 6; k++) bad = bad || bad_value(E.Cb.vel[k]) || bad_value(E.Cb.warm[k]);
-    for (int k = 0; k < 3; k++) { E.Cb.pos[k] = bad ? C.qpos0_cube[k] : E.Cb.pos[k]; E.qlag7[k] = bad ? C.qpos0_cube[k] : E.qlag7[k]; }
-    for (int k = 0; k < 4; k++) { E.Cb.quat[k] = bad ? C.qpos0_cube[3 + k] : E.Cb.quat[k]; E.qlag7[3 + k] = bad ? C.qpos0_cube[3 + k] : E.qlag7[3 + k]; }
-    for (int k = 0; k < 6; k++) { E.Cb.vel[k] = bad ? 0.0 : E.Cb.vel[k]; E.Cb.warm[k] = bad ? 0.0 : E.Cb.warm[k]; }
+    for (int k = 0; k < 3; k++) { E.Cb.pos[k] = sel(bad, C.qpos0_cube[k], E.Cb.pos[k]); E.qlag7[k] = sel(bad, C.qpos0_cube[k], E.qlag7[k]); }
+    for (int k = 0; k < 4; k++) { E.Cb.quat[k] = sel(bad, C.qpos0_cube[3 + k], E.Cb.quat[k]); E.qlag7[3 + k] = sel(bad, C.qpos0_cube[3 + k], E.qlag7[3 + k]); }
+    for (int k = 0; k < 6; k++) { E.Cb.vel[k] = sel(bad, 0.0, E.Cb.vel[k]); E.Cb.warm[k] = sel(bad, 0.0, E.Cb.warm[k]); }
   }
   if (C.block_gripper) {       // _step_callback: finger joints := 0, mj_forward (poses, contacts of the new state)
     E.R.q[7] = 0; E.R.q[9] = 0;
     for (int k = 0; k < 6; k++) E.qlag6[k] = E.R.q[k];
-    CubeSys<PnpScratch> CS{MS, E.Cb, E.dr};
+    CubeSys<PnpScratch> CS(MS, E.Cb, E.dr);
     CS.prepare(P, E.R.q);
+    E.Cb = CS.Cb;
     for (int k = 0; k < 3; k++) E.qlag7[k] = E.Cb.pos[k];
     for (int k = 0; k < 4; k++) E.qlag7[3 + k] = E.Cb.quat[k];
     E.touch = CS.touch[0] && CS.touch[1];
@@ -413,7 +454,7 @@ __global__ __launch_bounds__(PNP_LANES) void step_pnp_kernel(Cfg C, View V, cons
   real dx = ag[0] - E.goal[0], dy = ag[1] - E.goal[1], dz = ag[2] - E.goal[2];
   const real dist = sqrt(dx * dx + dy * dy + dz * dz);
   const bool succ = dist < C.distance_threshold;
-  real rew = C.reward_type == MCG_REWARD_SPARSE ? -(real)(float)(dist > C.distance_threshold) : -dist;
+  real rew = sel(C.reward_type == MCG_REWARD_SPARSE, -(real)(float)(dist > C.distance_threshold), -dist);
   if (C.reward_type == MCG_REWARD_SHAPING) {
     // stage_rewards (mycobot.py:402-448): reach 0.2 (1 - tanh d), grasp 0.5 iff both pads touch the cube, lift
     // 0.5 + 0.4 (1 - tanh d_obj,target); the target0 site stays at its MJCF position unless rendering (Appendix D-8)
@@ -442,22 +483,28 @@ __global__ __launch_bounds__(PNP_LANES) void step_pnp_kernel(Cfg C, View V, cons
     reset_envp(C, i, E, done);
     real obs2[25], ag2[3];
     observe_pnp(C, P, E, obs2, ag2);
-    for (int k = 0; k < 25; k++) obs[k] = done ? obs2[k] : obs[k];
-    for (int k = 0; k < 3; k++) ag[k] = done ? ag2[k] : ag[k];
+    for (int k = 0; k < 25; k++) obs[k] = sel(done, obs2[k], obs[k]);
+    for (int k = 0; k < 3; k++) ag[k] = sel(done, ag2[k], ag[k]);
   }
   write_obs(O, i, 25, obs, ag, E.goal);
   store_envp(V, i, E);
+  MCG_TICK(ST_POST);
+  MCG_TICK_FLUSH();
 }
 
 __global__ __launch_bounds__(PNP_LANES) void reset_pnp_kernel(Cfg C, View V, const mcg_model* __restrict__ Pg,
                                                               const uint8_t* __restrict__ mask, int reseed, mcg_step_out O) {
   const int i = blockIdx.x * PNP_LANES + threadIdx.x;
   if (i >= C.n) return;
+#ifdef MCG_BAKED_MODEL
+  const ModelPtr P = as_model_ptr(&kBakedModels[0]);
+#else
   const ModelPtr P = as_model_ptr(Pg);
+#endif
   EnvP E;
   load_envp(V, i, E);
   const bool doit = !mask || mask[i];
-  E.episode = (doit && reseed) ? 0 : E.episode;
+  E.episode = sel((doit && reseed), 0, E.episode);
   reset_envp(C, i, E, doit);
   store_envp(V, i, E);
   real obs[25], ag[3];
@@ -472,7 +519,7 @@ __global__ void reward_kernel(const double* __restrict__ ag, const double* __res
   if (i >= n) return;
   double dx = ag[3 * i] - dg[3 * i], dy = ag[3 * i + 1] - dg[3 * i + 1], dz = ag[3 * i + 2] - dg[3 * i + 2];
   double d = sqrt(dx * dx + dy * dy + dz * dz);
-  out[i] = reward_type == MCG_REWARD_SPARSE ? -(double)(float)(d > thr) : -d;
+  out[i] = sel(reward_type == MCG_REWARD_SPARSE, -(double)(float)(d > thr), -d);
 }
 
 // state <-> caller arrays (both SoA [dim, N])
@@ -580,6 +627,15 @@ void mcg_destroy(mcg_env* e) {
   delete e;
 }
 
+#ifdef MCG_STAGE_CLOCKS
+// development builds only (tools/stage_clocks.py): read and optionally clear the per-stage shader-clock totals
+extern "C" int mcg_debug_stage_clocks(unsigned long long* out, int clear) {
+  if (hipDeviceSynchronize() != hipSuccess) return MCG_ERR_HIP;
+  if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(mcg::g_stage_clocks), sizeof(unsigned long long) * (mcg::ST_COUNT + mcg::CN_COUNT)) != hipSuccess) return MCG_ERR_HIP;
+  if (clear) { unsigned long long z[mcg::ST_COUNT + mcg::CN_COUNT] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(mcg::g_stage_clocks), z, sizeof(z)) != hipSuccess) return MCG_ERR_HIP; }
+  return MCG_OK;
+}
+#endif
 int mcg_obs_dim(const mcg_env* e) { return e ? e->cfg.obs_dim : -1; }
 int mcg_action_dim(const mcg_env* e) { return e ? e->cfg.act_dim : -1; }
 int mcg_nq(const mcg_env* e) { return e ? e->cfg.nq : -1; }
