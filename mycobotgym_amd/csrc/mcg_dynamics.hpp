@@ -325,6 +325,7 @@ template <int STRIDE>
 struct LaneScratchT {
   LdsPtr base;
   MCG_DEV explicit LaneScratchT(real* shared_column) : base((LdsPtr)shared_column) {}
+  MCG_DEV explicit LaneScratchT(LdsPtr column) : base(column) {}
   MCG_DEV real ld(int k) const { return base[k * STRIDE]; }
   MCG_DEV void st(int k, real v) const { base[k * STRIDE] = v; }
 };

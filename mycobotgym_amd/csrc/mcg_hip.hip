@@ -363,22 +363,46 @@ MCG_DEV void observe_pnp(const Cfg& C, ModelPtr P, const EnvP& E, real* obs, rea
   obs[23] = E.R.qd[6] * C.dt; obs[24] = E.R.qd[8] * C.dt;
 }
 
-// one mj_step of robot + cube: collision first (needs both), then the robot's pipeline with the coupling hook, then the cube
+// The coupled sub-step (a finger pad touches the cube: robot and cube accelerations are solved together) is rare and
+// large.  It lives out of line, on a COPY of the env, so that its code and its live ranges stay out of the hot path's
+// register allocation (inlined, it doubled the cost of the uncoupled robot pipeline) and the env struct itself never
+// has its address taken.  It redoes the collision pass: contacts in LDS are the same, the derived numbers are cheap.
+struct CoupledIO { EnvP E; };
+__device__ __noinline__ void pnp_substep_coupled(unsigned long long model_bits, CoupledIO* io, unsigned lds_column) {
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)model_bits), hi = __builtin_amdgcn_readfirstlane((unsigned)(model_bits >> 32));
+  const ModelPtr P = (ModelPtr)(((unsigned long long)hi << 32) | lo);
+  const PnpScratch MS((LdsPtr)(uintptr_t)lds_column);
+  EnvP E = io->E;
+  CubeSys<PnpScratch> CS(MS, E.Cb, E.dr);
+  CS.prepare(P, E.R.q);
+  MCG_TICK(ST_COLLIDE);
+  robot_substep(P, E.R, E.qlag6, MS, &CS);     // its hook runs the coupled solve when a pad touches the cube
+  CS.finish(E.qlag7);
+  MCG_TICK(ST_CUBE_FIN);
+  E.Cb = CS.Cb;
+  io->E = E;
+}
+
+// one mj_step of robot + cube: collision first (needs both); without pad contact the cost separates into the cube alone
+// and the robot alone (the same instantiation as Reach)
 MCG_DEV void pnp_substep(ModelPtr P, EnvP& E, const PnpScratch MS) {
   CubeSys<PnpScratch> CS(MS, E.Cb, E.dr);
   CS.prepare(P, E.R.q);
   MCG_TICK(ST_COLLIDE);
   E.touch = CS.touch[0] && CS.touch[1];        // contacts of this forward pass: what check_contact sees after the step
-  const bool coupled = __any(CS.any_pad);      // wave-uniform
-  if (!coupled) {                              // the cost separates: finish the cube first, so that none of its
-    CS.solve_alone();                          // working set is live (and spilled) across the robot's pipeline
-    MCG_TICK(ST_CUBE);
-    CS.finish(E.qlag7);
-    MCG_TICK(ST_CUBE_FIN);
+  if (__any(CS.any_pad)) {                     // wave-uniform
+    CoupledIO io; io.E = E;
+    pnp_substep_coupled((unsigned long long)P, &io, (unsigned)(uintptr_t)MS.base);
+    const bool touch = E.touch;
+    E = io.E; E.touch = touch;
+    return;
   }
-  robot_substep(P, E.R, E.qlag6, MS, &CS);     // its hook runs the coupled solve when a pad touches the cube
-  if (coupled) { CS.finish(E.qlag7); MCG_TICK(ST_CUBE_FIN); }
+  CS.solve_alone();                            // finish the cube first: none of its working set is live (and spilled)
+  MCG_TICK(ST_CUBE);                           // across the robot's pipeline
+  CS.finish(E.qlag7);
+  MCG_TICK(ST_CUBE_FIN);
   E.Cb = CS.Cb;
+  robot_substep(P, E.R, E.qlag6, MS);
 }
 
 template <int CONTROLLER>
