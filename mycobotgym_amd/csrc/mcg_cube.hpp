@@ -115,12 +115,13 @@ MCG_DEV void box_box(ContactList<LS>& CL, bool live, const real* pa, const real*
     const real expr = pA[i2]*Cm[i1][j] - pA[i1]*Cm[i2][j];
     const real len = sqrt(fmax(0.0, 1 - Cm[i][j]*Cm[i][j]));
     const bool valid = len >= 1e-9;
-    const real s = (fabs(expr) - (ha[i1]*Q[i2][j] + ha[i2]*Q[i1][j] + hb[j1]*Q[i][j2] + hb[j2]*Q[i][j1])) / (valid ? len : 1.0);
+    const real il = 1.0 / (valid ? len : 1.0);
+    const real s = (fabs(expr) - (ha[i1]*Q[i2][j] + ha[i2]*Q[i1][j] + hb[j1]*Q[i][j2] + hb[j2]*Q[i][j1])) * il;
     sep = sep || (valid && s > 0);
     const bool tk = valid && (s * 1.05 > best);
     real L[3]; cross(A[i], B[j], L);
     best = sel(tk, s, best); code = sel(tk, 6 + 3*i + j, code); invert = sel(tk, (expr < 0), invert);
-    _Pragma("unroll") for (int k = 0; k < 3; k++) nrm[k] = sel(tk, L[k] / len, nrm[k]);
+    _Pragma("unroll") for (int k = 0; k < 3; k++) nrm[k] = sel(tk, L[k] * il, nrm[k]);
   }
   const bool hit = !sep && code >= 0;
   if (!__any(hit)) return;
@@ -175,6 +176,10 @@ MCG_DEV void box_box(ContactList<LS>& CL, bool live, const real* pa, const real*
   S.st(LDS_POLY + 6, cx + k1 - k3); S.st(LDS_POLY + 7, cy + k2 - k4);
   int np = sel(face, 4, 0);
   int src = LDS_POLY, dst = LDS_POLY + 32;
+  // Sutherland-Hodgman keeps a polygon that lies strictly inside all four limits as it is (same vertices, same order):
+  // the usual case of the cube on the table needs no clipping pass at all.
+  const bool inside = fabs(cx) + fabs(k1) + fabs(k3) < rect[0] && fabs(cy) + fabs(k2) + fabs(k4) < rect[1];
+  if (__any(face && !inside))
   _Pragma("unroll") for (int dir = 0; dir < 2; dir++) for (int sgn = -1; sgn <= 1; sgn += 2) {
     int nq = 0;
     const real lim = sel(dir == 0, rect[0], rect[1]);
