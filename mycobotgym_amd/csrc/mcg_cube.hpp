@@ -408,16 +408,15 @@ struct CubeSys {
   // line-search data.  When the mask is consistent -- the usual case -- x is the minimiser and B's forces are final.
   MCG_DEV void solve_alone() {
     derive(model());
-    const real* mu = mu_tc; const real Bc = B_tc;
+    const real Bc = B_tc; const real mu[3] = {mu_tc[0], mu_tc[1], mu_tc[2]};
     real a[6];
     _Pragma("unroll") for (int k = 0; k < 6; k++) a[k] = a_c[k];
-    // a pyramid row is Jn + m Jk (m = +-mu_k), so every J.v is (Jn.v) + m (Jk.v): four dot products per contact, not six
+    // The six pyramid rows of a contact are Jn +- mu_k J_k over the basis B = [Jn J1 J2 Jt]: every J.v is a combination
+    // of four dot products, and sum_r w_r j_r j_r^T = B W B^T with a 4x4 arrow matrix W (7 numbers), sum_r w_r a_r j_r = B t.
     auto dots = [](const CubeRows& R, const real* v, real* o) {
       o[0] = o[1] = o[2] = o[3] = 0;
-      _Pragma("unroll") for (int d = 0; d < 6; d++) { o[0] += R.Jn[d] * v[d]; o[1] += R.J1[d] * v[d]; o[2] += R.J2[d] * v[d]; o[3] += R.Jt[d] * v[d]; }
+      _Pragma("unroll") for (int d = 0; d < 6; d++) { o[0] = fma(R.Jn[d], v[d], o[0]); o[1] = fma(R.J1[d], v[d], o[1]); o[2] = fma(R.J2[d], v[d], o[2]); o[3] = fma(R.Jt[d], v[d], o[3]); }
     };
-    auto rowval = [&](const real* o, int r) { const int k = r >> 1; const real m = ((r & 1) ? -1.0 : 1.0) * (sel3(k, mu[0], mu[1], mu[2]));
-                                               return o[0] + m * (sel3(k, o[1], o[2], o[3])); };
     bool conv = false;
     real fcx[6];
     for (int it = 0; it < 50; it++) {
@@ -431,20 +430,35 @@ struct CubeSys {
         const real D = sel((c < ncon), S.ld(b + 13), 0.0), kterm = S.ld(b + 14);
         const int mask = (int)S.ld(LDS_ACT + c);
         real dv[4], da[4]; dots(R, Cb.vel, dv); dots(R, a, da);
+        real W00 = 0, t0 = 0, W0[3], Wd[3], t[3];
         int m0 = 0;
-        _Pragma("unroll") for (int r = 0; r < 6; r++) {
-          const real ar = -Bc * rowval(dv, r) - kterm;
-          m0 |= (rowval(da, r) - ar < 0) ? (1 << r) : 0;
-          const int mk = sel((it == 0), m0, mask);
-          const real wgt = ((mk >> r) & 1) ? D : 0.0;
-          real j[6]; pyramid_row(R, r, mu, j);
-          _Pragma("unroll") for (int d = 0; d < 6; d++) { const real wj = wgt * j[d]; g[d] += wj * ar; for (int e = 0; e <= d; e++) H[tri(d, e)] += wj * j[e]; }
+        static_for<3>([&](auto Kk) {
+          constexpr int k = Kk;
+          const real m = mu[k];
+          const real arp = -Bc * fma(m, dv[1 + k], dv[0]) - kterm, arm = -Bc * fma(-m, dv[1 + k], dv[0]) - kterm;
+          const bool bp0 = fma(m, da[1 + k], da[0]) - arp < 0, bm0 = fma(-m, da[1 + k], da[0]) - arm < 0;
+          m0 |= (bp0 ? (1 << (2 * k)) : 0) | (bm0 ? (1 << (2 * k + 1)) : 0);
+          const bool bp = sel(it == 0, bp0, ((mask >> (2 * k)) & 1) != 0), bm = sel(it == 0, bm0, ((mask >> (2 * k + 1)) & 1) != 0);
+          const real wp = sel(bp, D, 0.0), wm = sel(bm, D, 0.0);
+          W00 += wp + wm; t0 = fma(wp, arp, fma(wm, arm, t0));
+          W0[k] = m * (wp - wm); Wd[k] = m * m * (wp + wm); t[k] = m * (wp * arp - wm * arm);
+        });
+        real U0[6], U1[6], U2[6], U3[6];
+        _Pragma("unroll") for (int d = 0; d < 6; d++) {
+          g[d] += R.Jn[d] * t0 + R.J1[d] * t[0] + R.J2[d] * t[1] + R.Jt[d] * t[2];
+          U0[d] = W00 * R.Jn[d] + W0[0] * R.J1[d] + W0[1] * R.J2[d] + W0[2] * R.Jt[d];
+          U1[d] = W0[0] * R.Jn[d] + Wd[0] * R.J1[d];
+          U2[d] = W0[1] * R.Jn[d] + Wd[1] * R.J2[d];
+          U3[d] = W0[2] * R.Jn[d] + Wd[2] * R.Jt[d];
         }
+        static_for<6>([&](auto Dd) { constexpr int d = Dd;
+          static_for<d + 1>([&](auto Ee) { constexpr int e = Ee;
+            H[tri(d, e)] += R.Jn[d] * U0[e] + R.J1[d] * U1[e] + R.J2[d] * U2[e] + R.Jt[d] * U3[e]; }); });
         if (it == 0 && c < ncon) S.st(LDS_ACT + c, (real)m0);
       }
-      real x[6];
+      real x[6], dinv[6];
       _Pragma("unroll") for (int k = 0; k < 6; k++) x[k] = g[k];
-      chol_factor<6>(H); chol_solve<6>(H, x);
+      spd_factor<6>(H, dinv); spd_solve<6>(H, dinv, x);
       real p[6]; _Pragma("unroll") for (int k = 0; k < 6; k++) { p[k] = x[k] - a[k]; fcx[k] = 0; }
       bool same = true;
       for (int c = 0; __any(c < ncon); c++) {                    // pass B: consistency at x, forces at x, line-search data
@@ -454,15 +468,19 @@ struct CubeSys {
         const int mask = (int)S.ld(LDS_ACT + c);
         real dv[4], da[4], dp[4]; dots(R, Cb.vel, dv); dots(R, a, da); dots(R, p, dp);
         real fb[4] = {0, 0, 0, 0};              // force on the basis vectors: f_n = sum f_r, f_k = sum m_r f_r
-        _Pragma("unroll") for (int r = 0; r < 6; r++) {
-          const real r0 = rowval(da, r) - (-Bc * rowval(dv, r) - kterm), jp = rowval(dp, r);
-          if (c < ncon) { S.st(LDS_ROW + (c * 6 + r) * 2, r0); S.st(LDS_ROW + (c * 6 + r) * 2 + 1, jp); }
-          const real rx = r0 + jp;
-          same = same && (c >= ncon || (rx < 0) == (((mask >> r) & 1) != 0));
-          const real f = sel((rx < 0), -D * rx, 0.0);
-          const int k = r >> 1; const real m = ((r & 1) ? -1.0 : 1.0) * (sel3(k, mu[0], mu[1], mu[2]));
-          fb[0] += f; fb[1] += sel((k == 0), m * f, 0.0); fb[2] += sel((k == 1), m * f, 0.0); fb[3] += sel((k == 2), m * f, 0.0);
-        }
+        static_for<3>([&](auto Kk) {
+          constexpr int k = Kk;
+          static_for<2>([&](auto Od) {
+            constexpr int odd = Od; constexpr int r = 2 * k + odd;
+            const real m = odd ? -mu[k] : mu[k];
+            const real r0 = fma(m, da[1 + k], da[0]) - (-Bc * fma(m, dv[1 + k], dv[0]) - kterm), jp = fma(m, dp[1 + k], dp[0]);
+            if (c < ncon) { S.st(LDS_ROW + (c * 6 + r) * 2, r0); S.st(LDS_ROW + (c * 6 + r) * 2 + 1, jp); }
+            const real rx = r0 + jp;
+            same = same && (c >= ncon || (rx < 0) == (((mask >> r) & 1) != 0));
+            const real f = sel((rx < 0), -D * rx, 0.0);
+            fb[0] += f; fb[1 + k] = fma(m, f, fb[1 + k]);
+          });
+        });
         _Pragma("unroll") for (int d = 0; d < 6; d++) fcx[d] += R.Jn[d] * fb[0] + R.J1[d] * fb[1] + R.J2[d] * fb[2] + R.Jt[d] * fb[3];
       }
       const bool finish = !conv && same;

@@ -268,6 +268,32 @@ MCG_DEV void ldl_solve(const real* A, const real* dinv, real* x) {
   });
 }
 
+// dense SPD solve by L D L^T with reciprocals (no square roots, no IEEE divisions): the cube's 6x6 Newton systems
+template <int N>
+MCG_DEV void spd_factor(real* A, real* dinv) {           // packed lower triangle, in place: L below the diagonal, D on it
+  static_for<N>([&](auto J) {
+    constexpr int j = J;
+    real v[N];
+    real d = A[tri(j, j)];
+    static_for<j>([&](auto Kk) { constexpr int k = Kk; v[k] = A[tri(j, k)] * A[tri(k, k)]; d = fma(-A[tri(j, k)], v[k], d); });
+    A[tri(j, j)] = d;
+    dinv[j] = rcp_nr(d);
+    static_for<N - 1 - j>([&](auto Ii) {
+      constexpr int i = j + 1 + Ii;
+      real sacc = A[tri(i, j)];
+      static_for<j>([&](auto Kk) { constexpr int k = Kk; sacc = fma(-A[tri(i, k)], v[k], sacc); });
+      A[tri(i, j)] = sacc * dinv[j];
+    });
+  });
+}
+template <int N>
+MCG_DEV void spd_solve(const real* A, const real* dinv, real* x) {
+  static_for<N>([&](auto I) { constexpr int i = I; static_for<i>([&](auto Kk) { constexpr int k = Kk; x[i] = fma(-A[tri(i, k)], x[k], x[i]); }); });
+  static_for<N>([&](auto I) { constexpr int i = I; x[i] *= dinv[i]; });
+  static_for<N>([&](auto I) { constexpr int i = N - 1 - I;
+    static_for<N - 1 - i>([&](auto Kk) { constexpr int k = i + 1 + Kk; x[i] = fma(-A[tri(k, i)], x[k], x[i]); }); });
+}
+
 // dense SPD solve for the 6x6 IK system (once per control step; not on the sub-step path)
 template <int N>
 MCG_DEV void chol_factor(real* A) {
