@@ -28,7 +28,8 @@ N_ENVS_PER_GPU = 8192
 # B = 2*S + A + O, S = 46 doubles + counters, A = 28 B, O = 135 B  ->  939 B.   (DESIGN.md "Bytes per env-step")
 BYTES_PER_ENV_STEP = 939
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
-FP64_VECTOR_PEAK_TFLOPS = 78.6  # [RECALL, AMD datasheet]; the guide lists no FP64 vector figure
+FP64_VECTOR_PEAK_TFLOPS = 78.6  # 256 CUs x 4 SIMDs x 16 lanes/clk x 2 FLOP x 2.4 GHz; the 16 lanes/clk (4.02 clk per wave64
+                                # v_fma_f64 per SIMD) is measured: tools/microbench/issue_rate.hip, profiles/r01/issue_rate.log
 
 
 def cpu_baseline(controller: str, budget_envs: int, steps: int):
@@ -157,12 +158,14 @@ def main():
         algo_bytes = BYTES_PER_ENV_STEP * n
         achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
         traffic = None; src = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
+        pmc = os.path.join(ROOT, "profiles", "pmc_latest.json" if args.task == "reach" else "pmc_latest_pnp.json")
+        flops = None
         if os.path.exists(pmc):
             with open(pmc) as f:
                 pj = json.load(f)
             if pj.get("controller") == args.controller and pj.get("n_envs") == n and pj.get("task", "reach") == args.task:
-                traffic = pj.get("hbm_bytes_per_launch"); src = "profiles/pmc_latest.json: " + pj.get("note", "")
+                traffic = pj.get("hbm_bytes_per_launch"); src = "profiles/" + os.path.basename(pmc) + ": " + pj.get("note", "")
+                flops = pj.get("f64_flops_per_launch")
         out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                            "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": src,
                            "kernel": "step_reach_kernel", "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": algo_bytes,
@@ -173,6 +176,13 @@ def main():
             out["roofline"]["algorithmic_bytes_per_launch"] = 1363 * n       # PickAndPlace B = 1363 B per env-step
             out["roofline"]["achieved"] = 1363 * n / (kernel_ms * 1e-3) / 1e9
             out["roofline"]["frac"] = out["roofline"]["achieved"] / HBM_PEAK_GBPS
+        if flops:
+            # secondary (the binding) roofline, SURVEY 8(d): FP64 vector FLOP/s.  Peak = 1024 SIMDs x 16 lanes/clk x 2 x 2.4 GHz;
+            # the 16 lanes/clk is measured here (tools/microbench/issue_rate.hip: 4.02 clk per wave64 v_fma_f64 per SIMD).
+            tf = flops / (kernel_ms * 1e-3) / 1e12
+            out["roofline"]["valu_f64"] = {"achieved": tf, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                           "frac": tf / FP64_VECTOR_PEAK_TFLOPS, "flops_per_launch": flops,
+                                           "source": "SQ_INSTS_VALU_{FMA,ADD,MUL,TRANS}_F64 x active lanes, " + (src or "")}
         if not args.no_secondary and world == 1 and args.task == "reach":
             other = "IK" if args.controller == "joint" else "joint"
             dt2, k2, _ = run(other, max(K // 5, 20), max(W // 5, 5))

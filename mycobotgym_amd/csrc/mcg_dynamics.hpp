@@ -112,11 +112,7 @@ MCG_DEV void sym_rot_up(real c, real s, real* I) {
 typedef const __attribute__((address_space(4))) mcg_model* ModelPtr;
 typedef const __attribute__((address_space(4))) real* CRealPtr;
 MCG_DEV ModelPtr as_model_ptr(const mcg_model* p) { return (ModelPtr)p; }
-#ifdef MCG_BAKED_MODEL      // timing experiment only: the default model folded into the code as literals
-MCG_DEV ModelPtr launder(ModelPtr p) { return p; }
-#else
 MCG_DEV ModelPtr launder(ModelPtr p) { asm volatile("" : "+s"(p)); return p; }
-#endif
 // Scheduling fence between body blocks / stages: without it the machine scheduler clusters the scalar loads of a
 // whole unrolled pass at the top of the (several-thousand-instruction) block and spills hundreds of SGPRs.
 #define MCG_FENCE() __builtin_amdgcn_sched_barrier(0)

@@ -17,9 +17,6 @@
 #include "mcg_cube.hpp"
 #include "model_gen.h"
 
-#ifdef MCG_BAKED_MODEL
-#include "../../ab/baked_model.h"
-#endif
 using namespace mcg;
 
 namespace {
@@ -162,11 +159,7 @@ __global__ __launch_bounds__(64) void step_reach_kernel(Cfg C, View V, const mcg
                                                         const float* __restrict__ actions, mcg_step_out O) {
   __shared__ real lds[LDS_SLOTS][64];
   const LaneScratch MS(&lds[0][threadIdx.x]);
-#ifdef MCG_BAKED_MODEL
-  const ModelPtr P = as_model_ptr(&kBakedModels[0]);
-#else
   const ModelPtr P = as_model_ptr(Pg);
-#endif
   const int i = blockIdx.x * 64 + threadIdx.x;
   if (i >= C.n) return;
   MCG_TICK_INIT();
@@ -249,11 +242,7 @@ __global__ __launch_bounds__(64) void reset_reach_kernel(Cfg C, View V, const mc
                                                          const uint8_t* __restrict__ mask, int reseed, mcg_step_out O) {
   const int i = blockIdx.x * 64 + threadIdx.x;
   if (i >= C.n) return;
-#ifdef MCG_BAKED_MODEL
-  const ModelPtr P = as_model_ptr(&kBakedModels[0]);
-#else
   const ModelPtr P = as_model_ptr(Pg);
-#endif
   Env E;
   load_env(V, i, E);
   const bool doit = !mask || mask[i];
@@ -410,11 +399,7 @@ __global__ __launch_bounds__(PNP_LANES) void step_pnp_kernel(Cfg C, View V, cons
                                                              const float* __restrict__ actions, mcg_step_out O) {
   __shared__ real lds[PNP_SLOTS][PNP_LANES];
   const PnpScratch MS(&lds[0][threadIdx.x]);
-#ifdef MCG_BAKED_MODEL
-  const ModelPtr P = as_model_ptr(&kBakedModels[0]);
-#else
   const ModelPtr P = as_model_ptr(Pg);
-#endif
   const int i = blockIdx.x * PNP_LANES + threadIdx.x;
   if (i >= C.n) return;
   MCG_TICK_INIT();
@@ -520,11 +505,7 @@ __global__ __launch_bounds__(PNP_LANES) void reset_pnp_kernel(Cfg C, View V, con
                                                               const uint8_t* __restrict__ mask, int reseed, mcg_step_out O) {
   const int i = blockIdx.x * PNP_LANES + threadIdx.x;
   if (i >= C.n) return;
-#ifdef MCG_BAKED_MODEL
-  const ModelPtr P = as_model_ptr(&kBakedModels[0]);
-#else
   const ModelPtr P = as_model_ptr(Pg);
-#endif
   EnvP E;
   load_envp(V, i, E);
   const bool doit = !mask || mask[i];

@@ -7,9 +7,12 @@ FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE under-reports wide coal
 import csv, glob, json, os, statistics, sys
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+task = sys.argv[2] if len(sys.argv) > 2 else "reach"        # reach | pnp
 root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 src = os.path.join(root, "gpurun_out", tag)
-KERNEL = "step_reach_kernel<0>"
+KERNEL = "step_reach_kernel<0>" if task == "reach" else "step_pnp_kernel<0>"
+LANES = 64 if task == "reach" else 32           # active lanes per wave (PNP_LANES)
+ALGO_BYTES = 939 if task == "reach" else 1363
 
 
 def rows(pattern):
@@ -31,7 +34,7 @@ stats = [r for r in rows("stats/*/*_kernel_stats.csv")]
 summary["kernel_stats_top"] = [{"name": r["Name"][:90], "calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]),
                                 "pct": float(r["Percentage"])} for r in stats[:4]]
 counters = {}
-for d in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2"):
+for d in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2", "pmc_flops"):
     for r in rows(f"{d}/*/*_counter_collection.csv"):
         if KERNEL in r["Kernel_Name"]:
             counters.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
@@ -42,15 +45,25 @@ if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
     rd_raw, wr = c["FETCH_SIZE"] * 1024, c["WRITE_SIZE"] * 1024
     summary["hbm"] = {"read_bytes_raw": rd_raw, "read_bytes_x2_corrected": 2 * rd_raw, "write_bytes": wr,
                       "bytes_per_launch_corrected": 2 * rd_raw + wr, "bytes_per_env_step_corrected": (2 * rd_raw + wr) / n_envs,
-                      "algorithmic_bytes_per_env_step": 939}
+                      "algorithmic_bytes_per_env_step": ALGO_BYTES}
 if "SQ_INSTS_VALU" in c and "SQ_WAVES" in c:
     waves = c["SQ_WAVES"]
     summary["per_wave"] = {k: c[k] / waves for k in c if k.startswith("SQ_") and k != "SQ_WAVES"}
     summary["per_wave"]["waves"] = waves
+flops = None
+if "SQ_INSTS_VALU_FMA_F64" in c:
+    # wave-level instruction counts -> FLOPs over the active lanes (FMA = 2); transcendental F64 (rcp, sqrt) counted as 1
+    flops = LANES * (2 * c["SQ_INSTS_VALU_FMA_F64"] + c.get("SQ_INSTS_VALU_ADD_F64", 0) + c.get("SQ_INSTS_VALU_MUL_F64", 0)
+                     + c.get("SQ_INSTS_VALU_TRANS_F64", 0))
+    summary["f64"] = {"flops_per_launch": flops, "flops_per_env_step": flops / n_envs,
+                      "fma": c["SQ_INSTS_VALU_FMA_F64"], "add": c.get("SQ_INSTS_VALU_ADD_F64", 0),
+                      "mul": c.get("SQ_INSTS_VALU_MUL_F64", 0), "trans": c.get("SQ_INSTS_VALU_TRANS_F64", 0)}
 os.makedirs(os.path.join(root, "profiles"), exist_ok=True)
 json.dump(summary, open(os.path.join(root, "profiles", f"{tag}_summary.json"), "w"), indent=1)
 if "hbm" in summary:
-    json.dump({"task": "reach", "controller": "joint", "n_envs": n_envs, "hbm_bytes_per_launch": summary["hbm"]["bytes_per_launch_corrected"],
+    name = "pmc_latest.json" if task == "reach" else "pmc_latest_pnp.json"
+    json.dump({"task": task, "controller": "joint", "n_envs": n_envs, "hbm_bytes_per_launch": summary["hbm"]["bytes_per_launch_corrected"],
+               "f64_flops_per_launch": flops,
                "note": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH_SIZE x2 (gfx950), tag {tag}"},
-              open(os.path.join(root, "profiles", "pmc_latest.json"), "w"), indent=1)
+              open(os.path.join(root, "profiles", name), "w"), indent=1)
 print(json.dumps(summary, indent=1))
