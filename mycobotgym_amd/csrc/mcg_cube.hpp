@@ -356,6 +356,9 @@ struct CubeSys {
       }
     }
     ncon = CL.n;
+#ifdef MCG_STAGE_CLOCKS
+    { int mx = 0; for (int c = 0; __any(c < ncon); c++) mx = c + 1; if (threadIdx.x == 0) sh_stage[ST_COUNT + 1 + CN_CONTACTS] += mx; }   // wave-max contacts
+#endif
     // Lanes with fewer contacts than their wave-mates still walk the longer list with zero weights: give them clean
     // zeros to multiply (uninitialised LDS may hold NaN / inf, and 0 * NaN would poison the sums).
     for (int c = 0; __any(c < ncon); c++) {
@@ -579,7 +582,9 @@ struct CubeSys {
     }
     bool conv = false;
     real xr[NB], xc[6];
+    MCG_COUNT(CN_COUPLED);
     for (int it = 0; it < 50; it++) {
+      MCG_COUNT(CN_COUPLED_IT);
       real G[NB * (NB + 1) / 2], dinv[NB], gr[NB];
       {
         real L[NB * (NB + 1) / 2];
@@ -672,6 +677,7 @@ struct CubeSys {
       conv = conv || finish;
       if (!__any(!conv)) break;
       // line search (bisection): smooth part = robot quadratic with H0 = M + equality rows (no limits), cube diag M
+      MCG_COUNT(CN_COUPLED_LS);
       real lin0 = 0, quad = 0;
       {
         real L[NB * (NB + 1) / 2];

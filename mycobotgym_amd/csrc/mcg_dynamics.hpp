@@ -37,7 +37,7 @@ constexpr real MINVAL = 1e-15, MINIMP = 1e-4, MAXIMP = 0.9999;
 // accumulates shader-clock deltas per pipeline stage in LDS and adds them to a device-global table at kernel end.
 enum { ST_LOAD = 0, ST_CTRL, ST_TRIG, ST_RNE, ST_ACT, ST_CRB, ST_ROWS, ST_G0, ST_NEWTON, ST_EULER, ST_COLLIDE, ST_CUBE,
        ST_COUPLED, ST_CUBE_FIN, ST_POST, ST_N_BUILD, ST_N_FACTOR, ST_N_SOLVE, ST_N_CHECK, ST_E_RHS, ST_COUNT,
-       CN_SUBSTEP = 0, CN_NEWTON_IT, CN_LINESEARCH, CN_CUBE_IT, CN_CUBE_LS, CN_COUNT };
+       CN_SUBSTEP = 0, CN_NEWTON_IT, CN_LINESEARCH, CN_CUBE_IT, CN_CUBE_LS, CN_COUPLED, CN_COUPLED_IT, CN_COUPLED_LS, CN_CONTACTS, CN_COUNT };
 #ifdef MCG_STAGE_CLOCKS
 __device__ unsigned long long g_stage_clocks[ST_COUNT + CN_COUNT];      // stage clocks, then event counts (per wave)
 __shared__ unsigned long long sh_stage[ST_COUNT + 1 + CN_COUNT];

@@ -36,6 +36,7 @@ extern "C" {
 #define MCO_MAXEXCL 16
 #define MCO_MAXCON 12      /* contacts kept per env; the HIP kernels use the same cap (MAXCON in mcg_cube.hpp) */
 #define MCO_MAXEFC 224
+#define MCO_MAXMOCAP 1
 
 enum { MCO_JNT_FREE = 0, MCO_JNT_HINGE = 3 };
 enum { MCO_GEOM_PLANE = 0, MCO_GEOM_BOX = 6, MCO_GEOM_MESH = 7 };
@@ -50,6 +51,7 @@ typedef struct mco_model {
   /* bodies */
   int body_parent[MCO_MAXBODY], body_rootid[MCO_MAXBODY], body_weldid[MCO_MAXBODY];
   int body_dofadr[MCO_MAXBODY], body_dofnum[MCO_MAXBODY];
+  int body_mocapid[MCO_MAXBODY];  /* -1, or the slot in data->mocap_pos / mocap_quat (mocap model variant) */
   double body_pos[MCO_MAXBODY][3], body_quat[MCO_MAXBODY][4];
   double body_ipos[MCO_MAXBODY][3], body_iquat[MCO_MAXBODY][4];
   double body_mass[MCO_MAXBODY], body_inertia[MCO_MAXBODY][3];
@@ -117,6 +119,8 @@ typedef struct mco_data {
   double efc_vel[MCO_MAXEFC], efc_aref[MCO_MAXEFC], efc_force[MCO_MAXEFC];
   double qfrc_constraint[MCO_MAXNV], qacc[MCO_MAXNV];
   int solver_iter, warning_badstate;
+  /* mocap bodies (kept last: pyoracle addresses the leading state members by offset) */
+  double mocap_pos[MCO_MAXMOCAP][3], mocap_quat[MCO_MAXMOCAP][4];
 } mco_data;
 
 /* generic field setters so that a ctypes caller need not mirror the struct layout */
@@ -127,6 +131,7 @@ int mco_model_set_d(mco_model* m, const char* field, const double* v, int n);
 int mco_model_get_d(const mco_model* m, const char* field, double* v, int n);
 int mco_data_get_d(const mco_data* d, const char* field, double* v, int n);
 int mco_data_get_i(const mco_data* d, const char* field, int* v, int n);
+int mco_data_set_d(mco_data* d, const char* field, const double* v, int n);
 
 void mco_setconst(mco_model* m);                         /* mj_setConst: invweight0, meaninertia */
 void mco_reset_data(const mco_model* m, mco_data* d);    /* mj_resetData */

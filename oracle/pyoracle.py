@@ -97,6 +97,12 @@ class OracleModel:
                   "geom_condim", "geom_contype", "geom_conaffinity", "site_body"):
             si(k, table[k])
         si("jnt_limited", [int(x) for x in table["jnt_limited"]])
+        mocap = [bool(x) for x in table.get("body_mocap", [])]
+        ids, nxt = [-1] * 32, 0                     # MCO_MAXBODY entries; -1 = not a mocap body
+        for b, is_m in enumerate(mocap):
+            if is_m: ids[b] = nxt; nxt += 1
+        assert nxt <= 1, "the oracle holds one mocap body (MCO_MAXMOCAP)"
+        si("body_mocapid", ids)
         for k in ("body_pos", "body_quat", "body_ipos", "body_iquat", "body_mass", "body_inertia", "jnt_pos",
                   "jnt_axis", "jnt_range", "jnt_solref", "jnt_solimp", "dof_armature", "dof_damping", "qpos0",
                   "geom_pos", "geom_quat", "geom_size", "geom_friction", "geom_solref", "geom_solimp",
@@ -182,6 +188,12 @@ class OracleData:
     def qvel(self): return self._raw("qvel", self.model.nv)
     @property
     def ctrl(self): return self._raw("ctrl", self.model.nu)
+
+    def set_mocap(self, pos, quat):
+        L = lib(); L.mco_data_set_d.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int]
+        p = np.ascontiguousarray(pos, dtype=np.float64); q = np.ascontiguousarray(quat, dtype=np.float64)
+        assert L.mco_data_set_d(C.c_void_p(self.ptr), b"mocap_pos", _ptr(p), 3) == 0
+        assert L.mco_data_set_d(C.c_void_p(self.ptr), b"mocap_quat", _ptr(q), 4) == 0
 
     def forward(self): lib().mco_forward(self.model.buf, C.c_void_p(self.ptr))
     def step(self, n=1):

@@ -187,3 +187,40 @@ def test_quaternion_helpers_vs_scipy(po):
         v = np.zeros(3); L.mco_quat2vel(p(v), p(q), 50.0)
         rv = rot.as_rotvec() / 50.0
         assert np.abs(v - rv).max() < 1e-12
+
+
+def test_mocap_weld_keyframe_is_an_equilibrium(po):
+    """Reference data known answer for the mocap variant: the `fetch_env` keyframe of mycobot280_mocap.xml:6-9
+    (qpos + mocap pose) was saved with the arm hanging on the weld.  It is a wrist-singular pose: the weld cannot be met,
+    the residual (1.2 mm) is parallel to the null direction of J^T and stays there only if the six weld rows are equally
+    stiff.  The restated weld must hold the keyframe: residual unchanged to 2 %, joints within the keyframe's rounding
+    along the singular direction."""
+    tab = load_json("mycobot280_mocap")
+    m = po.OracleModel(tab)
+    d = po.OracleData(m)
+    key = tab["keys"][0]
+    d.set_state(qpos=key["qpos"], qvel=key["qvel"], ctrl=key["ctrl"])
+    d.set_mocap(key["mpos"], key["mquat"])
+    d.forward()
+    assert int(d.get("nefc", (1,), np.int32)[0]) == 13                 # weld 6 + two connects 6 + joint 1 (SURVEY A.2)
+    r0 = d.get("efc_pos", (224,))[:6].copy()
+    J = d.get("efc_J", (224, 24))[:6, :6]
+    n = np.linalg.svd(J.T)[2][-1]
+    assert abs(r0 @ n) / np.linalg.norm(r0) > 0.999                    # the reference's residual lies in the singular direction
+    assert 1.0e-3 < np.linalg.norm(r0[:3]) < 1.3e-3                    # "about 1 mm below mpos" (SURVEY Appendix E)
+    q0 = np.array(d.qpos[:6])
+    d.step(4000)
+    d.forward()
+    r = d.get("efc_pos", (224,))[:6]
+    assert np.abs(d.qvel[:12]).max() < 1e-8                            # settled
+    assert np.linalg.norm(r - r0) < 0.02 * np.linalg.norm(r0)
+    assert np.abs(np.array(d.qpos[:6]) - q0).max() < 5e-3
+
+
+def test_mocap_weld_rest_pose_has_no_residual(po):
+    tab = load_json("mycobot280_mocap")
+    d = po.OracleData(po.OracleModel(tab))
+    d.forward()
+    assert np.abs(d.get("efc_pos", (224,))[:6]).max() < 1e-12           # FK(EEF; qpos0) == mocap rest pose, mocap.xml:3
+    tcp = tab["body_name"].index("gripper_tcp")
+    assert np.allclose(d.get("xpos", (32, 3))[tcp], tab["body_pos"][tab["body_name"].index("robot0:mocap")], atol=1e-8)

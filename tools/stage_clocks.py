@@ -15,15 +15,22 @@ from mycobotgym_amd import MyCobotVecEnv, _abi
 NAMES = ["load", "controller", "sincos", "rne", "actuation", "crb->M", "constraint rows", "g0", "newton: other (setup, line search)", "euler: factor M+hB, solve, integrate",
          "collide", "cube solve", "coupled solve", "cube finish", "post (obs/reward/reset/store)",
          "newton: build H", "newton: factor H", "newton: solve", "newton: active-set check", "euler: forces/rhs"]
-COUNTS = ["robot sub-steps", "robot Newton iterations", "robot line searches", "cube Newton iterations", "cube line searches"]
+COUNTS = ["robot sub-steps", "robot Newton iterations", "robot line searches", "cube Newton iterations", "cube line searches",
+          "coupled solves", "coupled Newton iterations", "coupled line searches", "wave-max contacts (per collision pass)"]
 fresh = "--fresh-actions" in sys.argv
+grasp = "--grasp" in sys.argv           # PickAndPlace joint with every env holding the cube (scripted grasp state)
 L = _abi.load()
 n = 8192
-for obj, ctrl, k in ((False, "joint", 200), (False, "IK", 50), (True, "joint", 100), (True, "IK", 20)):
-    envs = MyCobotVecEnv(n, has_object=obj, controller_type=ctrl, reward_type="dense")
+for obj, ctrl, k in (((True, "joint", 20),) if grasp else ((False, "joint", 200), (False, "IK", 50), (True, "joint", 100), (True, "IK", 20))):
+    envs = MyCobotVecEnv(n, has_object=obj, controller_type=ctrl, reward_type="dense", max_episode_steps=10 ** 9 if grasp else 50)
     envs.reset(seed=0)
     a = torch.rand(n, envs.action_dim, device="cuda") * 2 - 1
-    for _ in range(60): envs.step(a)
+    if grasp:
+        from mycobotgym_amd.scenarios import grasp_state
+        st = grasp_state(n, seed=0)
+        a = torch.as_tensor(st.pop("action"), device="cuda")
+        envs.set_state(**st)
+    for _ in range(5 if grasp else 60): envs.step(a)
     out = (C.c_ulonglong * (len(NAMES) + len(COUNTS)))()
     assert L.mcg_debug_stage_clocks(out, 1) == 0
     for _ in range(k):
