@@ -60,7 +60,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=100)
-    ap.add_argument("--controller", default="joint", choices=["joint", "IK"])
+    ap.add_argument("--controller", default="joint", choices=["joint", "IK", "mocap"])
     ap.add_argument("--task", default="reach", choices=["reach", "pnp"],
                     help="reach = BASELINE configs[1] (the headline metric); pnp = configs[2], PickAndPlace with contacts")
     ap.add_argument("--dr", action="store_true", help="PickAndPlace with per-reset domain randomisation (configs[4])")
@@ -138,7 +138,7 @@ def main():
     dt, kernel_ms, stats = run(args.controller, K, W)
     total_envs = n * world
     value = total_envs * K / dt
-    substeps = 20 if args.controller == "joint" else 100
+    substeps = 100 if args.controller == "IK" else 20
     out = {
         "metric": "env-steps/sec (whole node), MyCobot Reach, N_envs=8192/GPU" if args.task == "reach" else
                   "env-steps/sec (whole node), MyCobot PickAndPlace, N_envs=8192/GPU",
@@ -184,7 +184,7 @@ def main():
                                            "frac": tf / FP64_VECTOR_PEAK_TFLOPS, "flops_per_launch": flops,
                                            "source": "SQ_INSTS_VALU_{FMA,ADD,MUL,TRANS}_F64 x active lanes, " + (src or "")}
         if not args.no_secondary and world == 1 and args.task == "reach":
-            other = "IK" if args.controller == "joint" else "joint"
+            other = "joint" if args.controller == "IK" else "IK"
             dt2, k2, _ = run(other, max(K // 5, 20), max(W // 5, 5))
             out["secondary"] = {"controller": other, "env_steps_per_sec": n * max(K // 5, 20) / dt2, "kernel_ms": k2,
                                 "physics_substeps_per_sec": n * max(K // 5, 20) / dt2 * (100 if other == "IK" else 20)}

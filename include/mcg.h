@@ -8,7 +8,7 @@
  *   mcg_create          MyCobotEnv.__init__ + _env_setup         mycobotgym/envs/mycobot.py:30-115, 450-481
  *                       (MuJoCo model compile is replaced by the precompiled mcg_model block)
  *   mcg_reset           MyCobotEnv.reset / reset_model / _sample_goal   mycobot.py:506-514, 207-243
- *   mcg_step            MyCobotEnv.step (controller branch -> mujoco.mj_step x frame_skip -> _get_obs ->
+ *   mcg_step            MyCobotEnv.step (controller branch joint | IK | mocap -> mujoco.mj_step x frame_skip -> _get_obs ->
  *                       _is_success / compute_reward / compute_terminated / compute_truncated)
  *                       mycobot.py:132-205, 245-298, 342-400; IKController mycobotgym/utils.py:499-556;
  *                       TimeLimit(50) from the registration mycobotgym/__init__.py:34; auto-reset as in
@@ -32,10 +32,10 @@
 extern "C" {
 #endif
 
-#define MCG_ABI_VERSION 1
+#define MCG_ABI_VERSION 2
 
 enum { MCG_OK = 0, MCG_ERR_ARG = 1, MCG_ERR_HIP = 2, MCG_ERR_UNSUPPORTED = 3 };
-enum { MCG_CTRL_JOINT = 0, MCG_CTRL_IK = 1 };                 /* controller_type "joint" | "IK" */
+enum { MCG_CTRL_JOINT = 0, MCG_CTRL_IK = 1, MCG_CTRL_MOCAP = 2 };   /* controller_type "joint" | "IK" | "mocap" */
 enum { MCG_REWARD_SPARSE = 0, MCG_REWARD_DENSE = 1, MCG_REWARD_SHAPING = 2 };
 
 /* Numeric model block (produced by mycobotgym_amd/model/specialize.py from the compiled MJCF).
@@ -65,6 +65,12 @@ typedef struct mcg_model {
   double contact_par[3][15];        /* table-cube, right pad-cube, left pad-cube: the 10 solver numbers | friction[5] */
   double contact_diag[3][2];        /* summed body_invweight0 (translational, rotational) */
   double geom_friction0[3];         /* sliding friction of the table, pad and cube geoms (re-mixed under domain randomisation) */
+  /* mocap variant only (mycobot280_mocap.xml): weld between the mocap body and gripper_tcp */
+  double base_quat[4];              /* orientation of the arm's base body: start of the xquat chain */
+  double weld_on;                   /* 1 = the model carries the weld (and no arm actuators) */
+  double weld_par[10], weld_diag;   /* solver numbers as in limit_par; the six rows share one weight */
+  double weld_anchor[3];            /* weld point on the robot, link6 frame */
+  double weld_relpos[3], weld_relquat[4], weld_torquescale;
 } mcg_model;
 
 typedef struct mcg_config {
@@ -122,7 +128,7 @@ typedef struct mcg_env mcg_env;
 
 int mcg_abi_version(void);
 const char* mcg_last_error(void);
-/* built-in model blocks: 0 = legacy mesh inertia (default), 1 = exact mesh inertia */
+/* built-in model blocks: 0 = legacy mesh inertia (default), 1 = exact mesh inertia; 2, 3 = the same for the mocap variant */
 int mcg_default_model(int variant, mcg_model* out);
 
 int mcg_create(const mcg_config* cfg, const mcg_model* model /* NULL = variant 0 */, int device, mcg_env** out);

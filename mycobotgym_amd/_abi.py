@@ -15,7 +15,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MCG_LIB") or os.path.join(_HERE, "libmycobot_hip.so")
 
 MCG_OK, MCG_ERR_ARG, MCG_ERR_HIP, MCG_ERR_UNSUPPORTED = 0, 1, 2, 3
-CTRL_JOINT, CTRL_IK = 0, 1
+CTRL_JOINT, CTRL_IK, CTRL_MOCAP = 0, 1, 2
+ABI_VERSION = 2
 REWARD_SPARSE, REWARD_DENSE, REWARD_SHAPING = 0, 1, 2
 
 d = C.c_double
@@ -43,6 +44,8 @@ class McgModel(C.Structure):
         ("contact_par", (d * 15) * 3),
         ("contact_diag", (d * 2) * 3),
         ("geom_friction0", d * 3),
+        ("base_quat", d * 4), ("weld_on", d), ("weld_par", d * 10), ("weld_diag", d), ("weld_anchor", d * 3),
+        ("weld_relpos", d * 3), ("weld_relquat", d * 4), ("weld_torquescale", d),
     ]
 
     @classmethod

@@ -32,13 +32,6 @@ struct Cube {
   real pos[3], quat[4], vel[6], warm[6];     // vel = world linear velocity, body-frame angular velocity (MuJoCo free joint)
 };
 
-MCG_DEV void quat_to_mat(const real* q, real* m) {       // row-major world <- body
-  const real q00 = q[0]*q[0], q01 = q[0]*q[1], q02 = q[0]*q[2], q03 = q[0]*q[3];
-  const real q11 = q[1]*q[1], q12 = q[1]*q[2], q13 = q[1]*q[3], q22 = q[2]*q[2], q23 = q[2]*q[3], q33 = q[3]*q[3];
-  m[0] = q00 + q11 - q22 - q33; m[4] = q00 - q11 + q22 - q33; m[8] = q00 - q11 - q22 + q33;
-  m[1] = 2*(q12 - q03); m[2] = 2*(q13 + q02); m[3] = 2*(q12 + q03);
-  m[5] = 2*(q23 - q01); m[6] = 2*(q13 - q02); m[7] = 2*(q23 + q01);
-}
 
 // mju_makeFrame [RECALL]: tangents completing a unit normal
 MCG_DEV void make_frame(const real* n, real* t1, real* t2) {

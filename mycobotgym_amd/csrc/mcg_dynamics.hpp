@@ -358,8 +358,61 @@ typedef LaneScratchT<64> LaneScratch;
 // accelerations together and returns the contact forces on the robot dofs.  Reach passes NoCoupling (compiled out).
 struct NoCoupling { static constexpr bool enabled = false; };
 
-template <class LS, class CPL = NoCoupling>
-MCG_DEV void robot_substep(ModelPtr Pm, Robot& S, real* qlag6, const LS MS, CPL* CP = nullptr) {
+// Mocap weld (mocap controller, mycobot.py:172-189; mocap.xml:15-20): six equality rows pull gripper_tcp to the mocap
+// body's pose.  NoWeld compiles the rows out (joint / IK controllers).
+struct NoWeld { static constexpr bool enabled = false; };
+struct Weld { static constexpr bool enabled = true; real pos[3], quat[4]; };     // mocap pose, quaternion normalised
+
+MCG_DEV void mulquat(const real* a, const real* b, real* r);
+MCG_DEV void normalize4(real* q);
+MCG_DEV void quat_to_mat(const real* q, real* m) {       // row-major world <- body
+  const real q00 = q[0]*q[0], q01 = q[0]*q[1], q02 = q[0]*q[2], q03 = q[0]*q[3];
+  const real q11 = q[1]*q[1], q12 = q[1]*q[2], q13 = q[1]*q[3], q22 = q[2]*q[2], q23 = q[2]*q[3], q33 = q[3]*q[3];
+  m[0] = q00 + q11 - q22 - q33; m[4] = q00 - q11 + q22 - q33; m[8] = q00 - q11 - q22 + q33;
+  m[1] = 2*(q12 - q03); m[2] = 2*(q13 + q02); m[3] = 2*(q12 + q03);
+  m[5] = 2*(q23 - q01); m[6] = 2*(q13 - q02); m[7] = 2*(q23 + q01);
+}
+
+// World pose of gripper_tcp at arm angles q6: position of the weld point, MuJoCo's xquat (the chain product
+// base_quat * prod_i (cos(q_i/2), axis_i sin(q_i/2)), sign included: the weld residual depends on it), Jacobians.
+struct TcpPose { real pos[3], quat[4], jacp[3][6], jacr[3][6]; };
+MCG_DEV void tcp_forward(ModelPtr P, const real* q6, TcpPose& X, bool want_jac) {
+  real R[9], p[3], anchor[6][3], axis[6][3], Q[4];
+  const TrigC T = load_trig();
+  for (int k = 0; k < 9; k++) R[k] = P->base_mat[k];
+  for (int k = 0; k < 3; k++) p[k] = P->base_pos[k];
+  for (int k = 0; k < 4; k++) Q[k] = P->base_quat[k];
+  static_for<6>([&](auto I) {
+    constexpr int i = I; constexpr int K = AXK[i]; constexpr int A = (K + 1) % 3, B = (K + 2) % 3;
+    real r[3]; ldc<3>(P->body[i].r, r);
+    for (int k = 0; k < 3; k++) p[k] += R[3 * k] * r[0] + R[3 * k + 1] * r[1] + R[3 * k + 2] * r[2];
+    for (int k = 0; k < 3; k++) { anchor[i][k] = p[k]; axis[i][k] = AXS[i] * R[3 * k + K]; }
+    real s, c; sincos_cw(T, AXS[i] * q6[i], s, c);
+    for (int k = 0; k < 3; k++) {
+      real ca = R[3 * k + A], cb = R[3 * k + B];
+      R[3 * k + A] = c * ca + s * cb; R[3 * k + B] = -s * ca + c * cb;
+    }
+    real sh, ch; sincos_cw(T, 0.5 * (AXS[i] * q6[i]), sh, ch);
+    real ql[4] = {ch, 0, 0, 0}, Qn[4]; ql[1 + K] = sh;
+    mulquat(Q, ql, Qn);
+    for (int k = 0; k < 4; k++) Q[k] = Qn[k];
+  });
+  normalize4(Q);
+  for (int k = 0; k < 4; k++) X.quat[k] = Q[k];
+  real wa[3]; ldc<3>(P->weld_anchor, wa);
+  for (int k = 0; k < 3; k++) X.pos[k] = p[k] + R[3 * k] * wa[0] + R[3 * k + 1] * wa[1] + R[3 * k + 2] * wa[2];
+  if (want_jac) {
+    static_for<6>([&](auto I) {
+      constexpr int i = I;
+      real d[3] = {X.pos[0] - anchor[i][0], X.pos[1] - anchor[i][1], X.pos[2] - anchor[i][2]}, c3[3];
+      cross(axis[i], d, c3);
+      for (int k = 0; k < 3; k++) { X.jacp[k][i] = c3[k]; X.jacr[k][i] = axis[i][k]; }
+    });
+  }
+}
+
+template <class LS, class CPL = NoCoupling, class WLD = NoWeld>
+MCG_DEV void robot_substep(ModelPtr Pm, Robot& S, real* qlag6, const LS MS, CPL* CP = nullptr, const WLD* WD = nullptr) {
   MCG_COUNT(CN_SUBSTEP);
   const real h = launder(Pm)->timestep;
   real cs[NB], sn[NB];
@@ -603,6 +656,44 @@ MCG_DEV void robot_substep(ModelPtr Pm, Robot& S, real* qlag6, const LS MS, CPL*
   static_for<10>([&](auto I) { constexpr int j = I; pin(Dl[j]); pin(arefl[j]); pin(sgl[j]); });
   MCG_FENCE();
 
+  // mocap weld: rows 0-2 position (mocap point - weld point), rows 3-5 orientation torquescale * imag(neg(q_tcp) q_m relquat);
+  // Jacobian = -(jac of the weld point), its rotational part mapped through 0.5 neg(q_tcp) (.) q_m relquat; arm dofs only.
+  // [RECALL mj_instantiateEquality mjEQ_WELD; the common row weight is pinned by the reference keyframe, see the oracle]
+  real Jw[6][6], Dw = 0, arefw[6];
+  if constexpr (WLD::enabled) {
+    ModelPtr Q = launder(Pm);
+    TcpPose X; tcp_forward(Q, S.q, X, true);
+    real par[10], rq[4], rp[3]; ldc<10>(Q->weld_par, par); ldc<4>(Q->weld_relquat, rq); ldc<3>(Q->weld_relpos, rp);
+    const real ts = Q->weld_torquescale;
+    real Rm[9]; quat_to_mat(WD->quat, Rm);
+    real cpos[6];
+    for (int k = 0; k < 3; k++) cpos[k] = (WD->pos[k] + Rm[3 * k] * rp[0] + Rm[3 * k + 1] * rp[1] + Rm[3 * k + 2] * rp[2]) - X.pos[k];
+    real quat[4], quat1[4] = {X.quat[0], -X.quat[1], -X.quat[2], -X.quat[3]}, quat2[4];
+    mulquat(WD->quat, rq, quat);
+    mulquat(quat1, quat, quat2);
+    for (int k = 0; k < 3; k++) cpos[3 + k] = ts * quat2[1 + k];
+    static_for<6>([&](auto I) {
+      constexpr int j = I;
+      for (int k = 0; k < 3; k++) Jw[k][j] = -X.jacp[k][j];
+      const real ax[4] = {0, -X.jacr[0][j], -X.jacr[1][j], -X.jacr[2][j]};
+      real t4[4], q3[4];
+      mulquat(quat1, ax, t4); mulquat(t4, quat, q3);
+      for (int k = 0; k < 3; k++) Jw[3 + k][j] = 0.5 * q3[1 + k] * ts;
+    });
+    real ss = 0; for (int k = 0; k < 6; k++) ss = fma(cpos[k], cpos[k], ss);
+    const real imp = impedance(par, sqrt(ss));
+    Dw = imp * rcp_nr(fmax(MINVAL * imp, (1 - imp) * Q->weld_diag));
+    static_for<6>([&](auto Rr) {
+      constexpr int r = Rr;
+      real vel = 0;
+      static_for<6>([&](auto I) { constexpr int j = I; vel = fma(Jw[r][j], S.qd[j], vel); });
+      arefw[r] = -par[1] * vel - par[0] * imp * cpos[r];
+    });
+    pin(Dw); pin6(arefw);
+    for (int r = 0; r < 6; r++) pin6(Jw[r]);
+    MCG_FENCE();
+  }
+
   MCG_TICK(ST_ROWS);
   // ---- P8/P9: g0 = qfrc_smooth + J^T D aref over the equality rows                          (Newton system)
   real g0[NB];
@@ -617,6 +708,9 @@ MCG_DEV void robot_substep(ModelPtr Pm, Robot& S, real* qlag6, const LS MS, CPL*
     });
   });
   g0[6] += Dj * arefj; g0[8] -= Dj * arefj;
+  if constexpr (WLD::enabled)
+    static_for<6>([&](auto Rr) { constexpr int r = Rr; const real da = Dw * arefw[r];
+      static_for<6>([&](auto I) { constexpr int j = I; g0[j] = fma(Jw[r][j], da, g0[j]); }); });
   // H = M + J^T D J (equality rows) + active limit rows, assembled from LDS-resident M for each Newton iteration
   auto build_H = [&](real* H, const bool* act_) {
     static_for<NB>([&](auto I) { constexpr int i = I;
@@ -634,6 +728,10 @@ MCG_DEV void robot_substep(ModelPtr Pm, Robot& S, real* qlag6, const LS MS, CPL*
       });
     });
     H[tri(6, 6)] += Dj; H[tri(8, 8)] += Dj; H[tri(8, 6)] -= Dj;
+    if constexpr (WLD::enabled)
+      static_for<6>([&](auto Rr) { constexpr int r = Rr;
+        static_for<6>([&](auto A_) { constexpr int a = A_; const real ja = Dw * Jw[r][a];
+          static_for<a + 1>([&](auto B_) { constexpr int b = B_; H[tri(a, b)] = fma(ja, Jw[r][b], H[tri(a, b)]); }); }); });
     static_for<10>([&](auto I) { constexpr int j = I; H[tri(j, j)] += act_[j] ? Dl[j] : 0.0; });
   };
 
@@ -742,6 +840,12 @@ MCG_DEV void robot_substep(ModelPtr Pm, Robot& S, real* qlag6, const LS MS, CPL*
     });
   });
   { const real force = -Dj * (a[6] - a[8] - arefj); rhs[6] += force; rhs[8] -= force; }
+  if constexpr (WLD::enabled)
+    static_for<6>([&](auto Rr) { constexpr int r = Rr;
+      real jar = -arefw[r];
+      static_for<6>([&](auto I) { constexpr int j = I; jar = fma(Jw[r][j], a[j], jar); });
+      const real force = -Dw * jar;
+      static_for<6>([&](auto I) { constexpr int j = I; rhs[j] = fma(Jw[r][j], force, rhs[j]); }); });
   static_for<NB>([&](auto I) { constexpr int i = I; rhs[i] += extra[i]; });
   static_for<10>([&](auto I) { constexpr int j = I;
     const real jar = sgl[j] * a[j] - arefl[j];

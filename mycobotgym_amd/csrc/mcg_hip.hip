@@ -154,6 +154,21 @@ MCG_DEV void write_obs(const mcg_step_out& O, int i, int D, const real* obs, con
 
 // ------------------------------------------------------------------------------------------------ step kernel
 // MyCobotEnv.step (mycobot.py:132-205) for Reach, controller = joint | IK.
+// mocap branch of step (mycobot.py:172-189) with gymnasium_robotics' mocap_set_action [RECALL]: the mocap pose is reset to the
+// pose of the welded body as of the last forward pass (lagged angles), then moved by (0.1 a[:3], quat - xquat_tcp); the stored
+// quaternion is normalised by the next mj_kinematics.  quat = a[3:7], or the fixed fetch orientation.
+MCG_DEV void mocap_target(const Cfg& C, ModelPtr P, const real* qlag6, const float* act, Weld& W) {
+  TcpPose X; tcp_forward(P, qlag6, X, false);
+  for (int k = 0; k < 3; k++) W.pos[k] = X.pos[k] + (real)(act[k] * 0.1f);           // f32 product, as numpy computes it
+  const real fq[4] = {0.5, -0.5, -0.5, 0.5};
+  for (int k = 0; k < 4; k++) {
+    const real qt = C.fetch ? fq[k] : (real)act[3 + k];
+    const real dq = qt - X.quat[k];
+    W.quat[k] = X.quat[k] + dq;
+  }
+  normalize4(W.quat);
+}
+
 template <int CONTROLLER>
 __global__ __launch_bounds__(64) void step_reach_kernel(Cfg C, View V, const mcg_model* __restrict__ Pg,
                                                         const float* __restrict__ actions, mcg_step_out O) {
@@ -166,11 +181,12 @@ __global__ __launch_bounds__(64) void step_reach_kernel(Cfg C, View V, const mcg
   Env E;
   load_env(V, i, E);
   MCG_TICK(ST_LOAD);
-  float act[7];
-  _Pragma("unroll") for (int k = 0; k < 7; k++) {   // act_dim is 7 or 4 (fetch IK): static indices keep the array in registers
-    const float x = (k < 4 || C.act_dim == 7) ? actions[(size_t)i * C.act_dim + (k < C.act_dim ? k : 0)] : 0.f;
+  float act[8];
+  _Pragma("unroll") for (int k = 0; k < 8; k++) {   // act_dim is 7, 4 (fetch) or 8 (mocap): static indices keep the array in registers
+    const float x = (k < C.act_dim) ? actions[(size_t)i * C.act_dim + (k < C.act_dim ? k : 0)] : 0.f;
     act[k] = fminf(fmaxf(x, -1.f), 1.f);
   }
+  const float act_last = C.act_dim == 8 ? act[7] : (C.act_dim == 7 ? act[6] : act[3]);     // the gripper command
 
   if constexpr (CONTROLLER == MCG_CTRL_IK) {
     EefPose X;
@@ -183,7 +199,7 @@ __global__ __launch_bounds__(64) void step_reach_kernel(Cfg C, View V, const mcg
       for (int k = 0; k < 3; k++) e[k] = (real)(act[3 + k] * 0.5f);
       euler2quat(e, qr); mat2quat(X.mat, cur); mulquat(qr, cur, tquat);
     }
-    const real grip = C.grip_center + (real)(C.act_dim == 7 ? act[6] : act[3]) * C.grip_range;
+    const real grip = C.grip_center + (real)act_last * C.grip_range;
     for (int c = 0; c < C.control_steps; c++) {
       if (c > 0) eef_forward(P, E.qlag6, X, true);
       real dq[6];
@@ -193,6 +209,11 @@ __global__ __launch_bounds__(64) void step_reach_kernel(Cfg C, View V, const mcg
       MCG_TICK(ST_CTRL);
       for (int s = 0; s < C.frame_skip; s++) robot_substep(P, E.R, E.qlag6, MS);
     }
+  } else if constexpr (CONTROLLER == MCG_CTRL_MOCAP) {
+    Weld W; mocap_target(C, P, E.qlag6, act, W);
+    E.R.ctrl[6] = C.grip_center + (real)act_last * C.grip_range;
+    MCG_TICK(ST_CTRL);
+    for (int s = 0; s < C.frame_skip; s++) robot_substep<LaneScratch, NoCoupling, Weld>(P, E.R, E.qlag6, MS, nullptr, &W);
   } else {
     for (int k = 0; k < 7; k++) E.R.ctrl[k] = (real)act[k];
     MCG_TICK(ST_CTRL);
@@ -356,8 +377,9 @@ MCG_DEV void observe_pnp(const Cfg& C, ModelPtr P, const EnvP& E, real* obs, rea
 // large.  It lives out of line, on a COPY of the env, so that its code and its live ranges stay out of the hot path's
 // register allocation (inlined, it doubled the cost of the uncoupled robot pipeline) and the env struct itself never
 // has its address taken.  It redoes the collision pass: contacts in LDS are the same, the derived numbers are cheap.
-struct CoupledIO { EnvP E; };
-__device__ __noinline__ void pnp_substep_coupled(unsigned long long model_bits, CoupledIO* io, unsigned lds_column) {
+template <class WLD> struct CoupledIO { EnvP E; WLD W; };
+template <class WLD>
+__device__ __noinline__ void pnp_substep_coupled(unsigned long long model_bits, CoupledIO<WLD>* io, unsigned lds_column) {
   const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)model_bits), hi = __builtin_amdgcn_readfirstlane((unsigned)(model_bits >> 32));
   const ModelPtr P = (ModelPtr)(((unsigned long long)hi << 32) | lo);
   const PnpScratch MS((LdsPtr)(uintptr_t)lds_column);
@@ -365,7 +387,8 @@ __device__ __noinline__ void pnp_substep_coupled(unsigned long long model_bits, 
   CubeSys<PnpScratch> CS(MS, E.Cb, E.dr);
   CS.prepare(P, E.R.q);
   MCG_TICK(ST_COLLIDE);
-  robot_substep(P, E.R, E.qlag6, MS, &CS);     // its hook runs the coupled solve when a pad touches the cube
+  const WLD W = io->W;
+  robot_substep<PnpScratch, CubeSys<PnpScratch>, WLD>(P, E.R, E.qlag6, MS, &CS, &W);     // its hook runs the coupled solve
   CS.finish(E.qlag7);
   MCG_TICK(ST_CUBE_FIN);
   E.Cb = CS.Cb;
@@ -374,14 +397,15 @@ __device__ __noinline__ void pnp_substep_coupled(unsigned long long model_bits, 
 
 // one mj_step of robot + cube: collision first (needs both); without pad contact the cost separates into the cube alone
 // and the robot alone (the same instantiation as Reach)
-MCG_DEV void pnp_substep(ModelPtr P, EnvP& E, const PnpScratch MS) {
+template <class WLD>
+MCG_DEV void pnp_substep(ModelPtr P, EnvP& E, const PnpScratch MS, const WLD& W) {
   CubeSys<PnpScratch> CS(MS, E.Cb, E.dr);
   CS.prepare(P, E.R.q);
   MCG_TICK(ST_COLLIDE);
   E.touch = CS.touch[0] && CS.touch[1];        // contacts of this forward pass: what check_contact sees after the step
   if (__any(CS.any_pad)) {                     // wave-uniform
-    CoupledIO io; io.E = E;
-    pnp_substep_coupled((unsigned long long)P, &io, (unsigned)(uintptr_t)MS.base);
+    CoupledIO<WLD> io; io.E = E; io.W = W;
+    pnp_substep_coupled<WLD>((unsigned long long)P, &io, (unsigned)(uintptr_t)MS.base);
     const bool touch = E.touch;
     E = io.E; E.touch = touch;
     return;
@@ -391,7 +415,7 @@ MCG_DEV void pnp_substep(ModelPtr P, EnvP& E, const PnpScratch MS) {
   CS.finish(E.qlag7);
   MCG_TICK(ST_CUBE_FIN);
   E.Cb = CS.Cb;
-  robot_substep(P, E.R, E.qlag6, MS);
+  robot_substep<PnpScratch, NoCoupling, WLD>(P, E.R, E.qlag6, MS, nullptr, &W);
 }
 
 template <int CONTROLLER>
@@ -407,11 +431,12 @@ __global__ __launch_bounds__(PNP_LANES) void step_pnp_kernel(Cfg C, View V, cons
   load_envp(V, i, E);
   MCG_TICK(ST_LOAD);
   E.touch = false;
-  float act[7];
-  _Pragma("unroll") for (int k = 0; k < 7; k++) {   // act_dim is 7 or 4 (fetch IK): static indices keep the array in registers
-    const float x = (k < 4 || C.act_dim == 7) ? actions[(size_t)i * C.act_dim + (k < C.act_dim ? k : 0)] : 0.f;
+  float act[8];
+  _Pragma("unroll") for (int k = 0; k < 8; k++) {   // act_dim is 7, 4 (fetch) or 8 (mocap): static indices keep the array in registers
+    const float x = (k < C.act_dim) ? actions[(size_t)i * C.act_dim + (k < C.act_dim ? k : 0)] : 0.f;
     act[k] = fminf(fmaxf(x, -1.f), 1.f);
   }
+  const float act_last = C.act_dim == 8 ? act[7] : (C.act_dim == 7 ? act[6] : act[3]);     // the gripper command
   if constexpr (CONTROLLER == MCG_CTRL_IK) {
     EefPose X;
     eef_forward(P, E.qlag6, X, true);
@@ -423,7 +448,7 @@ __global__ __launch_bounds__(PNP_LANES) void step_pnp_kernel(Cfg C, View V, cons
       for (int k = 0; k < 3; k++) e[k] = (real)(act[3 + k] * 0.5f);
       euler2quat(e, qr); mat2quat(X.mat, cur); mulquat(qr, cur, tquat);
     }
-    const real grip = C.grip_center + (real)(C.act_dim == 7 ? act[6] : act[3]) * C.grip_range;
+    const real grip = C.grip_center + (real)act_last * C.grip_range;
     for (int c = 0; c < C.control_steps; c++) {
       if (c > 0) eef_forward(P, E.qlag6, X, true);
       real dq[6];
@@ -431,12 +456,17 @@ __global__ __launch_bounds__(PNP_LANES) void step_pnp_kernel(Cfg C, View V, cons
       for (int k = 0; k < 6; k++) E.R.ctrl[k] += dq[k];
       E.R.ctrl[6] = grip;
       MCG_TICK(ST_CTRL);
-      for (int s = 0; s < C.frame_skip; s++) pnp_substep(P, E, MS);
+      for (int s = 0; s < C.frame_skip; s++) pnp_substep(P, E, MS, NoWeld{});
     }
+  } else if constexpr (CONTROLLER == MCG_CTRL_MOCAP) {
+    Weld W; mocap_target(C, P, E.qlag6, act, W);
+    E.R.ctrl[6] = C.grip_center + (real)act_last * C.grip_range;
+    MCG_TICK(ST_CTRL);
+    for (int s = 0; s < C.frame_skip; s++) pnp_substep(P, E, MS, W);
   } else {
     for (int k = 0; k < 7; k++) E.R.ctrl[k] = (real)act[k];
     MCG_TICK(ST_CTRL);
-    for (int s = 0; s < C.frame_skip; s++) pnp_substep(P, E, MS);
+    for (int s = 0; s < C.frame_skip; s++) pnp_substep(P, E, MS, NoWeld{});
   }
   guard_robot(E.R, E.qlag6);
   {   // same guard for the cube: back to its model pose at rest
@@ -564,7 +594,12 @@ int mcg_default_model(int variant, mcg_model* out) {
 int mcg_create(const mcg_config* c, const mcg_model* model, int device, mcg_env** out) {
   if (!c || !out) return fail(MCG_ERR_ARG, "mcg_create: null argument%s");
   if (c->n_envs <= 0) return fail(MCG_ERR_ARG, "mcg_create: n_envs must be positive%s");
-  if (c->controller != MCG_CTRL_JOINT && c->controller != MCG_CTRL_IK) return fail(MCG_ERR_ARG, "mcg_create: controller must be joint or IK%s");
+  if (c->controller != MCG_CTRL_JOINT && c->controller != MCG_CTRL_IK && c->controller != MCG_CTRL_MOCAP) return fail(MCG_ERR_ARG, "mcg_create: controller must be joint, IK or mocap%s");
+  {   // the mocap controller needs the model variant with the weld (and without arm actuators), the others the one without
+    const mcg_model* mm = model ? model : &kDefaultModels[0];
+    if ((c->controller == MCG_CTRL_MOCAP) != (mm->weld_on != 0.0))
+      return fail(MCG_ERR_ARG, "mcg_create: the mocap controller goes with the mocap model variants (mcg_default_model 2 / 3), joint and IK with 0 / 1%s");
+  }
   if (c->controller == MCG_CTRL_JOINT && c->fetch_env) return fail(MCG_ERR_ARG, "Joint controller not supported for Fetch env%s");  // mycobot.py:96
   if (c->reward_type == MCG_REWARD_SHAPING && !c->has_object) return fail(MCG_ERR_UNSUPPORTED, "mcg_create: reward_shaping reads the cube, which the Reach engine drops (SURVEY D-7)%s");
   if (c->reward_type < MCG_REWARD_SPARSE || c->reward_type > MCG_REWARD_SHAPING) return fail(MCG_ERR_ARG, "mcg_create: bad reward_type%s");
@@ -573,6 +608,7 @@ int mcg_create(const mcg_config* c, const mcg_model* model, int device, mcg_env*
     bool ok = true;
     for (int k = 0; k < 12; k++) ok = ok && (mm->limit_par[k][6] == 1.0 || mm->limit_par[k][6] == 2.0);
     for (int k = 0; k < 3; k++) ok = ok && (mm->eq_par[k][6] == 1.0 || mm->eq_par[k][6] == 2.0);
+    if (mm->weld_on != 0.0) ok = ok && (mm->weld_par[6] == 1.0 || mm->weld_par[6] == 2.0);
     if (!ok) return fail(MCG_ERR_UNSUPPORTED, "mcg_create: solimp power must be 1 or 2 (the MJCF default is 2)%s");
   }
   if (c->frame_skip <= 0 || c->control_steps <= 0 || c->max_episode_steps <= 0) return fail(MCG_ERR_ARG, "mcg_create: frame_skip, control_steps, max_episode_steps must be positive%s");
@@ -589,7 +625,8 @@ int mcg_create(const mcg_config* c, const mcg_model* model, int device, mcg_env*
   C.max_episode_steps = c->max_episode_steps; C.target_in_the_air = c->target_in_the_air; C.auto_reset = c->auto_reset;
   C.nq = c->has_object ? 19 : 12; C.nv = c->has_object ? 18 : 12;
   C.obs_dim = c->has_object ? 25 : 10;
-  C.act_dim = (c->controller == MCG_CTRL_IK && c->fetch_env) ? 4 : 7;                 // mycobot.py:84-103
+  C.act_dim = c->controller == MCG_CTRL_MOCAP ? (c->fetch_env ? 4 : 8)
+            : (c->controller == MCG_CTRL_IK && c->fetch_env) ? 4 : 7;                 // mycobot.py:84-103
   C.distance_threshold = c->distance_threshold; C.height_offset = c->height_offset;
   for (int k = 0; k < 3; k++) C.igx[k] = c->initial_gripper_xpos[k];
   C.dt = c->frame_skip * m->timestep;                                                // mycobot.py:346
@@ -667,6 +704,8 @@ static int launch_step(mcg_env* e, const float* actions, const mcg_step_out& o, 
     dim3 grid((e->cfg.n + PNP_LANES - 1) / PNP_LANES), block(PNP_LANES);
     if (e->cfg.controller == MCG_CTRL_IK)
       hipLaunchKernelGGL(step_pnp_kernel<MCG_CTRL_IK>, grid, block, 0, s, e->cfg, e->view, e->d_model, actions, o);
+    else if (e->cfg.controller == MCG_CTRL_MOCAP)
+      hipLaunchKernelGGL(step_pnp_kernel<MCG_CTRL_MOCAP>, grid, block, 0, s, e->cfg, e->view, e->d_model, actions, o);
     else
       hipLaunchKernelGGL(step_pnp_kernel<MCG_CTRL_JOINT>, grid, block, 0, s, e->cfg, e->view, e->d_model, actions, o);
     return hipGetLastError() == hipSuccess ? MCG_OK : MCG_ERR_HIP;
@@ -674,6 +713,8 @@ static int launch_step(mcg_env* e, const float* actions, const mcg_step_out& o, 
   dim3 grid((e->cfg.n + 63) / 64), block(64);
   if (e->cfg.controller == MCG_CTRL_IK)
     hipLaunchKernelGGL(step_reach_kernel<MCG_CTRL_IK>, grid, block, 0, s, e->cfg, e->view, e->d_model, actions, o);
+  else if (e->cfg.controller == MCG_CTRL_MOCAP)
+    hipLaunchKernelGGL(step_reach_kernel<MCG_CTRL_MOCAP>, grid, block, 0, s, e->cfg, e->view, e->d_model, actions, o);
   else
     hipLaunchKernelGGL(step_reach_kernel<MCG_CTRL_JOINT>, grid, block, 0, s, e->cfg, e->view, e->d_model, actions, o);
   return hipGetLastError() == hipSuccess ? MCG_OK : MCG_ERR_HIP;

@@ -80,6 +80,8 @@ def specialize(m: dict) -> dict:
     Rb = quat_to_mat(np.asarray(m["body_quat"][base]))
     out["base_pos"] = np.asarray(m["body_pos"][base], dtype=float)
     out["base_mat"] = Rb
+    bq = np.asarray(m["body_quat"][base], dtype=float)
+    out["base_quat"] = bq / np.linalg.norm(bq)         # xquat of the arm's chain starts here (mocap weld residual)
     out["gravity_base"] = Rb.T @ (-np.asarray(m["opt"]["gravity"], dtype=float))
 
     # --- weld joint-less descendants into each moving body
@@ -152,8 +154,10 @@ def specialize(m: dict) -> dict:
     out["limit_diag"] = np.concatenate([diw[:12]])
 
     # --- equalities: connect(right_finger, right_hinge), connect(left_finger, left_hinge), joint(gear R = gear L)
-    eq = m["eq"]
-    assert [e["type"] for e in eq[:3]] == [0, 0, 2]
+    eq = list(m["eq"])
+    weld = [e for e in eq if e["type"] == 1]
+    eq = [e for e in eq if e["type"] != 1]
+    assert len(weld) <= 1 and [e["type"] for e in eq[:3]] == [0, 0, 2]
     assert (eq[0]["obj1"], eq[0]["obj2"]) == (ids[7], ids[10]) and (eq[1]["obj1"], eq[1]["obj2"]) == (ids[9], ids[11])
     assert (eq[2]["obj1"], eq[2]["obj2"]) == (6, 8) and np.allclose(eq[2]["data"][:5], [0, 1, 0, 0, 0])
     out["eq_anchor1"] = np.array([eq[0]["data"][0:3], eq[1]["data"][0:3]])
@@ -162,7 +166,11 @@ def specialize(m: dict) -> dict:
     out["eq_diag"] = np.array([biw[ids[7], 0] + biw[ids[10], 0], biw[ids[9], 0] + biw[ids[11], 0], diw[6] + diw[8]])
 
     # --- actuators: 6 joint servos + tendon servo over (gear R, gear L)
-    acts = m["actuators"]
+    acts = list(m["actuators"])
+    if len(acts) == 1:       # mocap variant (mocap_actuators.xml): no arm servos; zero-gain placeholders keep the layout
+        assert weld, "a model without arm actuators is expected to carry the mocap weld"
+        acts = [dict(trntype="joint", trnid=i, gear=1.0, gainprm=[0.0, 0, 0], biasprm=[0.0, 0, 0], ctrllimited=True,
+                     forcelimited=True, ctrlrange=[-1.0, 1.0], forcerange=[-1.0, 1.0]) for i in range(6)] + acts
     assert len(acts) == 7 and [a["trntype"] for a in acts] == ["joint"] * 6 + ["tendon"]
     assert [a["trnid"] for a in acts[:6]] == list(range(6)) and all(a["gear"] == 1 for a in acts)
     ten = m["tendons"][acts[6]["trnid"]]
@@ -179,6 +187,26 @@ def specialize(m: dict) -> dict:
     i6, R, p = weld_frames[m["site_body"][s]]
     assert i6 == 5 and np.allclose(R, np.eye(3)) and np.allclose(m["site_quat"][s], [1, 0, 0, 0])
     out["site_eef"] = p + np.asarray(m["site_pos"][s])
+
+    # --- mocap weld (mocap.xml:15-20): body1 = the mocap body (static), body2 = gripper_tcp, welded into link6
+    out["weld_on"] = 0.0
+    out["weld_par"] = np.zeros(10); out["weld_diag"] = 0.0; out["weld_anchor"] = np.zeros(3)
+    out["weld_relpos"] = np.zeros(3); out["weld_relquat"] = np.array([1.0, 0, 0, 0]); out["weld_torquescale"] = 1.0
+    if weld:
+        w = weld[0]
+        b1, b2 = w["obj1"], w["obj2"]
+        assert m["body_mocap"][b1] and m["body_name"][b2] == "gripper_tcp"
+        i6, R, p = weld_frames[b2]
+        assert i6 == 5 and np.allclose(R, np.eye(3)), "gripper_tcp: welded into link6 without rotation expected"
+        data = np.asarray(w["data"], dtype=float)
+        assert np.allclose(data[0:3], 0), "weld anchor at the origin of gripper_tcp expected (xpos[tcp] is the weld point)"
+        out["weld_on"] = 1.0
+        out["weld_par"] = np.array(_solparams(w["solref"], w["solimp"], h))
+        # all six rows carry the translational inverse weights (oracle/mco_physics.c, pinned by the keyframe equilibrium)
+        out["weld_diag"] = float(biw[b1, 0] + biw[b2, 0])
+        out["weld_anchor"] = p + data[0:3]               # anchor (body2 frame) in the link6 frame
+        out["weld_relpos"] = data[3:6]; out["weld_relquat"] = data[6:10]; out["weld_torquescale"] = float(data[10])
+        out["mocap_pose0"] = np.concatenate([np.asarray(m["body_pos"][b1], float), np.asarray(m["body_quat"][b1], float)])
 
     # --- contact geometry of the PickAndPlace scene: cube, table top, finger pads
     if has_cube:

@@ -25,28 +25,32 @@ from .registry import MAX_EPISODE_STEPS, spec as _spec
 from .spaces import Box, Dict, batch_box
 
 _ASSETS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "assets")
-_CONTROLLERS = {"joint": _abi.CTRL_JOINT, "IK": _abi.CTRL_IK}
+_CONTROLLERS = {"joint": _abi.CTRL_JOINT, "IK": _abi.CTRL_IK, "mocap": _abi.CTRL_MOCAP}
 _REWARDS = {"sparse": _abi.REWARD_SPARSE, "dense": _abi.REWARD_DENSE, "reward_shaping": _abi.REWARD_SHAPING}
 
 
-def load_table(has_object: bool, mesh_inertia: str = "legacy") -> dict:
-    name = "mycobot280" + ("" if has_object else "_reach") + ("_exactmesh" if mesh_inertia == "exact" else "")
+def load_table(has_object: bool, mesh_inertia: str = "legacy", mocap: bool = False) -> dict:
+    """Compiled model table: mycobot280.xml (joint / IK) or mycobot280_mocap.xml (mocap controller), mycobot.py:47-58."""
+    name = ("mycobot280" + ("_mocap" if mocap else "") + ("" if has_object else "_reach")
+            + ("_exactmesh" if mesh_inertia == "exact" else ""))
     from .model.mjcf import load_model
     return load_model(os.path.join(_ASSETS, name + ".json"))
 
 
-def initial_state(has_object: bool, fetch_env: bool, mesh_inertia: str = "legacy"):
+def initial_state(has_object: bool, fetch_env: bool, mesh_inertia: str = "legacy", mocap: bool = False):
     """(init_qpos, init_qvel, init_ctrl, initial_gripper_xpos, height_offset): what ``_env_setup`` and the
-    constructor snapshot (mycobot.py:78-82, 450-472).  Non-fetch: qpos0 / zero ctrl; fetch: keyframe 0."""
+    constructor snapshot (mycobot.py:78-82, 450-472).  Non-fetch: qpos0 / zero ctrl; fetch: keyframe 0.
+    ``init_ctrl`` always has the engine's 7 slots; the mocap model's single (finger) actuator is slot 6."""
     from .model.specialize import initial_gripper_xpos
-    full = load_table(True, mesh_inertia)
-    tab = full if has_object else load_table(False, mesh_inertia)
+    full = load_table(True, mesh_inertia, mocap)
+    tab = full if has_object else load_table(False, mesh_inertia, mocap)
     nq, nv = tab["nq"], tab["nv"]
     if fetch_env:
         key = full["keys"][0]
         qpos = np.asarray(key["qpos"], dtype=np.float64)[:nq].copy()
         qvel = np.asarray(key["qvel"], dtype=np.float64)[:nv].copy()
-        ctrl = np.asarray(key["ctrl"], dtype=np.float64).copy()
+        ctrl = np.zeros(7); kc = np.asarray(key["ctrl"], dtype=np.float64)
+        ctrl[7 - len(kc):] = kc
         height = float(key["qpos"][14])            # z of site object0 after mj_resetDataKeyframe + mj_forward
     else:
         qpos = np.asarray(tab["qpos0"], dtype=np.float64).copy()
@@ -68,8 +72,6 @@ class MyCobotVecEnv:
                  image_obs: bool = False, model: Optional["_abi.McgModel"] = None, **unused):
         if image_obs:
             raise NotImplementedError("image observations (-v1 ids, MyCobotImgEnv) need a rasteriser: out of scope")
-        if controller_type == "mocap":
-            raise NotImplementedError("mocap controller (SURVEY 8f-2) is not built yet")
         if controller_type == "delta_joint":
             raise NotImplementedError("delta_joint has no branch in the reference's step() (SURVEY D-10)")
         if controller_type not in _CONTROLLERS:
@@ -92,7 +94,8 @@ class MyCobotVecEnv:
         self.max_episode_steps = int(max_episode_steps)
         self.obj_range = obj_range
 
-        qpos, qvel, ctrl, igx, height = initial_state(self.has_object, self.fetch_env, mesh_inertia)
+        mocap = controller_type == "mocap"
+        qpos, qvel, ctrl, igx, height = initial_state(self.has_object, self.fetch_env, mesh_inertia, mocap)
         self.initial_gripper_xpos, self.height_offset = igx, height
         cfg = _abi.McgConfig()
         cfg.n_envs = self.num_envs; cfg.has_object = int(self.has_object)
@@ -114,7 +117,8 @@ class MyCobotVecEnv:
         self._cfg = cfg
         if model is None:     # built-in block; a caller-supplied mcg_model (tests, custom robots) overrides it
             model = _abi.McgModel()
-            _abi.check(self._lib.mcg_default_model(1 if mesh_inertia == "exact" else 0, C.byref(model)), "mcg_default_model")
+            variant = (1 if mesh_inertia == "exact" else 0) + (2 if mocap else 0)     # 2, 3: mocap body + weld (mycobot280_mocap.xml)
+            _abi.check(self._lib.mcg_default_model(variant, C.byref(model)), "mcg_default_model")
         self._model = model
         self._h = C.c_void_p()
         dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()

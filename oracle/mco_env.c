@@ -273,6 +273,16 @@ static void step_one(mco_envs* e, int i, const float* action) {                /
       d->ctrl[6] = grip;
       substeps(e, i, e->cfg.frame_skip);
     }
+  } else if (e->cfg.controller == MCO_CTRL_MOCAP) {                              /* mycobot.py:172-189 */
+    /* mocap_action = (0.1 a[:3], quat - xquat[tcp]); mocap_set_action: reset_mocap2body_xpos (mocap pose := pose of the
+       welded body, as of the last forward pass) then mocap_pos += dpos, mocap_quat += dquat  [RECALL gymnasium_robotics] */
+    int tb = e->cfg.tcp_body;
+    double quat[4] = {0.5, -0.5, -0.5, 0.5};                                      /* fetch: fixed orientation (:178-179) */
+    if (!e->cfg.fetch_env) for (int r = 0; r < 4; r++) quat[r] = (double)a[3 + r];
+    for (int r = 0; r < 3; r++) d->mocap_pos[0][r] = d->xpos[tb][r] + (double)(a[r] * 0.1f);      /* f32 product, as numpy */
+    for (int r = 0; r < 4; r++) { double dq = quat[r] - d->xquat[tb][r]; d->mocap_quat[0][r] = d->xquat[tb][r] + dq; }
+    d->ctrl[model_of(e, i)->nu - 1] = e->grip_center + (double)a[e->act_dim - 1] * e->grip_range;
+    substeps(e, i, e->cfg.frame_skip);
   } else {
     /* joint: `data.ctrl += 0.05 a` is overwritten by do_simulation's `data.ctrl[:] = action` (D-2) */
     for (int k = 0; k < 7; k++) d->ctrl[k] = (double)a[k];
@@ -344,7 +354,8 @@ mco_envs* mco_envs_create(const mco_model* model, const mco_env_config* cfg) {
   mco_envs* e = (mco_envs*)calloc(1, sizeof(mco_envs));
   e->model = *model; e->cfg = *cfg; e->seed = cfg->seed;
   e->obs_dim = cfg->has_object ? 25 : 10;
-  e->act_dim = (cfg->controller == MCO_CTRL_IK && cfg->fetch_env) ? 4 : 7;       /* mycobot.py:84-103 */
+  e->act_dim = (cfg->controller == MCO_CTRL_MOCAP) ? (cfg->fetch_env ? 4 : 8)
+             : (cfg->controller == MCO_CTRL_IK && cfg->fetch_env) ? 4 : 7;       /* mycobot.py:84-103 */
   e->dt = cfg->frame_skip * model->timestep;                                      /* mycobot.py:346 */
   int last = model->nu - 1;                                                       /* mycobot.py:113-115 */
   e->grip_range = (model->act_ctrlrange[last][1] - model->act_ctrlrange[last][0]) / 2.0;
@@ -357,12 +368,15 @@ mco_envs* mco_envs_create(const mco_model* model, const mco_env_config* cfg) {
   /* _env_setup (mycobot.py:450-472): forward at the initial state, cache the gripper position */
   mco_data* d = &e->env[0].d;
   memcpy(d->qpos, cfg->init_qpos, sizeof(double) * model->nq);
+  memcpy(d->mocap_pos[0], cfg->init_mocap, sizeof(double) * 3); memcpy(d->mocap_quat[0], cfg->init_mocap + 3, sizeof(double) * 4);
   mco_forward(model, d);
   memcpy(e->initial_gripper_xpos, d->site_xpos[cfg->eef_site], 3 * sizeof(double));
   for (int i = 0; i < cfg->n_envs; i++) {
     memset(&e->env[i], 0, sizeof(env_t));
     memcpy(e->env[i].d.qpos, cfg->init_qpos, sizeof(double) * model->nq);
     memcpy(e->env[i].qpos_lag, cfg->init_qpos, sizeof(double) * model->nq);
+    memcpy(e->env[i].d.mocap_pos[0], cfg->init_mocap, sizeof(double) * 3);
+    memcpy(e->env[i].d.mocap_quat[0], cfg->init_mocap + 3, sizeof(double) * 4);
   }
   return e;
 }

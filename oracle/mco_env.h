@@ -2,7 +2,8 @@
  * ORACLE -- TEST INFRASTRUCTURE ONLY.  Not part of the product path.
  *
  * CPU restatement of the reference's env layer on top of mco_physics:
- *   MyCobotEnv.step            /root/reference/mycobotgym/envs/mycobot.py:132-205
+ *   MyCobotEnv.step            /root/reference/mycobotgym/envs/mycobot.py:132-205   (mocap branch :172-189, with
+ *                              gymnasium_robotics' mocap_set_action / reset_mocap2body_xpos restated [RECALL])
  *   reset / reset_model        :506-514, :207-236      _sample_goal :238-243
  *   _get_obs / generate_mujoco_observations  :245-283, :342-388
  *   _is_success / compute_reward / compute_terminated / compute_truncated  :285-298, :390-400
@@ -26,7 +27,7 @@
 extern "C" {
 #endif
 
-enum { MCO_CTRL_JOINT = 0, MCO_CTRL_IK = 1 };
+enum { MCO_CTRL_JOINT = 0, MCO_CTRL_IK = 1, MCO_CTRL_MOCAP = 2 };
 enum { MCO_REWARD_SPARSE = 0, MCO_REWARD_DENSE = 1, MCO_REWARD_SHAPING = 2 };
 
 typedef struct mco_env_config {
@@ -35,9 +36,11 @@ typedef struct mco_env_config {
   int32_t eef_site, obj_site, obj_jnt, grip_jnt[2], n_threads;
   int32_t dr_enable, pad_geom[2], obj_geom;
   int32_t block_gripper, finger_jnt[2];      /* _step_callback: zero the two finger joints after every step (mycobot.py:300-306) */
+  int32_t tcp_body, pad_;                    /* mocap controller: the body welded to the mocap body (gripper_tcp) */
   double distance_threshold, height_offset;
   double init_qpos[MCO_MAXNQ], init_qvel[MCO_MAXNV], init_ctrl[MCO_MAXU];
   double dr_mass_range[2], dr_friction_range[2];
+  double init_mocap[7];                      /* mocap pose at construction: body pose, or the keyframe's mpos / mquat (fetch) */
   uint64_t seed;
   int64_t env_id_offset;
 } mco_env_config;

@@ -65,10 +65,10 @@ class EnvConfig(C.Structure):
         ("max_episode_steps", C.c_int32), ("target_in_the_air", C.c_int32), ("auto_reset", C.c_int32),
         ("eef_site", C.c_int32), ("obj_site", C.c_int32), ("obj_jnt", C.c_int32), ("grip_jnt", C.c_int32 * 2),
         ("n_threads", C.c_int32), ("dr_enable", C.c_int32), ("pad_geom", C.c_int32 * 2), ("obj_geom", C.c_int32),
-        ("block_gripper", C.c_int32), ("finger_jnt", C.c_int32 * 2),
+        ("block_gripper", C.c_int32), ("finger_jnt", C.c_int32 * 2), ("tcp_body", C.c_int32), ("pad_", C.c_int32),
         ("distance_threshold", C.c_double), ("height_offset", C.c_double),
         ("init_qpos", C.c_double * MAXNQ), ("init_qvel", C.c_double * MAXNV), ("init_ctrl", C.c_double * MAXU),
-        ("dr_mass_range", C.c_double * 2), ("dr_friction_range", C.c_double * 2),
+        ("dr_mass_range", C.c_double * 2), ("dr_friction_range", C.c_double * 2), ("init_mocap", C.c_double * 7),
         ("seed", C.c_uint64), ("env_id_offset", C.c_int64),
     ]
 

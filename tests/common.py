@@ -10,8 +10,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ASSETS = os.path.join(ROOT, "mycobotgym_amd", "assets")
 
 
-def table_name(has_object=False, mesh_inertia="legacy"):
-    return "mycobot280" + ("" if has_object else "_reach") + ("_exactmesh" if mesh_inertia == "exact" else "")
+def table_name(has_object=False, mesh_inertia="legacy", mocap=False):
+    return ("mycobot280" + ("_mocap" if mocap else "") + ("" if has_object else "_reach")
+            + ("_exactmesh" if mesh_inertia == "exact" else ""))
 
 
 def load_json(name):
@@ -34,13 +35,23 @@ def make_oracle(n, has_object=False, controller_type="joint", fetch_env=False, r
                 domain_randomization=None, block_gripper=False):
     from oracle import pyoracle as po
     from mycobotgym_amd.vec_env import initial_state
-    tab = table if table is not None else load_json(table_name(has_object, mesh_inertia))
+    mocap = controller_type == "mocap"
+    tab = table if table is not None else load_json(table_name(has_object, mesh_inertia, mocap))
     # the build's scoped collision set: pairs involving the cube
     model = po.OracleModel(tab, enable_contact=has_object, scope_geom=tab["geom_name"].index("object0") if has_object else -1)
-    qpos, qvel, ctrl, igx, height = initial_state(has_object, fetch_env, mesh_inertia)
+    qpos, qvel, ctrl, igx, height = initial_state(has_object, fetch_env, mesh_inertia, mocap)
+    ctrl = ctrl[7 - tab["nu"]:]                  # the oracle's ctrl has the model's nu entries (mocap model: the finger only)
     cfg = po.EnvConfig()
     cfg.n_envs = n; cfg.has_object = int(has_object)
-    cfg.controller = {"joint": 0, "IK": 1}[controller_type]; cfg.fetch_env = int(fetch_env)
+    cfg.controller = {"joint": 0, "IK": 1, "mocap": 2}[controller_type]; cfg.fetch_env = int(fetch_env)
+    cfg.tcp_body = tab["body_name"].index("gripper_tcp")
+    if mocap:
+        mb = tab["body_mocap"].index(True)
+        pose = list(tab["body_pos"][mb]) + list(tab["body_quat"][mb])
+        if fetch_env:
+            key = load_json(table_name(True, mesh_inertia, True))["keys"][0]
+            pose = list(key["mpos"]) + list(key["mquat"])
+        for k, v in enumerate(pose): cfg.init_mocap[k] = v
     cfg.reward_type = {"sparse": 0, "dense": 1, "reward_shaping": 2}[reward_type]
     cfg.frame_skip = frame_skip; cfg.control_steps = control_steps; cfg.max_episode_steps = max_episode_steps
     cfg.target_in_the_air = int(target_in_the_air); cfg.auto_reset = int(auto_reset)
@@ -101,6 +112,8 @@ def step_errors(envs, ora, actions):
 def sync_oracle_to(envs, ora):
     """Copy the oracle's state into the HIP engine (both then continue from identical state)."""
     s = ora.get_state()
+    if s["ctrl"].shape[1] < 7:      # mocap model: one actuator (the fingers) = the engine's ctrl slot 6
+        s["ctrl"] = np.concatenate([np.zeros((s["ctrl"].shape[0], 7 - s["ctrl"].shape[1])), s["ctrl"]], axis=1)
     envs.set_state(qpos=s["qpos"].T.copy(), qvel=s["qvel"].T.copy(), ctrl=s["ctrl"].T.copy(), warm=s["warm"].T.copy(),
                    qpos_lag=s["qpos_lag"].T.copy(), goal=s["goal"].T.copy(), elapsed=s["elapsed"], episode=s["episode"])
 

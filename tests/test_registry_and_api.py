@@ -47,7 +47,7 @@ def test_no_cpu_fallback(built):
 def test_unsupported_configurations_raise():
     from mycobotgym_amd import MyCobotVecEnv
     with pytest.raises(NotImplementedError):
-        MyCobotVecEnv(1, controller_type="mocap")
+        MyCobotVecEnv(1, controller_type="delta_joint")          # no branch in the reference's step() (SURVEY D-10)
     with pytest.raises(NotImplementedError):
         MyCobotVecEnv(1, image_obs=True)
     with pytest.raises(AssertionError, match="Joint controller not supported for Fetch env"):   # mycobot.py:96
@@ -69,7 +69,7 @@ def test_library_exports_every_declared_symbol(built):
     assert set(names) == set(_abi.EXPORTS), (names, _abi.EXPORTS)
     for n in names:
         assert getattr(lib, n) is not None
-    assert lib.mcg_abi_version() == 1
+    assert lib.mcg_abi_version() == 2
 
 
 def test_ctypes_mirror_matches_header_layout(built, tmp_path):
@@ -94,7 +94,7 @@ def test_default_model_blocks_match_specializer(built):
     from mycobotgym_amd.model.specialize import specialize
     from tests.common import load_json
     lib = _abi.load()
-    for variant, name in ((0, "mycobot280"), (1, "mycobot280_exactmesh")):
+    for variant, name in ((0, "mycobot280"), (1, "mycobot280_exactmesh"), (2, "mycobot280_mocap"), (3, "mycobot280_mocap_exactmesh")):
         got = _abi.McgModel()
         assert lib.mcg_default_model(variant, C.byref(got)) == 0
         want = _abi.McgModel.from_spec(specialize(_np_model(load_json(name))))
@@ -113,3 +113,18 @@ def test_create_argument_errors_without_touching_the_gpu(built):
     cfg = _abi.McgConfig(n_envs=4, controller=0, fetch_env=1, frame_skip=20, control_steps=5, max_episode_steps=50)
     assert lib.mcg_create(C.byref(cfg), None, 0, C.byref(h)) == _abi.MCG_ERR_ARG
     assert b"Joint controller not supported for Fetch env" in lib.mcg_last_error()
+
+
+def test_mocap_tables_and_initial_state():
+    """Host side of the mocap controller: model variant selection and the constructor snapshot."""
+    from mycobotgym_amd.vec_env import initial_state, load_table
+    tab = load_table(False, "legacy", mocap=True)
+    assert tab["nu"] == 1 and any(tab["body_mocap"]) and [e["type"] for e in tab["eq"]] == [1, 0, 0, 2]
+    qpos, qvel, ctrl, igx, height = initial_state(False, True, "legacy", mocap=True)
+    key = load_table(True, "legacy", mocap=True)["keys"][0]
+    assert np.allclose(qpos, key["qpos"][:12]) and ctrl.shape == (7,) and ctrl[6] == key["ctrl"][0]
+    # the keyframe's mocap position is the gripper position up to the weld's sag (SURVEY Appendix E)
+    assert np.linalg.norm(np.asarray(key["mpos"]) - igx) < 2e-3
+    qpos, qvel, ctrl, igx, height = initial_state(False, False, "legacy", mocap=True)
+    mb = tab["body_mocap"].index(True)
+    assert np.allclose(igx, tab["body_pos"][mb], atol=1e-8)      # mocap.xml:3 == FK(EEF; qpos0)

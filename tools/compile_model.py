@@ -28,7 +28,10 @@ def main():
         ("mycobot280_reach", "mycobot280.xml", "legacy", ("object0",)),  # Reach: cube unobserved -> dropped
         ("mycobot280_exactmesh", "mycobot280.xml", "exact", ()),
         ("mycobot280_reach_exactmesh", "mycobot280.xml", "exact", ("object0",)),
-        ("mycobot280_mocap", "mycobot280_mocap.xml", "legacy", ()),
+        ("mycobot280_mocap", "mycobot280_mocap.xml", "legacy", ()),   # mocap controller: + mocap body, weld, finger actuator only
+        ("mycobot280_mocap_reach", "mycobot280_mocap.xml", "legacy", ("object0",)),
+        ("mycobot280_mocap_exactmesh", "mycobot280_mocap.xml", "exact", ()),
+        ("mycobot280_mocap_reach_exactmesh", "mycobot280_mocap.xml", "exact", ("object0",)),
     ]
     os.makedirs(OUT, exist_ok=True)
     for name, xml, rule, drop in jobs:
