@@ -161,3 +161,35 @@ def test_bad_state_recovers(torch_cuda):
         assert torch.isfinite(obs["observation"]).all() and torch.isfinite(rew).all()
         assert all(torch.isfinite(v.double()).all() for v in envs.get_state().values())
         envs.close()
+
+
+def test_every_v0_id_constructs_and_steps(torch_cuda):
+    """The 30 `-v0` registrations of the reference (mycobotgym/__init__.py:26-45): 25 build an engine and step, the five
+    Reach-RewardShaping ids are rejected with a reason."""
+    torch = torch_cuda
+    from mycobotgym_amd import make
+    from mycobotgym_amd.registry import REGISTRY
+    ids = sorted(k for k in REGISTRY if k.endswith("-v0"))
+    assert len(ids) == 30
+    from mycobotgym_amd._abi import McgError
+    built_ids = 0
+    for env_id in ids:
+        if not REGISTRY[env_id]["has_object"] and REGISTRY[env_id]["reward_type"] == "reward_shaping":
+            # stage_rewards reads the cube, which the Reach engine drops (hidden, unobserved: SURVEY D-7): rejected loudly
+            with pytest.raises(McgError, match="reward_shaping"):
+                make(env_id, num_envs=16)
+            continue
+        built_ids += 1
+        envs = make(env_id, num_envs=16)
+        obs, _ = envs.reset(seed=1)
+        a = torch.rand(16, envs.action_dim, device="cuda") * 2 - 1
+        for _ in range(3):
+            obs, rew, term, trunc, info = envs.step(a)
+        assert torch.isfinite(obs["observation"]).all() and torch.isfinite(rew).all(), env_id
+        want = {"mocap": 8, "IK": 7, "joint": 7}[REGISTRY[env_id]["controller_type"]]
+        if REGISTRY[env_id]["fetch_env"]:
+            want = 4
+        assert envs.action_dim == want, env_id
+        assert obs["observation"].shape == (16, 25 if REGISTRY[env_id]["has_object"] else 10)
+        envs.close()
+    assert built_ids == 25          # 30 minus the five Reach-RewardShaping ids
