@@ -249,7 +249,7 @@ struct CubeSys {
   real h, Rc[9], Md[6], damp[6], fs[6];
   real B_tc, B_pc, mu_tc[3], mu_pc[3];
   int ncon; bool any_pad, solved, touch[2];    // touch: this forward pass has a right / left pad-cube contact
-  real a_c[6], fc[6];
+  real a_c[6];
 
   // ------------------------------------------------------------------------------------------------- prepare
   // Cheap quantities of the current state (rotation, inertia, smooth force, friction): re-derived by each stage that
@@ -289,7 +289,7 @@ struct CubeSys {
     derive(Pm);
     ModelPtr Q = launder(Pm);
     solved = false;
-    _Pragma("unroll") for (int k = 0; k < 6; k++) { a_c[k] = Cb.warm[k]; fc[k] = 0; }
+    _Pragma("unroll") for (int k = 0; k < 6; k++) a_c[k] = Cb.warm[k];
 
     // ---- P4 collision, in the oracle's pair order: ground-cube, table-cube, right pad-cube, left pad-cube
     ContactList<LS> CL{S, 0};
@@ -414,7 +414,6 @@ struct CubeSys {
       _Pragma("unroll") for (int d = 0; d < 6; d++) { o[0] = fma(R.Jn[d], v[d], o[0]); o[1] = fma(R.J1[d], v[d], o[1]); o[2] = fma(R.J2[d], v[d], o[2]); o[3] = fma(R.Jt[d], v[d], o[3]); }
     };
     bool conv = false;
-    real fcx[6];
     for (int it = 0; it < 50; it++) {
       MCG_COUNT(CN_CUBE_IT);
       real H[21], g[6];
@@ -455,15 +454,14 @@ struct CubeSys {
       real x[6], dinv[6];
       _Pragma("unroll") for (int k = 0; k < 6; k++) x[k] = g[k];
       spd_factor<6>(H, dinv); spd_solve<6>(H, dinv, x);
-      real p[6]; _Pragma("unroll") for (int k = 0; k < 6; k++) { p[k] = x[k] - a[k]; fcx[k] = 0; }
+      real p[6]; _Pragma("unroll") for (int k = 0; k < 6; k++) p[k] = x[k] - a[k];
       bool same = true;
-      for (int c = 0; __any(c < ncon); c++) {                    // pass B: consistency at x, forces at x, line-search data
+      for (int c = 0; __any(c < ncon); c++) {                    // pass B: consistency at x, line-search data
         CubeRows R; rows_cube(c, R);
         const int b = LDS_CON + c * CON_STRIDE;
         const real D = sel((c < ncon), S.ld(b + 13), 0.0), kterm = S.ld(b + 14);
         const int mask = (int)S.ld(LDS_ACT + c);
         real dv[4], da[4], dp[4]; dots(R, Cb.vel, dv); dots(R, a, da); dots(R, p, dp);
-        real fb[4] = {0, 0, 0, 0};              // force on the basis vectors: f_n = sum f_r, f_k = sum m_r f_r
         static_for<3>([&](auto Kk) {
           constexpr int k = Kk;
           static_for<2>([&](auto Od) {
@@ -473,14 +471,11 @@ struct CubeSys {
             if (c < ncon) { S.st(LDS_ROW + (c * 6 + r) * 2, r0); S.st(LDS_ROW + (c * 6 + r) * 2 + 1, jp); }
             const real rx = r0 + jp;
             same = same && (c >= ncon || (rx < 0) == (((mask >> r) & 1) != 0));
-            const real f = sel((rx < 0), -D * rx, 0.0);
-            fb[0] += f; fb[1 + k] = fma(m, f, fb[1 + k]);
           });
         });
-        _Pragma("unroll") for (int d = 0; d < 6; d++) fcx[d] += R.Jn[d] * fb[0] + R.J1[d] * fb[1] + R.J2[d] * fb[2] + R.Jt[d] * fb[3];
       }
       const bool finish = !conv && same;
-      _Pragma("unroll") for (int k = 0; k < 6; k++) { a[k] = sel(finish, x[k], a[k]); fc[k] = sel(finish, fcx[k], fc[k]); }
+      _Pragma("unroll") for (int k = 0; k < 6; k++) a[k] = sel(finish, x[k], a[k]);
       conv = conv || finish;
       if (!__any(!conv)) break;
       // Line search along p.  Any descent step that ends in a consistent active set yields the exact minimiser at the
@@ -535,7 +530,7 @@ struct CubeSys {
   // system stays a sparse 12x12 (pattern PAT_G) in registers.  Rows: joint limits, table-cube and pad-cube pyramids.
   template <class BuildH>
   MCG_DEV void solve_coupled(BuildH& build_H, const real* g0, const real* Dl, const real* arefl, const real* sgl,
-                             const real* qdr, real* ar, real* extra) {
+                             const real* qdr, real* ar) {
     derive(model());
     // dof slot of (side, j): arm j -> j; gear -> 6 + 2 side; finger -> 7 + 2 side.  Gather helpers with selects:
     auto gather8 = [](const real* v, int side, real* o) {
@@ -700,27 +695,7 @@ struct CubeSys {
       remask(alpha, conv);
     }
     (void)any_lim;
-    // contact forces on both sides
-    _Pragma("unroll") for (int k = 0; k < 6; k++) { a_c[k] = ac[k]; fc[k] = 0; }
-    for (int c = 0; __any(c < ncon); c++) {
-      CubeRows RC; PadRows RP; int type; real D, kterm;
-      contact_rows(c, RC, RP, type, D, kterm);
-      const int side = sel(type == PAIR_PADL_CUBE, 1, 0);
-      const bool tb_ = type == PAIR_TABLE_CUBE; const real mu[3] = {sel(tb_, mu_tc[0], mu_pc[0]), sel(tb_, mu_tc[1], mu_pc[1]), sel(tb_, mu_tc[2], mu_pc[2])}; const real Bc = sel(type == PAIR_TABLE_CUBE, B_tc, B_pc);
-      real a8[8], v8[8]; gather8(ar, side, a8); gather8(qdr, side, v8);
-      _Pragma("unroll") for (int r = 0; r < 6; r++) {
-        real jc[6], jr[8]; pyramid_row(RC, r, mu, jc); pyr8(RP, r, mu, jr);
-        real ja = 0, jv = 0;
-        _Pragma("unroll") for (int d = 0; d < 6; d++) { ja += jc[d] * ac[d]; jv += jc[d] * Cb.vel[d]; }
-        _Pragma("unroll") for (int d = 0; d < 8; d++) { ja += jr[d] * a8[d]; jv += jr[d] * v8[d]; }
-        const real jar = ja - (-Bc * jv - kterm);
-        const real f = sel((jar < 0), -D * jar, 0.0);
-        _Pragma("unroll") for (int d = 0; d < 6; d++) fc[d] += jc[d] * f;
-        _Pragma("unroll") for (int d = 0; d < 6; d++) extra[d] += jr[d] * f;
-        extra[6] += sel(side, 0.0, jr[6] * f); extra[7] += sel(side, 0.0, jr[7] * f);
-        extra[8] += sel(side, jr[6] * f, 0.0); extra[9] += sel(side, jr[7] * f, 0.0);
-      }
-    }
+    _Pragma("unroll") for (int k = 0; k < 6; k++) a_c[k] = ac[k];
     solved = true;
   }
 
@@ -731,7 +706,7 @@ struct CubeSys {
     _Pragma("unroll") for (int k = 0; k < 3; k++) qlag7[k] = Cb.pos[k];
     _Pragma("unroll") for (int k = 0; k < 4; k++) qlag7[3 + k] = Cb.quat[k];
     _Pragma("unroll") for (int k = 0; k < 6; k++) {
-      const real acc = (fs[k] + fc[k]) / (Md[k] + h * damp[k]);
+      const real acc = (Md[k] * a_c[k]) / (Md[k] + h * damp[k]);      // fs + J^T f = M a at the minimiser: no force needed
       Cb.vel[k] += h * acc;
       Cb.warm[k] = a_c[k];
     }

@@ -355,7 +355,7 @@ typedef LaneScratchT<64> LaneScratch;
 
 // One physics sub-step (mj_step) of the 12-dof robot.  `qlag` receives the positions the forward pass used.
 // Coupling hook: PickAndPlace passes an object that, when a finger pad touches the cube, solves the robot and cube
-// accelerations together and returns the contact forces on the robot dofs.  Reach passes NoCoupling (compiled out).
+// accelerations together (the Euler step needs no constraint force: M a carries it).  Reach passes NoCoupling (compiled out).
 struct NoCoupling { static constexpr bool enabled = false; };
 
 // Mocap weld (mocap controller, mycobot.py:172-189; mocap.xml:15-20): six equality rows pull gripper_tcp to the mocap
@@ -744,12 +744,10 @@ MCG_DEV void robot_substep(ModelPtr Pm, Robot& S, real* qlag6, const LS MS, CPL*
   bool act[10];
   static_for<10>([&](auto I) { constexpr int j = I; act[j] = (sgl[j] != 0) && (sgl[j] * a[j] - arefl[j] < 0); });
   bool conv = false;
-  real extra[NB];                 // contact forces on the robot dofs (coupled PickAndPlace solve), else 0
-  static_for<NB>([&](auto I) { constexpr int i = I; extra[i] = 0; });
   if constexpr (CPL::enabled) {
     if (__any(CP->any_pad)) {     // wave-uniform: every lane of the wave takes the coupled path (same minimiser)
       MCG_TICK(ST_G0);
-      CP->solve_coupled(build_H, g0, Dl, arefl, sgl, S.qd, a, extra);
+      CP->solve_coupled(build_H, g0, Dl, arefl, sgl, S.qd, a);
       conv = true;
       MCG_TICK(ST_COUPLED);
     }
@@ -826,36 +824,17 @@ MCG_DEV void robot_substep(ModelPtr Pm, Robot& S, real* qlag6, const LS MS, CPL*
   MCG_TICK_PIN(a, NB);
   MCG_TICK(ST_NEWTON);
   // ---- constraint forces -> qfrc_constraint; P10 implicit-damping Euler                  (mj_Euler, mj_advance)
+  // At the minimiser the gradient vanishes: M a = qfrc_smooth + J^T f over ALL rows (equality, limit, weld, contact), so the
+  // right-hand side of (M + hB) a' = qfrc_smooth + qfrc_constraint is M a: no Jacobian is live after the Newton solve.
   real rhs[NB];
-  static_for<NB>([&](auto I) { constexpr int i = I; rhs[i] = fs[i]; });
-  static_for<2>([&](auto Sd) {
-    constexpr int sd = Sd;
-    constexpr int idx[9] = {0, 1, 2, 3, 4, 5, 6 + 2 * sd, 7 + 2 * sd, 10 + sd};
-    static_for<3>([&](auto Kk) {
-      constexpr int k = Kk; constexpr int ncol = (k == 1) ? 6 : 9;
-      real jar = -arefc[sd][k];
-      static_for<ncol>([&](auto A_) { constexpr int c = A_; jar = fma(Jc[sd][k][c], a[idx[c]], jar); });
-      const real force = -Dc[sd] * jar;
-      static_for<ncol>([&](auto A_) { constexpr int c = A_; rhs[idx[c]] = fma(Jc[sd][k][c], force, rhs[idx[c]]); });
-    });
-  });
-  { const real force = -Dj * (a[6] - a[8] - arefj); rhs[6] += force; rhs[8] -= force; }
-  if constexpr (WLD::enabled)
-    static_for<6>([&](auto Rr) { constexpr int r = Rr;
-      real jar = -arefw[r];
-      static_for<6>([&](auto I) { constexpr int j = I; jar = fma(Jw[r][j], a[j], jar); });
-      const real force = -Dw * jar;
-      static_for<6>([&](auto I) { constexpr int j = I; rhs[j] = fma(Jw[r][j], force, rhs[j]); }); });
-  static_for<NB>([&](auto I) { constexpr int i = I; rhs[i] += extra[i]; });
-  static_for<10>([&](auto I) { constexpr int j = I;
-    const real jar = sgl[j] * a[j] - arefl[j];
-    rhs[j] += (sgl[j] != 0 && jar < 0) ? sgl[j] * (-Dl[j] * jar) : 0.0; });
-  MCG_TICK_PIN(rhs, NB);
   MCG_TICK(ST_E_RHS);
   {
     real Mh[NB * (NB + 1) / 2], dinv[NB];
     static_for<NB>([&](auto I) { constexpr int i = I;
       static_for<i + 1>([&](auto Jj) { constexpr int j = Jj; if constexpr (PAT_M.nz[i][j]) Mh[tri(i, j)] = MS.ld(tri(i, j)); }); });
+    static_for<NB>([&](auto I) { constexpr int i = I; real sacc = 0;
+      static_for<NB>([&](auto Jj) { constexpr int j = Jj;
+        if constexpr (PAT_M.nz[i > j ? i : j][i > j ? j : i]) sacc = fma(Mh[tri(i, j)], a[j], sacc); }); rhs[i] = sacc; });
     static_for<NB>([&](auto I) { constexpr int i = I; Mh[tri(i, i)] = fma(h, launder(Pm)->body[i].damping, Mh[tri(i, i)]); });
     ldl_factor<PAT_M>(Mh, dinv);
     ldl_solve<PAT_M>(Mh, dinv, rhs);
