@@ -36,7 +36,7 @@ constexpr real MINVAL = 1e-15, MINIMP = 1e-4, MAXIMP = 0.9999;
 // Opt-in stage clocks (-DMCG_STAGE_CLOCKS, development builds only; tools/stage_clocks.py): lane 0 of each wave
 // accumulates shader-clock deltas per pipeline stage in LDS and adds them to a device-global table at kernel end.
 enum { ST_LOAD = 0, ST_CTRL, ST_TRIG, ST_RNE, ST_ACT, ST_CRB, ST_ROWS, ST_G0, ST_NEWTON, ST_EULER, ST_COLLIDE, ST_CUBE,
-       ST_COUPLED, ST_CUBE_FIN, ST_POST, ST_N_BUILD, ST_N_FACTOR, ST_N_SOLVE, ST_N_CHECK, ST_E_RHS, ST_COUNT,
+       ST_COUPLED, ST_CUBE_FIN, ST_POST, ST_N_BUILD, ST_N_FACTOR, ST_N_SOLVE, ST_N_CHECK, ST_E_RHS, ST_R_AX5, ST_R_CONNECT, ST_R_LIMITS, ST_COUNT,
        CN_SUBSTEP = 0, CN_NEWTON_IT, CN_LINESEARCH, CN_CUBE_IT, CN_CUBE_LS, CN_COUPLED, CN_COUPLED_IT, CN_COUPLED_LS, CN_CONTACTS, CN_COUNT };
 #ifdef MCG_STAGE_CLOCKS
 __device__ unsigned long long g_stage_clocks[ST_COUNT + CN_COUNT];      // stage clocks, then event counts (per wave)
@@ -202,7 +202,7 @@ constexpr bool is_ancestor_or_self(int a, int i) {       // a on the path from i
   while (i >= 0) { if (i == a) return true; i = PAR[i]; }
   return false;
 }
-constexpr Pattern symbolic(bool with_constraints) {
+constexpr Pattern symbolic(bool with_constraints, bool fill = true) {
   Pattern P{};
   for (int i = 0; i < NB; i++) for (int j = 0; j <= i; j++) P.nz[i][j] = is_ancestor_or_self(j, i);
   if (with_constraints) {
@@ -214,6 +214,7 @@ constexpr Pattern symbolic(bool with_constraints) {
     for (int g = 0; g < 2; g++) for (int a = 0; a < 3; a++) for (int j = 0; j < 6; j++) P.nz[grp[g][a]][j] = true;
     P.nz[8][6] = true;
   }
+  if (!fill) return P;
   for (int k = NB - 1; k >= 0; k--)                      // fill-in of the leaves-first elimination
     for (int i = 0; i < k; i++) if (P.nz[k][i])
       for (int j = 0; j <= i; j++) if (P.nz[k][j]) P.nz[i][j] = true;
@@ -230,6 +231,7 @@ constexpr Pattern symbolic_grasp() {          // H plus the cross terms a cube p
 }
 constexpr Pattern PAT_M = symbolic(false);
 constexpr Pattern PAT_H = symbolic(true);
+constexpr Pattern PAT_E = symbolic(true, false);          // M + J^T D J over the equality rows, before fill-in
 constexpr Pattern PAT_G = symbolic_grasp();
 
 // in place on the packed lower triangle: A = L^T D L, L unit lower (stored below the diagonal), dinv = 1 / D
@@ -328,7 +330,9 @@ struct Robot {
 // Per-lane scratch in LDS: slot k of this lane lives at base[k * 64] (lane-contiguous rows: conflict-free
 // ds_read_b64 / ds_write_b64 with immediate offsets).  The joint-space inertia M is kept here between the stages
 // that consume it, so that only one 12x12 system occupies registers at a time.
-constexpr int LDS_SLOTS = NB * (NB + 1) / 2;
+constexpr int LDS_M = 0;                              // packed lower triangle of M                     (78 slots)
+constexpr int LDS_HEQ = NB * (NB + 1) / 2;            // H_eq = M + J^T D J over the equality (and weld) rows  (78 slots)
+constexpr int LDS_SLOTS = 2 * (NB * (NB + 1) / 2);
 // The lane's LDS column.  The pointer carries the LDS address space explicitly: passed through structs as a generic
 // pointer the accesses degrade to flat_load/flat_store with 64-bit address arithmetic instead of ds_read/ds_write
 // with immediate offsets.
@@ -584,6 +588,8 @@ MCG_DEV void robot_substep(ModelPtr Pm, Robot& S, real* qlag6, const LS MS, CPL*
       for (int k = 0; k < 3; k++) ax5[i][k] = t[k];
     });
   });
+  MCG_TICK_PIN(ax5[0], 3); MCG_TICK_PIN(ax5[1], 3); MCG_TICK_PIN(ax5[2], 3); MCG_TICK_PIN(ax5[3], 3); MCG_TICK_PIN(ax5[4], 3);
+  MCG_TICK(ST_R_AX5);
   // two connects; side 0: gear 6 / finger 7 / hinge 10, side 1: gear 8 / finger 9 / hinge 11.
   // Jc[sd][row][col], cols = arm 0..5, gear, finger, hinge; the y row has no gripper entries (planar mechanism).
   real Jc[2][3][9];
@@ -631,6 +637,8 @@ MCG_DEV void robot_substep(ModelPtr Pm, Robot& S, real* qlag6, const LS MS, CPL*
     Dj = imp * rcp_nr(fmax(MINVAL * imp, (1 - imp) * Q->eq_diag[2]));
     arefj = -par[1] * (S.qd[6] - S.qd[8]) - par[0] * imp * pos;
   }
+  MCG_TICK_PIN(&Dj, 1); MCG_TICK_PIN(&arefj, 1);
+  MCG_TICK(ST_R_CONNECT);
   // joint limits on dofs 0..9: a row exists while violated; sign = d(dist)/dq.
   // Control flow is wave-uniform (__any) with per-lane selects: hipcc (ROCm 7.2) places spill stores of values
   // merged after a lane-divergent region BEFORE the exec mask is restored, silently dropping lanes (see DESIGN.md
@@ -655,6 +663,7 @@ MCG_DEV void robot_substep(ModelPtr Pm, Robot& S, real* qlag6, const LS MS, CPL*
   });
   static_for<10>([&](auto I) { constexpr int j = I; pin(Dl[j]); pin(arefl[j]); pin(sgl[j]); });
   MCG_FENCE();
+  MCG_TICK(ST_R_LIMITS);
 
   // mocap weld: rows 0-2 position (mocap point - weld point), rows 3-5 orientation torquescale * imag(neg(q_tcp) q_m relquat);
   // Jacobian = -(jac of the weld point), its rotational part mapped through 0.5 neg(q_tcp) (.) q_m relquat; arm dofs only.
@@ -711,27 +720,46 @@ MCG_DEV void robot_substep(ModelPtr Pm, Robot& S, real* qlag6, const LS MS, CPL*
   if constexpr (WLD::enabled)
     static_for<6>([&](auto Rr) { constexpr int r = Rr; const real da = Dw * arefw[r];
       static_for<6>([&](auto I) { constexpr int j = I; g0[j] = fma(Jw[r][j], da, g0[j]); }); });
-  // H = M + J^T D J (equality rows) + active limit rows, assembled from LDS-resident M for each Newton iteration
-  auto build_H = [&](real* H, const bool* act_) {
-    static_for<NB>([&](auto I) { constexpr int i = I;
-      static_for<i + 1>([&](auto Jj) { constexpr int j = Jj;
-        if constexpr (PAT_M.nz[i][j]) H[tri(i, j)] = MS.ld(tri(i, j));
-        else if constexpr (PAT_H.nz[i][j]) H[tri(i, j)] = 0.0; }); });
-    static_for<2>([&](auto Sd) {
-      constexpr int sd = Sd;
-      constexpr int idx[9] = {0, 1, 2, 3, 4, 5, 6 + 2 * sd, 7 + 2 * sd, 10 + sd};
-      static_for<3>([&](auto Kk) {
-        constexpr int k = Kk; constexpr int ncol = (k == 1) ? 6 : 9;
-        static_for<ncol>([&](auto A_) { constexpr int a = A_;
-          const real ja = Dc[sd] * Jc[sd][k][a];
-          static_for<a + 1>([&](auto B_) { constexpr int b = B_; H[tri(idx[a], idx[b])] = fma(ja, Jc[sd][k][b], H[tri(idx[a], idx[b])]); }); });
-      });
-    });
-    H[tri(6, 6)] += Dj; H[tri(8, 8)] += Dj; H[tri(8, 6)] -= Dj;
+  // H_eq = M + J^T D J over the equality rows (two connects, gear coupling, mocap weld) is assembled ONCE per sub-step,
+  // group by group (arm block, then each side's gripper rows: at most 24 accumulators live), and parked in LDS next to M.
+  // The connect / weld Jacobians are dead from here on: the Newton iterations and the line search read H_eq back and add the
+  // active limit rows' diagonal, the Euler step needs M only.
+  {
+    real acc[21];
+    static_for<6>([&](auto A_) { constexpr int a = A_;
+      static_for<a + 1>([&](auto B_) { constexpr int b = B_; acc[tri(a, b)] = MS.ld(LDS_M + tri(a, b)); }); });
+    static_for<2>([&](auto Sd) { constexpr int sd = Sd;
+      static_for<3>([&](auto Kk) { constexpr int k = Kk;
+        static_for<6>([&](auto A_) { constexpr int a = A_; const real ja = Dc[sd] * Jc[sd][k][a];
+          static_for<a + 1>([&](auto B_) { constexpr int b = B_; acc[tri(a, b)] = fma(ja, Jc[sd][k][b], acc[tri(a, b)]); }); }); }); });
     if constexpr (WLD::enabled)
       static_for<6>([&](auto Rr) { constexpr int r = Rr;
         static_for<6>([&](auto A_) { constexpr int a = A_; const real ja = Dw * Jw[r][a];
-          static_for<a + 1>([&](auto B_) { constexpr int b = B_; H[tri(a, b)] = fma(ja, Jw[r][b], H[tri(a, b)]); }); }); });
+          static_for<a + 1>([&](auto B_) { constexpr int b = B_; acc[tri(a, b)] = fma(ja, Jw[r][b], acc[tri(a, b)]); }); }); });
+    static_for<6>([&](auto A_) { constexpr int a = A_;
+      static_for<a + 1>([&](auto B_) { constexpr int b = B_; MS.st(LDS_HEQ + tri(a, b), acc[tri(a, b)]); }); });
+  }
+  static_for<2>([&](auto Sd) {
+    constexpr int sd = Sd;
+    constexpr int idx[9] = {0, 1, 2, 3, 4, 5, 6 + 2 * sd, 7 + 2 * sd, 10 + sd};
+    static_for<3>([&](auto Ga) {                         // rows gear, finger, hinge of this side: columns 0 .. own index
+      constexpr int a = 6 + Ga; constexpr int i = idx[a];
+      real row[9];
+      static_for<a + 1>([&](auto B_) { constexpr int b = B_; constexpr int j = idx[b];
+        if constexpr (PAT_M.nz[i][j]) row[b] = MS.ld(LDS_M + tri(i, j)); else row[b] = 0.0; });
+      static_for<2>([&](auto Kk) { constexpr int k = 2 * Kk;            // the y row has no gripper entries
+        const real ja = Dc[sd] * Jc[sd][k][a];
+        static_for<a + 1>([&](auto B_) { constexpr int b = B_; row[b] = fma(ja, Jc[sd][k][b], row[b]); }); });
+      if constexpr (a == 6) row[6] += Dj;                               // gear coupling q6 - q8: +Dj on (6,6), (8,8)
+      static_for<a + 1>([&](auto B_) { constexpr int b = B_; MS.st(LDS_HEQ + tri(i, idx[b]), row[b]); });
+    });
+  });
+  MS.st(LDS_HEQ + tri(8, 6), -Dj);                                      // ... and -Dj on (8,6) (structurally zero in M)
+  auto build_H = [&](real* H, const bool* act_) {
+    static_for<NB>([&](auto I) { constexpr int i = I;
+      static_for<i + 1>([&](auto Jj) { constexpr int j = Jj;
+        if constexpr (PAT_E.nz[i][j]) H[tri(i, j)] = MS.ld(LDS_HEQ + tri(i, j));
+        else if constexpr (PAT_H.nz[i][j]) H[tri(i, j)] = 0.0; }); });
     static_for<10>([&](auto I) { constexpr int j = I; H[tri(j, j)] += act_[j] ? Dl[j] : 0.0; });
   };
 
@@ -831,7 +859,7 @@ MCG_DEV void robot_substep(ModelPtr Pm, Robot& S, real* qlag6, const LS MS, CPL*
   {
     real Mh[NB * (NB + 1) / 2], dinv[NB];
     static_for<NB>([&](auto I) { constexpr int i = I;
-      static_for<i + 1>([&](auto Jj) { constexpr int j = Jj; if constexpr (PAT_M.nz[i][j]) Mh[tri(i, j)] = MS.ld(tri(i, j)); }); });
+      static_for<i + 1>([&](auto Jj) { constexpr int j = Jj; if constexpr (PAT_M.nz[i][j]) Mh[tri(i, j)] = MS.ld(LDS_M + tri(i, j)); }); });
     static_for<NB>([&](auto I) { constexpr int i = I; real sacc = 0;
       static_for<NB>([&](auto Jj) { constexpr int j = Jj;
         if constexpr (PAT_M.nz[i > j ? i : j][i > j ? j : i]) sacc = fma(Mh[tri(i, j)], a[j], sacc); }); rhs[i] = sacc; });

@@ -12,9 +12,10 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 import torch
 from mycobotgym_amd import MyCobotVecEnv, _abi
 
-NAMES = ["load", "controller", "sincos", "rne", "actuation", "crb->M", "constraint rows", "g0", "newton: other (setup, line search)", "euler: factor M+hB, solve, integrate",
+NAMES = ["load", "controller", "sincos", "rne", "actuation", "crb->M", "rows: weld / rest", "g0", "newton: other (setup, line search)", "euler: factor M+hB, solve, integrate",
          "collide", "cube solve", "coupled solve", "cube finish", "post (obs/reward/reset/store)",
-         "newton: build H", "newton: factor H", "newton: solve", "newton: active-set check", "euler: forces/rhs"]
+         "newton: build H", "newton: factor H", "newton: solve", "newton: active-set check", "euler: forces/rhs",
+         "rows: arm axes in link6 frame", "rows: connects + coupling", "rows: limits"]
 COUNTS = ["robot sub-steps", "robot Newton iterations", "robot line searches", "cube Newton iterations", "cube line searches",
           "coupled solves", "coupled Newton iterations", "coupled line searches", "wave-max contacts (per collision pass)"]
 fresh = "--fresh-actions" in sys.argv
