@@ -163,7 +163,8 @@ def main():
         if os.path.exists(pmc):
             with open(pmc) as f:
                 pj = json.load(f)
-            if pj.get("controller") == args.controller and pj.get("n_envs") == n and pj.get("task", "reach") == args.task:
+            if (pj.get("controller") == args.controller and pj.get("n_envs") == n and pj.get("task", "reach") == args.task
+                    and not args.scripted_grasp):       # the counters were collected on the default workload of this task
                 traffic = pj.get("hbm_bytes_per_launch"); src = "profiles/" + os.path.basename(pmc) + ": " + pj.get("note", "")
                 flops = pj.get("f64_flops_per_launch")
         out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
