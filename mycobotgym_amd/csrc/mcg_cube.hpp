@@ -526,143 +526,200 @@ struct CubeSys {
   }
 
   // --------------------------------------------------------------- coupled robot + cube Newton (a pad touches the cube)
-  // Unknowns a_r (12) and a_c (6).  Per iteration the cube block is eliminated (Schur complement), so the robot
-  // system stays a sparse 12x12 (pattern PAT_G) in registers.  Rows: joint limits, table-cube and pad-cube pyramids.
+  // Unknowns a_r (12) and a_c (6).  Per iteration the cube block is eliminated (Schur complement), so the robot system
+  // stays a sparse 12x12 (pattern PAT_G).  Rows: joint limits, table-cube and pad-cube pyramids.
+  //
+  // Register budget rules the layout: the robot block G (78) and the coupling block Cm (10 x 6) are ACCUMULATED IN LDS, in
+  // the line-search row area (free until the consistency pass rewrites it), by read-modify-write per contact; a contact's
+  // 6 pyramid rows enter through the basis [Jn J1 J2 Jt] and a 4x4 arrow matrix W as in solve_alone.  Only the cube block
+  // Hc (21) and the right-hand sides stay in registers.  The Schur complement uses Hc = L D L^T and keeps W_i = L^-1 Cm_i
+  // in place of Cm_i: S = G - sum_d W_i[d] W_j[d] / D[d].
+  static constexpr int GA = LDS_ROW, CM = LDS_ROW + NB * (NB + 1) / 2;
+  static_assert(NB * (NB + 1) / 2 + 60 <= MAXCON * 12, "G and Cm must fit in the line-search row area");
+  struct Coupled {                 // one contact, as the coupled solve sees it
+    CubeRows RC; PadRows RP;
+    real D, kterm, Bc, mu[3];
+    int type, side, mask; bool pad;
+  };
+  MCG_DEV void contact_of(int c, Coupled& K) const {
+    const int b = LDS_CON + c * CON_STRIDE;
+    K.type = sel((c < ncon), (int)S.ld(b + 15), 0);
+    K.D = sel((c < ncon), S.ld(b + 13), 0.0); K.kterm = S.ld(b + 14);
+    K.mask = sel((c < ncon), (int)S.ld(LDS_ACT + c), 0);
+    K.pad = K.type != PAIR_TABLE_CUBE;
+    K.side = sel(K.type == PAIR_PADL_CUBE, 1, 0);
+    rows_cube(c, K.RC);
+    rows_pad(c, K.side, K.RP);
+    if (!K.pad) _Pragma("unroll") for (int j = 0; j < 8; j++) { K.RP.Jn[j] = 0; K.RP.J1[j] = 0; K.RP.J2[j] = 0; K.RP.Jt[j] = 0; }
+    _Pragma("unroll") for (int k = 0; k < 3; k++) K.mu[k] = sel(K.pad, mu_pc[k], mu_tc[k]);
+    K.Bc = sel(K.pad, B_pc, B_tc);
+  }
+  // the four basis dot products of a contact with a (cube 6-vector, robot 8-vector of the contact's side)
+  MCG_DEV static void bdots(const Coupled& K, const real* vc, const real* v8, real* o) {
+    o[0] = o[1] = o[2] = o[3] = 0;
+    _Pragma("unroll") for (int d = 0; d < 6; d++) { o[0] = fma(K.RC.Jn[d], vc[d], o[0]); o[1] = fma(K.RC.J1[d], vc[d], o[1]); o[2] = fma(K.RC.J2[d], vc[d], o[2]); o[3] = fma(K.RC.Jt[d], vc[d], o[3]); }
+    _Pragma("unroll") for (int j = 0; j < 8; j++) { o[0] = fma(K.RP.Jn[j], v8[j], o[0]); o[1] = fma(K.RP.J1[j], v8[j], o[1]); o[2] = fma(K.RP.J2[j], v8[j], o[2]); o[3] = fma(K.RP.Jt[j], v8[j], o[3]); }
+  }
+  MCG_DEV static void gather8(const real* v, int side, real* o) {   // arm 0..5, then gear / finger of the side
+    _Pragma("unroll") for (int j = 0; j < 6; j++) o[j] = v[j];
+    o[6] = sel(side, v[8], v[6]); o[7] = sel(side, v[9], v[7]);
+  }
+
   template <class BuildH>
   MCG_DEV void solve_coupled(BuildH& build_H, const real* g0, const real* Dl, const real* arefl, const real* sgl,
                              const real* qdr, real* ar) {
     derive(model());
-    // dof slot of (side, j): arm j -> j; gear -> 6 + 2 side; finger -> 7 + 2 side.  Gather helpers with selects:
-    auto gather8 = [](const real* v, int side, real* o) {
-      _Pragma("unroll") for (int j = 0; j < 6; j++) o[j] = v[j];
-      o[6] = sel(side, v[8], v[6]); o[7] = sel(side, v[9], v[7]);
-    };
-    auto contact_rows = [&](int c, CubeRows& RC, PadRows& RP, int& type, real& D, real& kterm) {
-      const int b = LDS_CON + c * CON_STRIDE;
-      type = sel((c < ncon), (int)S.ld(b + 15), 0);
-      D = sel((c < ncon), S.ld(b + 13), 0.0); kterm = S.ld(b + 14);
-      rows_cube(c, RC);
-      rows_pad(c, type == PAIR_PADL_CUBE ? 1 : 0, RP);
-      if (type == PAIR_TABLE_CUBE) _Pragma("unroll") for (int j = 0; j < 8; j++) { RP.Jn[j] = 0; RP.J1[j] = 0; RP.J2[j] = 0; RP.Jt[j] = 0; }
-    };
     real ac[6];
     _Pragma("unroll") for (int k = 0; k < 6; k++) ac[k] = a_c[k];
     bool actl[10];
     _Pragma("unroll") for (int j = 0; j < 10; j++) actl[j] = (sgl[j] != 0) && (sgl[j] * ar[j] - arefl[j] < 0);
-    bool any_lim = false;
-    _Pragma("unroll") for (int j = 0; j < 10; j++) any_lim = any_lim || (sgl[j] != 0);
     // initial contact masks
     for (int c = 0; __any(c < ncon); c++) {
-      CubeRows RC; PadRows RP; int type; real D, kterm;
-      contact_rows(c, RC, RP, type, D, kterm);
-      const int side = sel(type == PAIR_PADL_CUBE, 1, 0);
-      const bool tb_ = type == PAIR_TABLE_CUBE; const real mu[3] = {sel(tb_, mu_tc[0], mu_pc[0]), sel(tb_, mu_tc[1], mu_pc[1]), sel(tb_, mu_tc[2], mu_pc[2])}; const real Bc = sel(type == PAIR_TABLE_CUBE, B_tc, B_pc);
-      real a8[8], v8[8]; gather8(ar, side, a8); gather8(qdr, side, v8);
+      Coupled K; contact_of(c, K);
+      real a8[8], v8[8], da[4], dv[4];
+      gather8(ar, K.side, a8); gather8(qdr, K.side, v8);
+      bdots(K, ac, a8, da); bdots(K, Cb.vel, v8, dv);
       int mask = 0;
-      _Pragma("unroll") for (int r = 0; r < 6; r++) {
-        real jc[6], jr[8]; pyramid_row(RC, r, mu, jc); pyr8(RP, r, mu, jr);
-        real ja = 0, jv = 0;
-        _Pragma("unroll") for (int d = 0; d < 6; d++) { ja += jc[d] * ac[d]; jv += jc[d] * Cb.vel[d]; }
-        _Pragma("unroll") for (int d = 0; d < 8; d++) { ja += jr[d] * a8[d]; jv += jr[d] * v8[d]; }
-        mask |= (ja - (-Bc * jv - kterm) < 0) ? (1 << r) : 0;
-      }
+      static_for<3>([&](auto Kk) { constexpr int k = Kk; const real m = K.mu[k];
+        const real arp = -K.Bc * fma(m, dv[1 + k], dv[0]) - K.kterm, arm = -K.Bc * fma(-m, dv[1 + k], dv[0]) - K.kterm;
+        mask |= (fma(m, da[1 + k], da[0]) - arp < 0 ? (1 << (2 * k)) : 0) | (fma(-m, da[1 + k], da[0]) - arm < 0 ? (1 << (2 * k + 1)) : 0); });
       if (c < ncon) S.st(LDS_ACT + c, (real)mask);
     }
     bool conv = false;
     real xr[NB], xc[6];
+    MCG_TICK(ST_C_MASK);
     MCG_COUNT(CN_COUPLED);
     for (int it = 0; it < 50; it++) {
       MCG_COUNT(CN_COUPLED_IT);
-      real G[NB * (NB + 1) / 2], dinv[NB], gr[NB];
-      {
+      real gr[NB];
+      {   // G <- H_eq + active limit rows, parked in LDS; Cm <- 0
         real L[NB * (NB + 1) / 2];
         build_H(L, actl);
         static_for<NB>([&](auto I) { constexpr int i = I; static_for<i + 1>([&](auto Jj) { constexpr int j = Jj;
-          if constexpr (PAT_H.nz[i][j]) G[tri(i, j)] = L[tri(i, j)]; else if constexpr (PAT_G.nz[i][j]) G[tri(i, j)] = 0.0; }); });
+          if constexpr (PAT_H.nz[i][j]) S.st(GA + tri(i, j), L[tri(i, j)]); else if constexpr (PAT_G.nz[i][j]) S.st(GA + tri(i, j), 0.0); }); });
+        _Pragma("unroll") for (int k = 0; k < 60; k++) S.st(CM + k, 0.0);
       }
       for (int i = 0; i < NB; i++) gr[i] = g0[i];
       _Pragma("unroll") for (int j = 0; j < 10; j++) gr[j] += actl[j] ? sgl[j] * Dl[j] * arefl[j] : 0.0;
-      real Hc[21], gc[6], Cm[10][6];                 // Cm rows: arm 0..5, gear R, finger R, gear L, finger L
+      real Hc[21], gc[6];
       _Pragma("unroll") for (int k = 0; k < 21; k++) Hc[k] = 0;
       _Pragma("unroll") for (int k = 0; k < 6; k++) { Hc[tri(k, k)] = Md[k]; gc[k] = fs[k]; }
-      _Pragma("unroll") for (int i = 0; i < 10; i++) for (int d = 0; d < 6; d++) Cm[i][d] = 0;
       for (int c = 0; __any(c < ncon); c++) {
-        CubeRows RC; PadRows RP; int type; real D, kterm;
-        contact_rows(c, RC, RP, type, D, kterm);
-        const int side = sel(type == PAIR_PADL_CUBE, 1, 0);
-        const bool tb_ = type == PAIR_TABLE_CUBE; const real mu[3] = {sel(tb_, mu_tc[0], mu_pc[0]), sel(tb_, mu_tc[1], mu_pc[1]), sel(tb_, mu_tc[2], mu_pc[2])}; const real Bc = sel(type == PAIR_TABLE_CUBE, B_tc, B_pc);
-        const int mask = sel((c < ncon), (int)S.ld(LDS_ACT + c), 0);
-        real v8[8]; gather8(qdr, side, v8);
-        _Pragma("unroll") for (int r = 0; r < 6; r++) {
-          real jc[6], jr[8]; pyramid_row(RC, r, mu, jc); pyr8(RP, r, mu, jr);
-          real jv = 0;
-          _Pragma("unroll") for (int d = 0; d < 6; d++) jv += jc[d] * Cb.vel[d];
-          _Pragma("unroll") for (int d = 0; d < 8; d++) jv += jr[d] * v8[d];
-          const real aref = -Bc * jv - kterm;
-          const real w = ((mask >> r) & 1) ? D : 0.0;
-          const real wR = side ? 0.0 : w, wL = sel(side, w, 0.0);
-          _Pragma("unroll") for (int d = 0; d < 6; d++) { const real wj = w * jc[d]; gc[d] += wj * aref; for (int e = 0; e <= d; e++) Hc[tri(d, e)] += wj * jc[e]; }
-          // robot-robot block: arm x arm, arm x (gear, finger) of the side, (gear, finger) block; coupling Cm; g_r
-          static_for<6>([&](auto A_) { constexpr int a = A_;
-            const real wj = w * jr[a];
-            gr[a] += wj * aref;
-            static_for<a + 1>([&](auto B_) { constexpr int b = B_; G[tri(a, b)] += wj * jr[b]; });
-            _Pragma("unroll") for (int d = 0; d < 6; d++) Cm[a][d] += wj * jc[d]; });
-          {
-            const real gR = wR * jr[6], fR = wR * jr[7], gL = wL * jr[6], fL = wL * jr[7];
-            gr[6] += gR * aref; gr[7] += fR * aref; gr[8] += gL * aref; gr[9] += fL * aref;
-            static_for<6>([&](auto B_) { constexpr int b = B_;
-              G[tri(6, b)] += gR * jr[b]; G[tri(7, b)] += fR * jr[b]; G[tri(8, b)] += gL * jr[b]; G[tri(9, b)] += fL * jr[b]; });
-            G[tri(6, 6)] += gR * jr[6]; G[tri(7, 6)] += fR * jr[6]; G[tri(7, 7)] += fR * jr[7];
-            G[tri(8, 8)] += gL * jr[6]; G[tri(9, 8)] += fL * jr[6]; G[tri(9, 9)] += fL * jr[7];
-            _Pragma("unroll") for (int d = 0; d < 6; d++) { Cm[6][d] += gR * jc[d]; Cm[7][d] += fR * jc[d]; Cm[8][d] += gL * jc[d]; Cm[9][d] += fL * jc[d]; }
+        Coupled K; contact_of(c, K);
+        real W00 = 0, t0 = 0, W0[3], Wd[3], t[3];
+        {
+          real v8[8], dv[4]; gather8(qdr, K.side, v8); bdots(K, Cb.vel, v8, dv);
+          static_for<3>([&](auto Kk) { constexpr int k = Kk; const real m = K.mu[k];
+            const real arp = -K.Bc * fma(m, dv[1 + k], dv[0]) - K.kterm, arm = -K.Bc * fma(-m, dv[1 + k], dv[0]) - K.kterm;
+            const real wp = sel(((K.mask >> (2 * k)) & 1) != 0, K.D, 0.0), wm = sel(((K.mask >> (2 * k + 1)) & 1) != 0, K.D, 0.0);
+            W00 += wp + wm; t0 = fma(wp, arp, fma(wm, arm, t0));
+            W0[k] = m * (wp - wm); Wd[k] = m * m * (wp + wm); t[k] = m * (wp * arp - wm * arm); });
+        }
+        // U_b = sum_b' W_bb' B_b' on the cube part (6) and the robot part (8)
+        real Uc[4][6];
+        _Pragma("unroll") for (int d = 0; d < 6; d++) {
+          Uc[0][d] = W00 * K.RC.Jn[d] + W0[0] * K.RC.J1[d] + W0[1] * K.RC.J2[d] + W0[2] * K.RC.Jt[d];
+          Uc[1][d] = W0[0] * K.RC.Jn[d] + Wd[0] * K.RC.J1[d];
+          Uc[2][d] = W0[1] * K.RC.Jn[d] + Wd[1] * K.RC.J2[d];
+          Uc[3][d] = W0[2] * K.RC.Jn[d] + Wd[2] * K.RC.Jt[d];
+          gc[d] += K.RC.Jn[d] * t0 + K.RC.J1[d] * t[0] + K.RC.J2[d] * t[1] + K.RC.Jt[d] * t[2];
+        }
+        static_for<6>([&](auto Dd) { constexpr int d = Dd; static_for<d + 1>([&](auto Ee) { constexpr int e = Ee;
+          Hc[tri(d, e)] += K.RC.Jn[d] * Uc[0][e] + K.RC.J1[d] * Uc[1][e] + K.RC.J2[d] * Uc[2][e] + K.RC.Jt[d] * Uc[3][e]; }); });
+        if (__any(K.pad && c < ncon)) {          // wave-uniform: a table contact has no robot rows
+          real Ur[4][8];
+          _Pragma("unroll") for (int j = 0; j < 8; j++) {
+            Ur[0][j] = W00 * K.RP.Jn[j] + W0[0] * K.RP.J1[j] + W0[1] * K.RP.J2[j] + W0[2] * K.RP.Jt[j];
+            Ur[1][j] = W0[0] * K.RP.Jn[j] + Wd[0] * K.RP.J1[j];
+            Ur[2][j] = W0[1] * K.RP.Jn[j] + Wd[1] * K.RP.J2[j];
+            Ur[3][j] = W0[2] * K.RP.Jn[j] + Wd[2] * K.RP.Jt[j];
           }
+          const int gear = 6 + 2 * K.side, fing = 7 + 2 * K.side;                 // dof of local 6 / 7
+          const int rowoff[2] = {gear * (gear + 1) / 2, fing * (fing + 1) / 2};
+          static_for<8>([&](auto Ii) { constexpr int i = Ii;
+            const real gl = K.RP.Jn[i] * t0 + K.RP.J1[i] * t[0] + K.RP.J2[i] * t[1] + K.RP.Jt[i] * t[2];
+            if constexpr (i < 6) gr[i] += gl;
+            else if constexpr (i == 6) { gr[6] += sel(K.side, 0.0, gl); gr[8] += sel(K.side, gl, 0.0); }
+            else { gr[7] += sel(K.side, 0.0, gl); gr[9] += sel(K.side, gl, 0.0); }
+            // robot block, lower triangle in the contact's local order (arm 0..5, gear, finger: increasing dof index)
+            static_for<i + 1>([&](auto Jj) { constexpr int j = Jj;
+              const real v = K.RP.Jn[i] * Ur[0][j] + K.RP.J1[i] * Ur[1][j] + K.RP.J2[i] * Ur[2][j] + K.RP.Jt[i] * Ur[3][j];
+              int k;
+              if constexpr (i < 6) k = GA + tri(i, j);
+              else k = GA + rowoff[i - 6] + (j < 6 ? j : (j == 6 ? gear : fing));
+              S.st(k, S.ld(k) + v); });
+            // coupling block Cm[dof i][cube d]
+            const int slot = (i < 6) ? i : (i == 6 ? gear : fing);
+            static_for<6>([&](auto Dd) { constexpr int d = Dd;
+              const real v = K.RP.Jn[i] * Uc[0][d] + K.RP.J1[i] * Uc[1][d] + K.RP.J2[i] * Uc[2][d] + K.RP.Jt[i] * Uc[3][d];
+              const int k = CM + slot * 6 + d;
+              S.st(k, S.ld(k) + v); }); });
         }
       }
-      // Schur complement on the cube block: S = G - Cm Hc^-1 Cm^T, rhs = gr - Cm Hc^-1 gc
-      chol_factor<6>(Hc);
-      real T[10][6], ygc[6];
-      _Pragma("unroll") for (int d = 0; d < 6; d++) ygc[d] = gc[d];
-      chol_solve<6>(Hc, ygc);
-      static_for<10>([&](auto I) { constexpr int i = I;
-        _Pragma("unroll") for (int d = 0; d < 6; d++) T[i][d] = Cm[i][d];
-        chol_solve<6>(Hc, T[i]);
-        real sdot = 0; _Pragma("unroll") for (int d = 0; d < 6; d++) sdot += Cm[i][d] * ygc[d];
+      MCG_TICK_PIN(gr, NB); MCG_TICK_PIN(gc, 6);
+      MCG_TICK(ST_C_ASSEMBLE);
+      // Schur complement on the cube block: Hc = L D L^T, W_i = L^-1 Cm_i (kept in place of Cm_i)
+      real dinvc[6], yl[6];
+      spd_factor<6>(Hc, dinvc);
+      _Pragma("unroll") for (int d = 0; d < 6; d++) yl[d] = gc[d];
+      spd_forward<6>(Hc, yl);
+      static_for<10>([&](auto Ii) { constexpr int i = Ii;
+        real w[6];
+        _Pragma("unroll") for (int d = 0; d < 6; d++) w[d] = S.ld(CM + i * 6 + d);
+        spd_forward<6>(Hc, w);
+        real sdot = 0;
+        _Pragma("unroll") for (int d = 0; d < 6; d++) { S.st(CM + i * 6 + d, w[d]); sdot = fma(w[d] * dinvc[d], yl[d], sdot); }
         gr[i] -= sdot; });
-      static_for<10>([&](auto I) { constexpr int i = I; static_for<i + 1>([&](auto Jj) { constexpr int j = Jj;
-        real sdot = 0; _Pragma("unroll") for (int d = 0; d < 6; d++) sdot += Cm[i][d] * T[j][d];
-        G[tri(i, j)] -= sdot; }); });
+      real G[NB * (NB + 1) / 2], dinv[NB];
+      static_for<NB>([&](auto I) { constexpr int i = I; static_for<i + 1>([&](auto Jj) { constexpr int j = Jj;
+        if constexpr (PAT_G.nz[i][j]) G[tri(i, j)] = S.ld(GA + tri(i, j)); }); });
+      static_for<10>([&](auto Ii) { constexpr int i = Ii;
+        real wi[6];
+        _Pragma("unroll") for (int d = 0; d < 6; d++) wi[d] = S.ld(CM + i * 6 + d) * dinvc[d];
+        static_for<i + 1>([&](auto Jj) { constexpr int j = Jj;
+          real sdot = 0;
+          _Pragma("unroll") for (int d = 0; d < 6; d++) sdot = fma(wi[d], S.ld(CM + j * 6 + d), sdot);
+          G[tri(i, j)] -= sdot; }); });
       for (int i = 0; i < NB; i++) xr[i] = gr[i];
+      MCG_TICK_PIN(xr, NB);
+      MCG_TICK(ST_C_SCHUR);
       ldl_factor<PAT_G>(G, dinv);
       ldl_solve<PAT_G>(G, dinv, xr);
-      _Pragma("unroll") for (int d = 0; d < 6; d++) { real sdot = 0; static_for<10>([&](auto I) { constexpr int i = I; sdot += T[i][d] * xr[i]; }); xc[d] = ygc[d] - sdot; }
+      {   // x_c = L^-T D^-1 (L^-1 g_c - sum_i W_i x_r[i])
+        real z[6];
+        _Pragma("unroll") for (int d = 0; d < 6; d++) z[d] = yl[d];
+        static_for<10>([&](auto Ii) { constexpr int i = Ii;
+          _Pragma("unroll") for (int d = 0; d < 6; d++) z[d] = fma(-S.ld(CM + i * 6 + d), xr[i], z[d]); });
+        _Pragma("unroll") for (int d = 0; d < 6; d++) z[d] *= dinvc[d];
+        spd_backward<6>(Hc, z);
+        _Pragma("unroll") for (int d = 0; d < 6; d++) xc[d] = z[d];
+      }
+      MCG_TICK_PIN(xr, NB); MCG_TICK_PIN(xc, 6);
+      MCG_TICK(ST_C_SOLVE);
       // consistency of the assumed active set at (xr, xc); r0 / dr of every contact row for the line search
+      // (from here on the row area of LDS holds line-search rows again: G and W are dead)
       real pr[NB], pc[6];
       for (int i = 0; i < NB; i++) pr[i] = xr[i] - ar[i];
       _Pragma("unroll") for (int d = 0; d < 6; d++) pc[d] = xc[d] - ac[d];
       bool same = true;
       _Pragma("unroll") for (int j = 0; j < 10; j++) { const bool now = (sgl[j] != 0) && (sgl[j] * xr[j] - arefl[j] < 0); same = same && (now == actl[j]); }
       for (int c = 0; __any(c < ncon); c++) {
-        CubeRows RC; PadRows RP; int type; real D, kterm;
-        contact_rows(c, RC, RP, type, D, kterm);
-        const int side = sel(type == PAIR_PADL_CUBE, 1, 0);
-        const bool tb_ = type == PAIR_TABLE_CUBE; const real mu[3] = {sel(tb_, mu_tc[0], mu_pc[0]), sel(tb_, mu_tc[1], mu_pc[1]), sel(tb_, mu_tc[2], mu_pc[2])}; const real Bc = sel(type == PAIR_TABLE_CUBE, B_tc, B_pc);
-        const int mask = (int)S.ld(LDS_ACT + c);
-        real a8[8], v8[8], p8[8]; gather8(ar, side, a8); gather8(qdr, side, v8); gather8(pr, side, p8);
-        _Pragma("unroll") for (int r = 0; r < 6; r++) {
-          real jc[6], jr[8]; pyramid_row(RC, r, mu, jc); pyr8(RP, r, mu, jr);
-          real ja = 0, jv = 0, jp = 0;
-          _Pragma("unroll") for (int d = 0; d < 6; d++) { ja += jc[d] * ac[d]; jv += jc[d] * Cb.vel[d]; jp += jc[d] * pc[d]; }
-          _Pragma("unroll") for (int d = 0; d < 8; d++) { ja += jr[d] * a8[d]; jv += jr[d] * v8[d]; jp += jr[d] * p8[d]; }
-          const real r0 = ja - (-Bc * jv - kterm);
-          if (c < ncon) { S.st(LDS_ROW + (c * 6 + r) * 2, r0); S.st(LDS_ROW + (c * 6 + r) * 2 + 1, jp); }
-          same = same && (c >= ncon || ((r0 + jp) < 0) == (((mask >> r) & 1) != 0));
-        }
+        Coupled K; contact_of(c, K);
+        real a8[8], v8[8], p8[8], da[4], dv[4], dp[4];
+        gather8(ar, K.side, a8); gather8(qdr, K.side, v8); gather8(pr, K.side, p8);
+        bdots(K, ac, a8, da); bdots(K, Cb.vel, v8, dv); bdots(K, pc, p8, dp);
+        static_for<3>([&](auto Kk) { constexpr int k = Kk;
+          static_for<2>([&](auto Od) { constexpr int odd = Od; constexpr int r = 2 * k + odd;
+            const real m = odd ? -K.mu[k] : K.mu[k];
+            const real r0 = fma(m, da[1 + k], da[0]) - (-K.Bc * fma(m, dv[1 + k], dv[0]) - K.kterm), jp = fma(m, dp[1 + k], dp[0]);
+            if (c < ncon) { S.st(LDS_ROW + (c * 6 + r) * 2, r0); S.st(LDS_ROW + (c * 6 + r) * 2 + 1, jp); }
+            same = same && (c >= ncon || ((r0 + jp) < 0) == (((K.mask >> r) & 1) != 0)); }); });
       }
       const bool finish = !conv && same;
       for (int i = 0; i < NB; i++) ar[i] = sel(finish, xr[i], ar[i]);
       _Pragma("unroll") for (int d = 0; d < 6; d++) ac[d] = sel(finish, xc[d], ac[d]);
       conv = conv || finish;
+      MCG_TICK(ST_C_CHECK);
       if (!__any(!conv)) break;
       // line search (bisection): smooth part = robot quadratic with H0 = M + equality rows (no limits), cube diag M
       MCG_COUNT(CN_COUPLED_LS);
@@ -693,8 +750,8 @@ struct CubeSys {
       _Pragma("unroll") for (int d = 0; d < 6; d++) ac[d] = sel(conv, ac[d], ac[d] + alpha * pc[d]);
       _Pragma("unroll") for (int j = 0; j < 10; j++) { const bool now = (sgl[j] != 0) && (sgl[j] * ar[j] - arefl[j] < 0); actl[j] = sel(conv, actl[j], now); }
       remask(alpha, conv);
+      MCG_TICK(ST_C_LS);
     }
-    (void)any_lim;
     _Pragma("unroll") for (int k = 0; k < 6; k++) a_c[k] = ac[k];
     solved = true;
   }

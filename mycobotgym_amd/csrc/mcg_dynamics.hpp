@@ -36,7 +36,7 @@ constexpr real MINVAL = 1e-15, MINIMP = 1e-4, MAXIMP = 0.9999;
 // Opt-in stage clocks (-DMCG_STAGE_CLOCKS, development builds only; tools/stage_clocks.py): lane 0 of each wave
 // accumulates shader-clock deltas per pipeline stage in LDS and adds them to a device-global table at kernel end.
 enum { ST_LOAD = 0, ST_CTRL, ST_TRIG, ST_RNE, ST_ACT, ST_CRB, ST_ROWS, ST_G0, ST_NEWTON, ST_EULER, ST_COLLIDE, ST_CUBE,
-       ST_COUPLED, ST_CUBE_FIN, ST_POST, ST_N_BUILD, ST_N_FACTOR, ST_N_SOLVE, ST_N_CHECK, ST_E_RHS, ST_R_AX5, ST_R_CONNECT, ST_R_LIMITS, ST_COUNT,
+       ST_COUPLED, ST_CUBE_FIN, ST_POST, ST_N_BUILD, ST_N_FACTOR, ST_N_SOLVE, ST_N_CHECK, ST_E_RHS, ST_R_AX5, ST_R_CONNECT, ST_R_LIMITS, ST_C_MASK, ST_C_ASSEMBLE, ST_C_SCHUR, ST_C_SOLVE, ST_C_CHECK, ST_C_LS, ST_COUNT,
        CN_SUBSTEP = 0, CN_NEWTON_IT, CN_LINESEARCH, CN_CUBE_IT, CN_CUBE_LS, CN_COUPLED, CN_COUPLED_IT, CN_COUPLED_LS, CN_CONTACTS, CN_COUNT };
 #ifdef MCG_STAGE_CLOCKS
 __device__ unsigned long long g_stage_clocks[ST_COUNT + CN_COUNT];      // stage clocks, then event counts (per wave)
@@ -283,6 +283,15 @@ MCG_DEV void spd_factor(real* A, real* dinv) {           // packed lower triangl
       A[tri(i, j)] = sacc * dinv[j];
     });
   });
+}
+template <int N>
+MCG_DEV void spd_forward(const real* A, real* x) {            // x <- L^-1 x  (unit lower L below the diagonal of A)
+  static_for<N>([&](auto I) { constexpr int i = I; static_for<i>([&](auto Kk) { constexpr int k = Kk; x[i] = fma(-A[tri(i, k)], x[k], x[i]); }); });
+}
+template <int N>
+MCG_DEV void spd_backward(const real* A, real* x) {           // x <- L^-T x
+  static_for<N>([&](auto I) { constexpr int i = N - 1 - I;
+    static_for<N - 1 - i>([&](auto Kk) { constexpr int k = i + 1 + Kk; x[i] = fma(-A[tri(k, i)], x[k], x[i]); }); });
 }
 template <int N>
 MCG_DEV void spd_solve(const real* A, const real* dinv, real* x) {

@@ -15,7 +15,9 @@ from mycobotgym_amd import MyCobotVecEnv, _abi
 NAMES = ["load", "controller", "sincos", "rne", "actuation", "crb->M", "rows: weld / rest", "g0", "newton: other (setup, line search)", "euler: factor M+hB, solve, integrate",
          "collide", "cube solve", "coupled solve", "cube finish", "post (obs/reward/reset/store)",
          "newton: build H", "newton: factor H", "newton: solve", "newton: active-set check", "euler: forces/rhs",
-         "rows: arm axes in link6 frame", "rows: connects + coupling", "rows: limits"]
+         "rows: arm axes in link6 frame", "rows: connects + coupling", "rows: limits",
+         "coupled: initial masks", "coupled: assembly over contacts", "coupled: Schur complement", "coupled: LDL + back-substitution",
+         "coupled: consistency + line-search rows", "coupled: line search + remask"]
 COUNTS = ["robot sub-steps", "robot Newton iterations", "robot line searches", "cube Newton iterations", "cube line searches",
           "coupled solves", "coupled Newton iterations", "coupled line searches", "wave-max contacts (per collision pass)"]
 fresh = "--fresh-actions" in sys.argv
