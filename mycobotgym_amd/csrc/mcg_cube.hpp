@@ -279,6 +279,14 @@ struct CubeSys {
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)pm_bits), hi = __builtin_amdgcn_readfirstlane((unsigned)(pm_bits >> 32));
     return (ModelPtr)(((unsigned long long)hi << 32) | lo);
   }
+  // contacts, joint frames and per-contact solver numbers are already in LDS (the caller ran prepare()): take them over
+  MCG_DEV void adopt(ModelPtr Pm, int ncon_, bool touch0, bool touch1) {
+    pm_bits = (unsigned long long)Pm;
+    derive(Pm);
+    solved = false;
+    _Pragma("unroll") for (int k = 0; k < 6; k++) a_c[k] = Cb.warm[k];
+    ncon = ncon_; touch[0] = touch0; touch[1] = touch1; any_pad = touch0 || touch1;
+  }
   MCG_DEV void prepare(ModelPtr Pm, const real* qr) {
     pm_bits = (unsigned long long)Pm;
     {   // mj_kinematics normalises the stored quaternion
@@ -492,6 +500,16 @@ struct CubeSys {
   }
 
   // phi'(alpha) = lin0 + alpha quad + sum_rows D min(0, r0 + alpha dr) dr over the contact rows stored at LDS_ROW
+  MCG_DEV void dphi_rows(real al, real& s, real& slope) const {     // adds the contact rows' part of phi' and phi''
+    for (int c = 0; __any(c < ncon); c++) {
+      const real D = sel((c < ncon), S.ld(LDS_CON + c * CON_STRIDE + 13), 0.0);
+      _Pragma("unroll") for (int r = 0; r < 6; r++) {
+        const real r0 = S.ld(LDS_ROW + (c * 6 + r) * 2), dr_ = S.ld(LDS_ROW + (c * 6 + r) * 2 + 1);
+        const real rr = r0 + al * dr_;
+        s += sel((rr < 0), D * rr * dr_, 0.0); slope += sel((rr < 0), D * dr_ * dr_, 0.0);
+      }
+    }
+  }
   MCG_DEV real dphi_rows(real al) const {
     real s = 0;
     for (int c = 0; __any(c < ncon); c++) {
@@ -641,19 +659,22 @@ struct CubeSys {
             if constexpr (i < 6) gr[i] += gl;
             else if constexpr (i == 6) { gr[6] += sel(K.side, 0.0, gl); gr[8] += sel(K.side, gl, 0.0); }
             else { gr[7] += sel(K.side, 0.0, gl); gr[9] += sel(K.side, gl, 0.0); }
-            // robot block, lower triangle in the contact's local order (arm 0..5, gear, finger: increasing dof index)
+            // robot block, lower triangle in the contact's local order (arm 0..5, gear, finger: increasing dof index), and
+            // coupling block Cm[dof i][cube d].  All loads of a row first, then all stores: the addresses are per-lane, so
+            // a load behind a store could not be hoisted and every entry would pay the LDS latency alone.
+            const int slot = (i < 6) ? i : (i == 6 ? gear : fing);
+            int kg[i + 1]; real og[i + 1], oc[6];
+            static_for<i + 1>([&](auto Jj) { constexpr int j = Jj;
+              if constexpr (i < 6) kg[j] = GA + tri(i, j);
+              else kg[j] = GA + rowoff[i - 6] + (j < 6 ? j : (j == 6 ? gear : fing));
+              og[j] = S.ld(kg[j]); });
+            static_for<6>([&](auto Dd) { constexpr int d = Dd; oc[d] = S.ld(CM + slot * 6 + d); });
             static_for<i + 1>([&](auto Jj) { constexpr int j = Jj;
               const real v = K.RP.Jn[i] * Ur[0][j] + K.RP.J1[i] * Ur[1][j] + K.RP.J2[i] * Ur[2][j] + K.RP.Jt[i] * Ur[3][j];
-              int k;
-              if constexpr (i < 6) k = GA + tri(i, j);
-              else k = GA + rowoff[i - 6] + (j < 6 ? j : (j == 6 ? gear : fing));
-              S.st(k, S.ld(k) + v); });
-            // coupling block Cm[dof i][cube d]
-            const int slot = (i < 6) ? i : (i == 6 ? gear : fing);
+              S.st(kg[j], og[j] + v); });
             static_for<6>([&](auto Dd) { constexpr int d = Dd;
               const real v = K.RP.Jn[i] * Uc[0][d] + K.RP.J1[i] * Uc[1][d] + K.RP.J2[i] * Uc[2][d] + K.RP.Jt[i] * Uc[3][d];
-              const int k = CM + slot * 6 + d;
-              S.st(k, S.ld(k) + v); }); });
+              S.st(CM + slot * 6 + d, oc[d] + v); }); });
         }
       }
       MCG_TICK_PIN(gr, NB); MCG_TICK_PIN(gc, 6);
@@ -737,15 +758,26 @@ struct CubeSys {
       // limit rows join the piecewise part
       real l_r0[10], l_dr[10];
       _Pragma("unroll") for (int j = 0; j < 10; j++) { l_r0[j] = sgl[j] * ar[j] - arefl[j]; l_dr[j] = sgl[j] * pr[j]; }
-      auto dphi = [&](real al) {
-        real sacc = lin0 + al * quad + dphi_rows(al);
-        _Pragma("unroll") for (int j = 0; j < 10; j++) { const real rr = l_r0[j] + al * l_dr[j]; sacc += sel((sgl[j] != 0 && rr < 0), Dl[j] * rr * l_dr[j], 0.0); }
+      // phi'(alpha) is piecewise linear and increasing: Newton on it (slope = quad + sum over active rows of D dr^2) lands
+      // exactly on the root once it is on the right piece; a bracket [lo, hi] with bisection as the fallback keeps it safe.
+      auto dphi = [&](real al, real& slope) {
+        real sacc = lin0 + al * quad; slope = quad;
+        dphi_rows(al, sacc, slope);
+        _Pragma("unroll") for (int j = 0; j < 10; j++) { const real rr = l_r0[j] + al * l_dr[j]; const bool on = sgl[j] != 0 && rr < 0;
+          sacc += sel(on, Dl[j] * rr * l_dr[j], 0.0); slope += sel(on, Dl[j] * l_dr[j] * l_dr[j], 0.0); }
         return sacc;
       };
-      real lo = 0, hi = 2;
-      const bool beyond = dphi(hi) < 0;
-      for (int b = 0; b < 24; b++) { const real mid = 0.5 * (lo + hi); const bool neg = dphi(mid) < 0; lo = sel(neg, mid, lo); hi = sel(neg, hi, mid); }
-      const real alpha = sel(beyond, 2.0, 0.5 * (lo + hi));
+      real lo = 0, hi = 2, sl;
+      const bool beyond = dphi(hi, sl) < 0;
+      real al = 1.0;
+      for (int b = 0; b < 8; b++) {
+        const real f = dphi(al, sl);
+        const bool neg = f < 0;
+        lo = sel(neg, al, lo); hi = sel(neg, hi, al);
+        const real nw = al - f / sl;
+        al = sel(nw > lo && nw < hi, nw, 0.5 * (lo + hi));
+      }
+      const real alpha = sel(beyond, 2.0, al);
       for (int i = 0; i < NB; i++) ar[i] = sel(conv, ar[i], ar[i] + alpha * pr[i]);
       _Pragma("unroll") for (int d = 0; d < 6; d++) ac[d] = sel(conv, ac[d], ac[d] + alpha * pc[d]);
       _Pragma("unroll") for (int j = 0; j < 10; j++) { const bool now = (sgl[j] != 0) && (sgl[j] * ar[j] - arefl[j] < 0); actl[j] = sel(conv, actl[j], now); }

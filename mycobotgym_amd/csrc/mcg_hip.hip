@@ -376,17 +376,16 @@ MCG_DEV void observe_pnp(const Cfg& C, ModelPtr P, const EnvP& E, real* obs, rea
 // The coupled sub-step (a finger pad touches the cube: robot and cube accelerations are solved together) is rare and
 // large.  It lives out of line, on a COPY of the env, so that its code and its live ranges stay out of the hot path's
 // register allocation (inlined, it doubled the cost of the uncoupled robot pipeline) and the env struct itself never
-// has its address taken.  It redoes the collision pass: contacts in LDS are the same, the derived numbers are cheap.
-template <class WLD> struct CoupledIO { EnvP E; WLD W; };
+// has its address taken.  The collision results stay where they are (LDS); the cheap derived numbers are recomputed.
+template <class WLD> struct CoupledIO { EnvP E; WLD W; int ncon; bool touch[2]; };
 template <class WLD>
 __device__ __noinline__ void pnp_substep_coupled(unsigned long long model_bits, CoupledIO<WLD>* io, unsigned lds_column) {
   const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)model_bits), hi = __builtin_amdgcn_readfirstlane((unsigned)(model_bits >> 32));
   const ModelPtr P = (ModelPtr)(((unsigned long long)hi << 32) | lo);
   const PnpScratch MS((LdsPtr)(uintptr_t)lds_column);
   EnvP E = io->E;
-  CubeSys<PnpScratch> CS(MS, E.Cb, E.dr);
-  CS.prepare(P, E.R.q);
-  MCG_TICK(ST_COLLIDE);
+  CubeSys<PnpScratch> CS(MS, E.Cb, E.dr);       // E.Cb holds the quaternion the caller's collision pass normalised
+  CS.adopt(P, io->ncon, io->touch[0], io->touch[1]);
   const WLD W = io->W;
   robot_substep<PnpScratch, CubeSys<PnpScratch>, WLD>(P, E.R, E.qlag6, MS, &CS, &W);     // its hook runs the coupled solve
   CS.finish(E.qlag7);
@@ -404,7 +403,7 @@ MCG_DEV void pnp_substep(ModelPtr P, EnvP& E, const PnpScratch MS, const WLD& W)
   MCG_TICK(ST_COLLIDE);
   E.touch = CS.touch[0] && CS.touch[1];        // contacts of this forward pass: what check_contact sees after the step
   if (__any(CS.any_pad)) {                     // wave-uniform
-    CoupledIO<WLD> io; io.E = E; io.W = W;
+    CoupledIO<WLD> io; io.E = E; io.E.Cb = CS.Cb; io.W = W; io.ncon = CS.ncon; io.touch[0] = CS.touch[0]; io.touch[1] = CS.touch[1];
     pnp_substep_coupled<WLD>((unsigned long long)P, &io, (unsigned)(uintptr_t)MS.base);
     const bool touch = E.touch;
     E = io.E; E.touch = touch;
