@@ -75,10 +75,19 @@ def main():
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # BENCH_SHARE_GPU=1 (rehearsal on a one-GPU box only): ranks share device 0 and rendezvous over gloo, because RCCL refuses
+    # two ranks on one device; the real multi-GPU run is one rank per GPU over RCCL ("nccl")
+    share = os.environ.get("BENCH_SHARE_GPU") == "1"
+    if share:
+        local_rank = 0
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    red_dev = "cpu" if share else None        # gloo reduces host tensors
     if args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if args.gpus > 1 and world == 1:
@@ -124,13 +133,14 @@ def main():
         dt = time.perf_counter() - t0
         kernel_ms = ev0.elapsed_time(ev1) / steps      # average launch-to-launch duration over the timed region
         if world > 1:
-            tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+            tt = torch.tensor([dt], dtype=torch.float64, device=red_dev or dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
         # logging path: episode statistics reduced over ranks with RCCL, off the timed region
         b = envs._buf
         stats = torch.stack([b["ep_return"].sum(), b["ep_length"].double().sum(), b["is_success"].double().sum()])
         if world > 1:
+            if red_dev: stats = stats.to(red_dev)
             dist.all_reduce(stats, op=dist.ReduceOp.SUM)
         envs.close()
         return dt, kernel_ms, stats.tolist()
