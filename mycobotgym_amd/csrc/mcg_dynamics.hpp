@@ -342,6 +342,8 @@ struct Robot {
 constexpr int LDS_M = 0;                              // packed lower triangle of M                     (78 slots)
 constexpr int LDS_HEQ = NB * (NB + 1) / 2;            // H_eq = M + J^T D J over the equality (and weld) rows  (78 slots)
 constexpr int LDS_SLOTS = 2 * (NB * (NB + 1) / 2);
+// two-wave variant (SplitA / helper_substep): factor of M + hB, its reciprocal pivots, and q published for the helper wave
+constexpr int LDS_FAC = LDS_SLOTS, LDS_FDINV = LDS_FAC + NB * (NB + 1) / 2, LDS_QB = LDS_FDINV + NB, LDS_SLOTS_SPLIT = LDS_QB + NB;
 // The lane's LDS column.  The pointer carries the LDS address space explicitly: passed through structs as a generic
 // pointer the accesses degrade to flat_load/flat_store with 64-bit address arithmetic instead of ds_read/ds_write
 // with immediate offsets.
@@ -424,9 +426,96 @@ MCG_DEV void tcp_forward(ModelPtr P, const real* q6, TcpPose& X, bool want_jac) 
   }
 }
 
-template <class LS, class CPL = NoCoupling, class WLD = NoWeld>
+// ---- P3 composite rigid bodies -> joint-space inertia M (packed lower triangle, in LDS)      (mj_crb)
+// Depends on the joint angles (through cs / sn) and the model only.
+template <class LS>
+MCG_DEV void crb_to_lds(ModelPtr Pm, const real* cs, const real* sn, const LS MS) {
+    real cm[NB], cmc[NB][3], cI[NB][6];
+    static_for<NB>([&](auto I) {
+      constexpr int i = NB - 1 - I; constexpr int K = AXK[i]; constexpr int A = (K + 1) % 3, B = (K + 2) % 3;
+      constexpr int p = PAR[i];
+      constexpr bool leaf = (i == 7 || i == 9 || i == 10 || i == 11);
+      const BodyC bc = load_body(launder(Pm), i); const BodyC* b = &bc;
+      if constexpr (leaf) {
+        cm[i] = b->mass;
+        for (int k = 0; k < 3; k++) cmc[i][k] = b->mc[k];
+        for (int k = 0; k < 6; k++) cI[i][k] = b->inertia[k];
+      } else {          // children (higher index) have already added their composites
+        cm[i] += b->mass;
+        for (int k = 0; k < 3; k++) cmc[i][k] += b->mc[k];
+        for (int k = 0; k < 6; k++) cI[i][k] += b->inertia[k];
+      }
+      // wrench of a unit acceleration about joint i acting on composite body i (frame i, about origin i)
+      constexpr int iKA = (K + A == 1) ? 3 : (K + A == 2) ? 4 : 5;
+      constexpr int iKB = (K + B == 1) ? 3 : (K + B == 2) ? 4 : 5;
+      const real sg = AXS[i];
+      real fj[3], nj[3];
+      nj[K] = sg * cI[i][K]; nj[A] = sg * cI[i][iKA]; nj[B] = sg * cI[i][iKB];
+      fj[K] = 0; fj[A] = -sg * cmc[i][B]; fj[B] = sg * cmc[i][A];          // (sg e_K) x mc
+      MS.st(tri(i, i), cI[i][K] + b->armature);
+      // walk to the root: M[i][j] = axis_j . moment about origin j
+      auto up = [&](auto self, auto Cur) -> void {
+        constexpr int cur = Cur; constexpr int pj = PAR[cur];
+        if constexpr (pj >= 0) {
+          constexpr int Kc = AXK[cur];
+          real rc[3]; ldc<3>(launder(Pm)->body[cur].r, rc);
+          real f2[3], n2[3];
+          rot_up<Kc>(cs[cur], sn[cur], fj, f2);
+          rot_up<Kc>(cs[cur], sn[cur], nj, n2);
+          cross_add(rc, f2, n2);
+          for (int k = 0; k < 3; k++) { fj[k] = f2[k]; nj[k] = n2[k]; }
+          MS.st(tri(i, pj), AXS[pj] * nj[AXK[pj]]);
+          self(self, std::integral_constant<int, pj>{});
+        }
+      };
+      up(up, std::integral_constant<int, i>{});
+      // add composite i to its parent
+      if constexpr (p >= 0) {
+        constexpr bool first_child = (i == 11 || i == 7 || i == 9 || i < 6);   // highest-index child of its parent
+        real It[6], h3[3];
+        for (int k = 0; k < 6; k++) It[k] = cI[i][k];
+        sym_rot_up<K>(cs[i], sn[i], It);
+        rot_up<K>(cs[i], sn[i], cmc[i], h3);
+        const real* r = b->r; const real m = cm[i];
+        const real rr = dot3(r, r), rh = dot3(r, h3);
+        const real d = m * rr + 2 * rh;
+        real add[6];
+        add[0] = It[0] + d - (m * r[0] * r[0] + 2 * r[0] * h3[0]);
+        add[1] = It[1] + d - (m * r[1] * r[1] + 2 * r[1] * h3[1]);
+        add[2] = It[2] + d - (m * r[2] * r[2] + 2 * r[2] * h3[2]);
+        add[3] = It[3] - (m * r[0] * r[1] + r[0] * h3[1] + h3[0] * r[1]);
+        add[4] = It[4] - (m * r[0] * r[2] + r[0] * h3[2] + h3[0] * r[2]);
+        add[5] = It[5] - (m * r[1] * r[2] + r[1] * h3[2] + h3[1] * r[2]);
+        if constexpr (first_child) {
+          cm[p] = m;
+          for (int k = 0; k < 3; k++) cmc[p][k] = h3[k] + m * r[k];
+          for (int k = 0; k < 6; k++) cI[p][k] = add[k];
+        } else {
+          cm[p] += m;
+          for (int k = 0; k < 3; k++) cmc[p][k] += h3[k] + m * r[k];
+          for (int k = 0; k < 6; k++) cI[p][k] += add[k];
+        }
+        pin(cm[p]); pin3(cmc[p]); pin6(cI[p]);
+      }
+      asm volatile("" ::: "memory");      // the M entries of this body are in LDS before the next block starts
+      MCG_FENCE();
+    });
+}
+
+// Two-wave variant (Reach, grids of at most one workgroup per CU, where 3 of the 4 SIMDs of a CU would idle): the workgroup
+// has a second wave over the same 64 environments.  It computes what depends on the joint angles alone -- M by the composite
+// rigid body pass, then the L^T D L factor of M + hB for the Euler step -- while the main wave does the bias forces, actuation
+// and constraint rows.  Three workgroup barriers per sub-step:
+//   S1  q(t) is published in LDS              (helper may read it)
+//   S2  M(t) is in LDS                        (main wave assembles H_eq, runs the Newton solve)
+//   S3  the factor of M + hB is in LDS        (main wave: a' = a - h (M + hB)^-1 (B a), which equals (M + hB)^-1 M a)
+struct NoSplit { static constexpr bool enabled = false; };
+struct SplitMain { static constexpr bool enabled = true; };
+
+template <class LS, class CPL = NoCoupling, class WLD = NoWeld, class SPL = NoSplit>
 MCG_DEV void robot_substep(ModelPtr Pm, Robot& S, real* qlag6, const LS MS, CPL* CP = nullptr, const WLD* WD = nullptr) {
   MCG_COUNT(CN_SUBSTEP);
+  if constexpr (SPL::enabled) __syncthreads();                     // S1
   const real h = launder(Pm)->timestep;
   real cs[NB], sn[NB];
   {
@@ -509,80 +598,7 @@ MCG_DEV void robot_substep(ModelPtr Pm, Robot& S, real* qlag6, const LS MS, CPL*
   MCG_FENCE();
 
   MCG_TICK(ST_ACT);
-  // ---- P3 composite rigid bodies -> joint-space inertia M (packed lower triangle, in LDS)      (mj_crb)
-  {
-    real cm[NB], cmc[NB][3], cI[NB][6];
-    static_for<NB>([&](auto I) {
-      constexpr int i = NB - 1 - I; constexpr int K = AXK[i]; constexpr int A = (K + 1) % 3, B = (K + 2) % 3;
-      constexpr int p = PAR[i];
-      constexpr bool leaf = (i == 7 || i == 9 || i == 10 || i == 11);
-      const BodyC bc = load_body(launder(Pm), i); const BodyC* b = &bc;
-      if constexpr (leaf) {
-        cm[i] = b->mass;
-        for (int k = 0; k < 3; k++) cmc[i][k] = b->mc[k];
-        for (int k = 0; k < 6; k++) cI[i][k] = b->inertia[k];
-      } else {          // children (higher index) have already added their composites
-        cm[i] += b->mass;
-        for (int k = 0; k < 3; k++) cmc[i][k] += b->mc[k];
-        for (int k = 0; k < 6; k++) cI[i][k] += b->inertia[k];
-      }
-      // wrench of a unit acceleration about joint i acting on composite body i (frame i, about origin i)
-      constexpr int iKA = (K + A == 1) ? 3 : (K + A == 2) ? 4 : 5;
-      constexpr int iKB = (K + B == 1) ? 3 : (K + B == 2) ? 4 : 5;
-      const real sg = AXS[i];
-      real fj[3], nj[3];
-      nj[K] = sg * cI[i][K]; nj[A] = sg * cI[i][iKA]; nj[B] = sg * cI[i][iKB];
-      fj[K] = 0; fj[A] = -sg * cmc[i][B]; fj[B] = sg * cmc[i][A];          // (sg e_K) x mc
-      MS.st(tri(i, i), cI[i][K] + b->armature);
-      // walk to the root: M[i][j] = axis_j . moment about origin j
-      auto up = [&](auto self, auto Cur) -> void {
-        constexpr int cur = Cur; constexpr int pj = PAR[cur];
-        if constexpr (pj >= 0) {
-          constexpr int Kc = AXK[cur];
-          real rc[3]; ldc<3>(launder(Pm)->body[cur].r, rc);
-          real f2[3], n2[3];
-          rot_up<Kc>(cs[cur], sn[cur], fj, f2);
-          rot_up<Kc>(cs[cur], sn[cur], nj, n2);
-          cross_add(rc, f2, n2);
-          for (int k = 0; k < 3; k++) { fj[k] = f2[k]; nj[k] = n2[k]; }
-          MS.st(tri(i, pj), AXS[pj] * nj[AXK[pj]]);
-          self(self, std::integral_constant<int, pj>{});
-        }
-      };
-      up(up, std::integral_constant<int, i>{});
-      // add composite i to its parent
-      if constexpr (p >= 0) {
-        constexpr bool first_child = (i == 11 || i == 7 || i == 9 || i < 6);   // highest-index child of its parent
-        real It[6], h3[3];
-        for (int k = 0; k < 6; k++) It[k] = cI[i][k];
-        sym_rot_up<K>(cs[i], sn[i], It);
-        rot_up<K>(cs[i], sn[i], cmc[i], h3);
-        const real* r = b->r; const real m = cm[i];
-        const real rr = dot3(r, r), rh = dot3(r, h3);
-        const real d = m * rr + 2 * rh;
-        real add[6];
-        add[0] = It[0] + d - (m * r[0] * r[0] + 2 * r[0] * h3[0]);
-        add[1] = It[1] + d - (m * r[1] * r[1] + 2 * r[1] * h3[1]);
-        add[2] = It[2] + d - (m * r[2] * r[2] + 2 * r[2] * h3[2]);
-        add[3] = It[3] - (m * r[0] * r[1] + r[0] * h3[1] + h3[0] * r[1]);
-        add[4] = It[4] - (m * r[0] * r[2] + r[0] * h3[2] + h3[0] * r[2]);
-        add[5] = It[5] - (m * r[1] * r[2] + r[1] * h3[2] + h3[1] * r[2]);
-        if constexpr (first_child) {
-          cm[p] = m;
-          for (int k = 0; k < 3; k++) cmc[p][k] = h3[k] + m * r[k];
-          for (int k = 0; k < 6; k++) cI[p][k] = add[k];
-        } else {
-          cm[p] += m;
-          for (int k = 0; k < 3; k++) cmc[p][k] += h3[k] + m * r[k];
-          for (int k = 0; k < 6; k++) cI[p][k] += add[k];
-        }
-        pin(cm[p]); pin3(cmc[p]); pin6(cI[p]);
-      }
-      asm volatile("" ::: "memory");      // the M entries of this body are in LDS before the next block starts
-      MCG_FENCE();
-    });
-  }
-
+  if constexpr (!SPL::enabled) crb_to_lds(Pm, cs, sn, MS);        // two-wave variant: the helper wave does it meanwhile
   MCG_TICK(ST_CRB);
   // ---- P5 constraint rows                                                   (mj_makeConstraint)
   // arm joint axes expressed in the link6 frame (for the tiny arm columns of the connect rows)
@@ -729,6 +745,7 @@ MCG_DEV void robot_substep(ModelPtr Pm, Robot& S, real* qlag6, const LS MS, CPL*
   if constexpr (WLD::enabled)
     static_for<6>([&](auto Rr) { constexpr int r = Rr; const real da = Dw * arefw[r];
       static_for<6>([&](auto I) { constexpr int j = I; g0[j] = fma(Jw[r][j], da, g0[j]); }); });
+  if constexpr (SPL::enabled) __syncthreads();                     // S2: M is in LDS
   // H_eq = M + J^T D J over the equality rows (two connects, gear coupling, mocap weld) is assembled ONCE per sub-step,
   // group by group (arm block, then each side's gripper rows: at most 24 accumulators live), and parked in LDS next to M.
   // The connect / weld Jacobians are dead from here on: the Newton iterations and the line search read H_eq back and add the
@@ -861,9 +878,18 @@ MCG_DEV void robot_substep(ModelPtr Pm, Robot& S, real* qlag6, const LS MS, CPL*
   MCG_TICK_PIN(a, NB);
   MCG_TICK(ST_NEWTON);
   // ---- constraint forces -> qfrc_constraint; P10 implicit-damping Euler                  (mj_Euler, mj_advance)
+  real rhs[NB];
+  if constexpr (SPL::enabled) {
+    __syncthreads();                                                // S3: the helper's factor of M + hB is in LDS
+    real Lf[NB * (NB + 1) / 2], dinv[NB];
+    static_for<NB>([&](auto I) { constexpr int i = I; dinv[i] = MS.ld(LDS_FDINV + i);
+      static_for<i>([&](auto Jj) { constexpr int j = Jj; if constexpr (PAT_M.nz[i][j]) Lf[tri(i, j)] = MS.ld(LDS_FAC + tri(i, j)); }); });
+    static_for<NB>([&](auto I) { constexpr int i = I; rhs[i] = launder(Pm)->body[i].damping * a[i]; });
+    ldl_solve<PAT_M>(Lf, dinv, rhs);
+    static_for<NB>([&](auto I) { constexpr int i = I; rhs[i] = fma(-h, rhs[i], a[i]); });
+  } else {
   // At the minimiser the gradient vanishes: M a = qfrc_smooth + J^T f over ALL rows (equality, limit, weld, contact), so the
   // right-hand side of (M + hB) a' = qfrc_smooth + qfrc_constraint is M a: no Jacobian is live after the Newton solve.
-  real rhs[NB];
   MCG_TICK(ST_E_RHS);
   {
     real Mh[NB * (NB + 1) / 2], dinv[NB];
@@ -876,12 +902,40 @@ MCG_DEV void robot_substep(ModelPtr Pm, Robot& S, real* qlag6, const LS MS, CPL*
     ldl_factor<PAT_M>(Mh, dinv);
     ldl_solve<PAT_M>(Mh, dinv, rhs);
   }
+  }
   static_for<NB>([&](auto I) { constexpr int i = I;
     S.qd[i] = fma(h, rhs[i], S.qd[i]);
     S.q[i] = fma(h, S.qd[i], S.q[i]);
-    S.warm[i] = a[i]; });
+    S.warm[i] = a[i];
+    if constexpr (SPL::enabled) MS.st(LDS_QB + i, S.q[i]); });
   MCG_TICK_PIN(S.q, NB); MCG_TICK_PIN(S.qd, NB);
   MCG_TICK(ST_EULER);
+}
+
+// The helper wave's share of one sub-step (see SplitMain).
+template <class LS>
+MCG_DEV void helper_substep(ModelPtr Pm, const LS MS) {
+  __syncthreads();                                                  // S1
+  real cs[NB], sn[NB];
+  {
+    const TrigC T = load_trig();
+    static_for<NB>([&](auto I) { constexpr int i = I; sincos_cw(T, AXS[i] * MS.ld(LDS_QB + i), sn[i], cs[i]); });
+  }
+  static_for<NB>([&](auto I) { constexpr int i = I; pin(sn[i]); pin(cs[i]); });
+  MCG_FENCE();
+  crb_to_lds(Pm, cs, sn, MS);
+  __syncthreads();                                                  // S2
+  {
+    const real h = launder(Pm)->timestep;
+    real Mh[NB * (NB + 1) / 2], dinv[NB];
+    static_for<NB>([&](auto I) { constexpr int i = I;
+      static_for<i + 1>([&](auto Jj) { constexpr int j = Jj; if constexpr (PAT_M.nz[i][j]) Mh[tri(i, j)] = MS.ld(LDS_M + tri(i, j)); }); });
+    static_for<NB>([&](auto I) { constexpr int i = I; Mh[tri(i, i)] = fma(h, launder(Pm)->body[i].damping, Mh[tri(i, i)]); });
+    ldl_factor<PAT_M>(Mh, dinv);
+    static_for<NB>([&](auto I) { constexpr int i = I; MS.st(LDS_FDINV + i, dinv[i]);
+      static_for<i>([&](auto Jj) { constexpr int j = Jj; if constexpr (PAT_M.nz[i][j]) MS.st(LDS_FAC + tri(i, j), Mh[tri(i, j)]); }); });
+  }
+  __syncthreads();                                                  // S3
 }
 
 // ---------------------------------------------------------------------------------- world-frame arm kinematics

@@ -6,6 +6,7 @@
 // is read once and written once per env-step (B = 2*S + A + O bytes per env-step).
 // gfx950 only; no CPU fallback exists on purpose.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 
 #include <cstdio>
 #include <cstring>
@@ -169,17 +170,29 @@ MCG_DEV void mocap_target(const Cfg& C, ModelPtr P, const real* qlag6, const flo
   normalize4(W.quat);
 }
 
-template <int CONTROLLER>
-__global__ __launch_bounds__(64) void step_reach_kernel(Cfg C, View V, const mcg_model* __restrict__ Pg,
-                                                        const float* __restrict__ actions, mcg_step_out O) {
-  __shared__ real lds[LDS_SLOTS][64];
-  const LaneScratch MS(&lds[0][threadIdx.x]);
+// SPLIT: two waves per 64 environments (see SplitMain in mcg_dynamics.hpp): launched when the grid has at most one workgroup
+// per CU, where the second wave runs on a SIMD that would idle.  132 KB of LDS per workgroup.
+template <int CONTROLLER, bool SPLIT>
+__global__ __launch_bounds__(SPLIT ? 128 : 64) void step_reach_kernel(Cfg C, View V, const mcg_model* __restrict__ Pg,
+                                                                      const float* __restrict__ actions, mcg_step_out O) {
+  typedef std::conditional_t<SPLIT, SplitMain, NoSplit> Split;
+  __shared__ real lds[SPLIT ? LDS_SLOTS_SPLIT : LDS_SLOTS][64];
+  const int lane = threadIdx.x & 63;
+  const LaneScratch MS(&lds[0][lane]);
   const ModelPtr P = as_model_ptr(Pg);
-  const int i = blockIdx.x * 64 + threadIdx.x;
-  if (i >= C.n) return;
+  const int i = blockIdx.x * 64 + lane;
+  if (i >= C.n) return;                          // the same lanes leave in both waves: barriers stay matched
+  if constexpr (SPLIT) {
+    if (threadIdx.x >= 64) {                     // helper wave: M and the Euler factor for every sub-step, nothing else
+      const int total = (CONTROLLER == MCG_CTRL_IK ? C.control_steps : 1) * C.frame_skip;
+      for (int s = 0; s < total; s++) helper_substep(P, MS);
+      return;
+    }
+  }
   MCG_TICK_INIT();
   Env E;
   load_env(V, i, E);
+  if constexpr (SPLIT) static_for<NB>([&](auto I) { constexpr int k = I; MS.st(LDS_QB + k, E.R.q[k]); });   // q(0) for the helper
   MCG_TICK(ST_LOAD);
   float act[8];
   _Pragma("unroll") for (int k = 0; k < 8; k++) {   // act_dim is 7, 4 (fetch) or 8 (mocap): static indices keep the array in registers
@@ -207,17 +220,17 @@ __global__ __launch_bounds__(64) void step_reach_kernel(Cfg C, View V, const mcg
       for (int k = 0; k < 6; k++) E.R.ctrl[k] += dq[k];
       E.R.ctrl[6] = grip;
       MCG_TICK(ST_CTRL);
-      for (int s = 0; s < C.frame_skip; s++) robot_substep(P, E.R, E.qlag6, MS);
+      for (int s = 0; s < C.frame_skip; s++) robot_substep<LaneScratch, NoCoupling, NoWeld, Split>(P, E.R, E.qlag6, MS);
     }
   } else if constexpr (CONTROLLER == MCG_CTRL_MOCAP) {
     Weld W; mocap_target(C, P, E.qlag6, act, W);
     E.R.ctrl[6] = C.grip_center + (real)act_last * C.grip_range;
     MCG_TICK(ST_CTRL);
-    for (int s = 0; s < C.frame_skip; s++) robot_substep<LaneScratch, NoCoupling, Weld>(P, E.R, E.qlag6, MS, nullptr, &W);
+    for (int s = 0; s < C.frame_skip; s++) robot_substep<LaneScratch, NoCoupling, Weld, Split>(P, E.R, E.qlag6, MS, nullptr, &W);
   } else {
     for (int k = 0; k < 7; k++) E.R.ctrl[k] = (real)act[k];
     MCG_TICK(ST_CTRL);
-    for (int s = 0; s < C.frame_skip; s++) robot_substep(P, E.R, E.qlag6, MS);
+    for (int s = 0; s < C.frame_skip; s++) robot_substep<LaneScratch, NoCoupling, NoWeld, Split>(P, E.R, E.qlag6, MS);
   }
 
   guard_robot(E.R, E.qlag6);
@@ -577,6 +590,8 @@ struct mcg_env {
   View view;
   mcg_model* d_model;
   int device;
+  int num_cu;
+  bool no_split;       // MCG_NO_SPLIT=1 in the environment at mcg_create: always the one-wave Reach kernels (tests, A/B timing)
 };
 
 extern "C" {
@@ -642,6 +657,12 @@ int mcg_create(const mcg_config* c, const mcg_model* model, int device, mcg_env*
   C.dr_mass[0] = c->dr_mass_range[0]; C.dr_mass[1] = c->dr_mass_range[1];
   C.dr_fric[0] = c->dr_friction_range[0]; C.dr_fric[1] = c->dr_friction_range[1];
   e->device = device;
+  {
+    hipDeviceProp_t prop;
+    e->num_cu = (hipGetDeviceProperties(&prop, device) == hipSuccess) ? prop.multiProcessorCount : 256;
+    const char* ns = getenv("MCG_NO_SPLIT");
+    e->no_split = ns && ns[0] == '1';
+  }
   e->view.n = C.n; e->view.nq = C.nq; e->view.nv = C.nv;
   size_t nd = (size_t)state_doubles(C.nq, C.nv) * C.n;
   hipError_t err = hipMalloc(&e->view.d, nd * sizeof(double));
@@ -709,13 +730,19 @@ static int launch_step(mcg_env* e, const float* actions, const mcg_step_out& o, 
       hipLaunchKernelGGL(step_pnp_kernel<MCG_CTRL_JOINT>, grid, block, 0, s, e->cfg, e->view, e->d_model, actions, o);
     return hipGetLastError() == hipSuccess ? MCG_OK : MCG_ERR_HIP;
   }
-  dim3 grid((e->cfg.n + 63) / 64), block(64);
-  if (e->cfg.controller == MCG_CTRL_IK)
-    hipLaunchKernelGGL(step_reach_kernel<MCG_CTRL_IK>, grid, block, 0, s, e->cfg, e->view, e->d_model, actions, o);
-  else if (e->cfg.controller == MCG_CTRL_MOCAP)
-    hipLaunchKernelGGL(step_reach_kernel<MCG_CTRL_MOCAP>, grid, block, 0, s, e->cfg, e->view, e->d_model, actions, o);
-  else
-    hipLaunchKernelGGL(step_reach_kernel<MCG_CTRL_JOINT>, grid, block, 0, s, e->cfg, e->view, e->d_model, actions, o);
+  dim3 grid((e->cfg.n + 63) / 64);
+  // up to one workgroup per CU three SIMDs of every CU would idle: the two-wave variant puts a helper wave on one of them
+  const bool split = (int)grid.x <= e->num_cu && !e->no_split;
+  const dim3 block(split ? 128 : 64);
+#define MCG_LAUNCH_REACH(CTRL)                                                                                                 \
+  do {                                                                                                                         \
+    if (split) hipLaunchKernelGGL((step_reach_kernel<CTRL, true>), grid, block, 0, s, e->cfg, e->view, e->d_model, actions, o);     \
+    else hipLaunchKernelGGL((step_reach_kernel<CTRL, false>), grid, block, 0, s, e->cfg, e->view, e->d_model, actions, o);          \
+  } while (0)
+  if (e->cfg.controller == MCG_CTRL_IK) MCG_LAUNCH_REACH(MCG_CTRL_IK);
+  else if (e->cfg.controller == MCG_CTRL_MOCAP) MCG_LAUNCH_REACH(MCG_CTRL_MOCAP);
+  else MCG_LAUNCH_REACH(MCG_CTRL_JOINT);
+#undef MCG_LAUNCH_REACH
   return hipGetLastError() == hipSuccess ? MCG_OK : MCG_ERR_HIP;
 }
 
