@@ -10,7 +10,7 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 task = sys.argv[2] if len(sys.argv) > 2 else "reach"        # reach | pnp
 root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 src = os.path.join(root, "gpurun_out", tag)
-KERNEL = "step_reach_kernel<0>" if task == "reach" else "step_pnp_kernel<0>"
+KERNEL = "step_reach_kernel<0" if task == "reach" else "step_pnp_kernel<0"      # joint controller; any variant (<0, true> = two-wave)
 LANES = 64 if task == "reach" else 32           # active lanes per wave (PNP_LANES)
 ALGO_BYTES = 939 if task == "reach" else 1363
 
@@ -23,6 +23,9 @@ def rows(pattern):
 
 
 summary = {"tag": tag, "kernel": KERNEL}
+import re
+names = sorted({m.group(0) for r in rows("stats/*/*_kernel_trace.csv") for m in [re.search(r"step_\w+<[^>]*>", r["Kernel_Name"])] if m and KERNEL in r["Kernel_Name"]})
+summary["kernel_variants_seen"] = names
 kt = [r for r in rows("stats/*/*_kernel_trace.csv") if KERNEL in r["Kernel_Name"]]
 dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in kt]
 summary["kernel_trace"] = {"launches": len(dur), "avg_us": statistics.mean(dur), "median_us": statistics.median(dur),
@@ -40,7 +43,7 @@ for d in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2", "pmc_flops"):
             counters.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
 summary["counters_avg_per_launch"] = {k: statistics.mean(v) for k, v in counters.items()}
 c = summary["counters_avg_per_launch"]
-n_envs = summary["kernel_trace"]["grid"]
+n_envs = summary["kernel_trace"]["grid"] * (64 if task == "reach" else 32) // summary["kernel_trace"]["workgroup"]   # two-wave: 128 threads per 64 envs
 if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
     rd_raw, wr = c["FETCH_SIZE"] * 1024, c["WRITE_SIZE"] * 1024
     summary["hbm"] = {"read_bytes_raw": rd_raw, "read_bytes_x2_corrected": 2 * rd_raw, "write_bytes": wr,
