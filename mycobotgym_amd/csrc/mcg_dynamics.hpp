@@ -512,8 +512,11 @@ MCG_DEV void crb_to_lds(ModelPtr Pm, const real* cs, const real* sn, const LS MS
 struct NoSplit { static constexpr bool enabled = false; };
 struct SplitMain { static constexpr bool enabled = true; };
 
-template <class LS, class CPL = NoCoupling, class WLD = NoWeld, class SPL = NoSplit>
-MCG_DEV void robot_substep(ModelPtr Pm, Robot& S, real* qlag6, const LS MS, CPL* CP = nullptr, const WLD* WD = nullptr) {
+// COMMIT = false: the new q / qd / qacc_warmstart go to *next and S stays as it was (speculative sub-step of the two-wave
+// PickAndPlace kernel: discarded when the helper wave's collision pass finds a pad contact).
+template <class LS, class CPL = NoCoupling, class WLD = NoWeld, class SPL = NoSplit, bool COMMIT = true>
+MCG_DEV void robot_substep(ModelPtr Pm, Robot& S, real* qlag6, const LS MS, CPL* CP = nullptr, const WLD* WD = nullptr,
+                           Robot* next = nullptr) {
   MCG_COUNT(CN_SUBSTEP);
   if constexpr (SPL::enabled) __syncthreads();                     // S1
   const real h = launder(Pm)->timestep;
@@ -904,10 +907,10 @@ MCG_DEV void robot_substep(ModelPtr Pm, Robot& S, real* qlag6, const LS MS, CPL*
   }
   }
   static_for<NB>([&](auto I) { constexpr int i = I;
-    S.qd[i] = fma(h, rhs[i], S.qd[i]);
-    S.q[i] = fma(h, S.qd[i], S.q[i]);
-    S.warm[i] = a[i];
-    if constexpr (SPL::enabled) MS.st(LDS_QB + i, S.q[i]); });
+    const real qd_new = fma(h, rhs[i], S.qd[i]), q_new = fma(h, qd_new, S.q[i]);
+    if constexpr (COMMIT) { S.qd[i] = qd_new; S.q[i] = q_new; S.warm[i] = a[i]; }
+    else { next->qd[i] = qd_new; next->q[i] = q_new; next->warm[i] = a[i]; }
+    if constexpr (SPL::enabled) MS.st(LDS_QB + i, q_new); });
   MCG_TICK_PIN(S.q, NB); MCG_TICK_PIN(S.qd, NB);
   MCG_TICK(ST_EULER);
 }

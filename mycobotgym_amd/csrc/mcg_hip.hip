@@ -430,19 +430,118 @@ MCG_DEV void pnp_substep(ModelPtr P, EnvP& E, const PnpScratch MS, const WLD& W)
   robot_substep<PnpScratch, NoCoupling, WLD>(P, E.R, E.qlag6, MS, nullptr, &W);
 }
 
-template <int CONTROLLER>
-__global__ __launch_bounds__(PNP_LANES) void step_pnp_kernel(Cfg C, View V, const mcg_model* __restrict__ Pg,
+// ------------------------------------------------------------------------------- two-wave PickAndPlace (DUAL)
+// Without a pad contact the cube's sub-step (collision, 6x6 Newton, integration) and the robot's are independent.  When the
+// grid has at most one workgroup per CU the workgroup gets a second wave over the same 32 environments: the CUBE wave owns
+// the cube for the whole env-step while the ROBOT wave runs the robot pipeline speculatively (results held back).  Two
+// workgroup barriers per sub-step:
+//   S1  q(t) of the robot is published                 (the cube wave needs the pads' pose for the collision pass)
+//   S2  contact list, pad-contact flags are published  (both waves take the same wave-uniform decision)
+// no pad contact in the wave: the robot wave commits, the cube wave has already advanced the cube.  Otherwise the cube wave
+// has left the cube untouched and published it; the robot wave discards its result, runs the coupled sub-step
+// (pnp_substep_coupled, as the one-wave kernel does) and hands the cube back (barrier S3).
+// Exchange area: the clip-polygon slots, which only the collision pass uses.
+constexpr int XCH_FLAG = LDS_POLY, XCH_T0 = LDS_POLY + 1, XCH_T1 = LDS_POLY + 2, XCH_NCON = LDS_POLY + 3;
+constexpr int XCH_CB = LDS_POLY + 4, XCH_QL7 = LDS_POLY + 23, XCH_Q = LDS_POLY + 32;
+static_assert(XCH_Q + NB <= LDS_POLY + 64, "exchange area exceeds the clip-polygon slots");
+
+MCG_DEV void cube_to_lds(const PnpScratch MS, const Cube& Cb) {
+  for (int k = 0; k < 3; k++) MS.st(XCH_CB + k, Cb.pos[k]);
+  for (int k = 0; k < 4; k++) MS.st(XCH_CB + 3 + k, Cb.quat[k]);
+  for (int k = 0; k < 6; k++) { MS.st(XCH_CB + 7 + k, Cb.vel[k]); MS.st(XCH_CB + 13 + k, Cb.warm[k]); }
+}
+MCG_DEV void cube_from_lds(const PnpScratch MS, Cube& Cb) {
+  for (int k = 0; k < 3; k++) Cb.pos[k] = MS.ld(XCH_CB + k);
+  for (int k = 0; k < 4; k++) Cb.quat[k] = MS.ld(XCH_CB + 3 + k);
+  for (int k = 0; k < 6; k++) { Cb.vel[k] = MS.ld(XCH_CB + 7 + k); Cb.warm[k] = MS.ld(XCH_CB + 13 + k); }
+}
+
+// the cube wave's whole env-step
+MCG_DEV void cube_wave(const View& V, ModelPtr P, const PnpScratch MS, int i, int total) {
+  Cube Cb; real dr[2], qlag7[7];
+  for (int k = 0; k < 3; k++) Cb.pos[k] = V.qpos(12 + k, i);
+  for (int k = 0; k < 4; k++) Cb.quat[k] = V.qpos(15 + k, i);
+  for (int k = 0; k < 6; k++) { Cb.vel[k] = V.qvel(12 + k, i); Cb.warm[k] = V.warm(12 + k, i); }
+  for (int k = 0; k < 7; k++) qlag7[k] = V.qlag(12 + k, i);
+  dr[0] = V.dr(0, i); dr[1] = V.dr(1, i);
+  bool touch = false;
+  for (int s = 0; s < total; s++) {
+    __syncthreads();                                                // S1
+    real q10[10];
+    static_for<10>([&](auto I) { constexpr int k = I; q10[k] = MS.ld(XCH_Q + k); });
+    CubeSys<PnpScratch> CS(MS, Cb, dr);
+    CS.prepare(P, q10);
+    touch = CS.touch[0] && CS.touch[1];
+    const bool coupled = __any(CS.any_pad);                         // wave-uniform; the robot wave reads the same flags
+    MS.st(XCH_FLAG, CS.any_pad ? 1.0 : 0.0);
+    if (coupled) {                                                  // hand the (normalised, not advanced) cube over
+      cube_to_lds(MS, CS.Cb);
+      MS.st(XCH_T0, CS.touch[0] ? 1.0 : 0.0); MS.st(XCH_T1, CS.touch[1] ? 1.0 : 0.0); MS.st(XCH_NCON, (real)CS.ncon);
+    } else {
+      CS.solve_alone();
+      CS.finish(qlag7);
+      Cb = CS.Cb;
+    }
+    __syncthreads();                                                // S2
+    if (coupled) {
+      __syncthreads();                                              // S3: the robot wave has run the coupled sub-step
+      cube_from_lds(MS, Cb);
+      for (int k = 0; k < 7; k++) qlag7[k] = MS.ld(XCH_QL7 + k);
+    }
+  }
+  cube_to_lds(MS, Cb);
+  for (int k = 0; k < 7; k++) MS.st(XCH_QL7 + k, qlag7[k]);
+  MS.st(XCH_T0, touch ? 1.0 : 0.0);
+  __syncthreads();                                                  // end of the env-step: the robot wave takes the cube
+}
+
+// the robot wave's sub-step
+template <class WLD>
+MCG_DEV void pnp_substep_robot(ModelPtr P, EnvP& E, const PnpScratch MS, const WLD& W) {
+  __syncthreads();                                                  // S1
+  Robot nx;
+  robot_substep<PnpScratch, NoCoupling, WLD, NoSplit, false>(P, E.R, E.qlag6, MS, nullptr, &W, &nx);
+  __syncthreads();                                                  // S2
+  const bool coupled = __any(MS.ld(XCH_FLAG) != 0.0);
+  if (coupled) {
+    CoupledIO<WLD> io; io.E = E; io.W = W;
+    cube_from_lds(MS, io.E.Cb);
+    io.ncon = (int)MS.ld(XCH_NCON); io.touch[0] = MS.ld(XCH_T0) != 0.0; io.touch[1] = MS.ld(XCH_T1) != 0.0;
+    pnp_substep_coupled<WLD>((unsigned long long)P, &io, (unsigned)(uintptr_t)MS.base);
+    E.R = io.E.R;
+    for (int k = 0; k < 6; k++) E.qlag6[k] = io.E.qlag6[k];
+    cube_to_lds(MS, io.E.Cb);
+    for (int k = 0; k < 7; k++) MS.st(XCH_QL7 + k, io.E.qlag7[k]);
+    static_for<NB>([&](auto I) { constexpr int k = I; MS.st(XCH_Q + k, E.R.q[k]); });
+    __syncthreads();                                                // S3
+  } else {
+    static_for<NB>([&](auto I) { constexpr int k = I; E.R.q[k] = nx.q[k]; E.R.qd[k] = nx.qd[k]; E.R.warm[k] = nx.warm[k]; MS.st(XCH_Q + k, nx.q[k]); });
+  }
+}
+
+template <int CONTROLLER, bool DUAL>
+__global__ __launch_bounds__(DUAL ? 128 : PNP_LANES) void step_pnp_kernel(Cfg C, View V, const mcg_model* __restrict__ Pg,
                                                              const float* __restrict__ actions, mcg_step_out O) {
   __shared__ real lds[PNP_SLOTS][PNP_LANES];
-  const PnpScratch MS(&lds[0][threadIdx.x]);
+  const int lane = DUAL ? (threadIdx.x & 63) : threadIdx.x;
+  if (DUAL && lane >= PNP_LANES) return;         // DUAL: two waves of 32 active lanes (threads 0-31 and 64-95)
+  const PnpScratch MS(&lds[0][lane]);
   const ModelPtr P = as_model_ptr(Pg);
-  const int i = blockIdx.x * PNP_LANES + threadIdx.x;
-  if (i >= C.n) return;
+  const int i = blockIdx.x * PNP_LANES + lane;
+  if (i >= C.n) return;                          // the same lanes leave in both waves: barriers stay matched
+  if constexpr (DUAL) {
+    if (threadIdx.x >= 64) {
+      cube_wave(V, P, MS, i, (CONTROLLER == MCG_CTRL_IK ? C.control_steps : 1) * C.frame_skip);
+      return;
+    }
+  }
   MCG_TICK_INIT();
   EnvP E;
   load_envp(V, i, E);
+  if constexpr (DUAL) static_for<NB>([&](auto I) { constexpr int k = I; MS.st(XCH_Q + k, E.R.q[k]); });   // q(0) for the cube wave
   MCG_TICK(ST_LOAD);
   E.touch = false;
+  auto substep = [&](const auto& W) { if constexpr (DUAL) pnp_substep_robot(P, E, MS, W); else pnp_substep(P, E, MS, W); };
   float act[8];
   _Pragma("unroll") for (int k = 0; k < 8; k++) {   // act_dim is 7, 4 (fetch) or 8 (mocap): static indices keep the array in registers
     const float x = (k < C.act_dim) ? actions[(size_t)i * C.act_dim + (k < C.act_dim ? k : 0)] : 0.f;
@@ -468,17 +567,23 @@ __global__ __launch_bounds__(PNP_LANES) void step_pnp_kernel(Cfg C, View V, cons
       for (int k = 0; k < 6; k++) E.R.ctrl[k] += dq[k];
       E.R.ctrl[6] = grip;
       MCG_TICK(ST_CTRL);
-      for (int s = 0; s < C.frame_skip; s++) pnp_substep(P, E, MS, NoWeld{});
+      for (int s = 0; s < C.frame_skip; s++) substep(NoWeld{});
     }
   } else if constexpr (CONTROLLER == MCG_CTRL_MOCAP) {
     Weld W; mocap_target(C, P, E.qlag6, act, W);
     E.R.ctrl[6] = C.grip_center + (real)act_last * C.grip_range;
     MCG_TICK(ST_CTRL);
-    for (int s = 0; s < C.frame_skip; s++) pnp_substep(P, E, MS, W);
+    for (int s = 0; s < C.frame_skip; s++) substep(W);
   } else {
     for (int k = 0; k < 7; k++) E.R.ctrl[k] = (real)act[k];
     MCG_TICK(ST_CTRL);
-    for (int s = 0; s < C.frame_skip; s++) pnp_substep(P, E, MS, NoWeld{});
+    for (int s = 0; s < C.frame_skip; s++) substep(NoWeld{});
+  }
+  if constexpr (DUAL) {                          // take the cube back from the cube wave
+    __syncthreads();
+    cube_from_lds(MS, E.Cb);
+    for (int k = 0; k < 7; k++) E.qlag7[k] = MS.ld(XCH_QL7 + k);
+    E.touch = MS.ld(XCH_T0) != 0.0;
   }
   guard_robot(E.R, E.qlag6);
   {   // same guard for the cube: back to its model pose at rest
@@ -721,13 +826,19 @@ int mcg_reset(mcg_env* e, const uint8_t* mask, int reseed, uint64_t seed, const 
 
 static int launch_step(mcg_env* e, const float* actions, const mcg_step_out& o, hipStream_t s) {
   if (e->cfg.has_object) {
-    dim3 grid((e->cfg.n + PNP_LANES - 1) / PNP_LANES), block(PNP_LANES);
-    if (e->cfg.controller == MCG_CTRL_IK)
-      hipLaunchKernelGGL(step_pnp_kernel<MCG_CTRL_IK>, grid, block, 0, s, e->cfg, e->view, e->d_model, actions, o);
-    else if (e->cfg.controller == MCG_CTRL_MOCAP)
-      hipLaunchKernelGGL(step_pnp_kernel<MCG_CTRL_MOCAP>, grid, block, 0, s, e->cfg, e->view, e->d_model, actions, o);
-    else
-      hipLaunchKernelGGL(step_pnp_kernel<MCG_CTRL_JOINT>, grid, block, 0, s, e->cfg, e->view, e->d_model, actions, o);
+    dim3 grid((e->cfg.n + PNP_LANES - 1) / PNP_LANES);
+    // up to one workgroup per CU: robot wave + cube wave (DUAL); beyond that the one-wave kernels
+    const bool dual = (int)grid.x <= e->num_cu && !e->no_split;
+    const dim3 block(dual ? 128 : PNP_LANES);
+#define MCG_LAUNCH_PNP(CTRL)                                                                                                   \
+  do {                                                                                                                         \
+    if (dual) hipLaunchKernelGGL((step_pnp_kernel<CTRL, true>), grid, block, 0, s, e->cfg, e->view, e->d_model, actions, o);       \
+    else hipLaunchKernelGGL((step_pnp_kernel<CTRL, false>), grid, block, 0, s, e->cfg, e->view, e->d_model, actions, o);           \
+  } while (0)
+    if (e->cfg.controller == MCG_CTRL_IK) MCG_LAUNCH_PNP(MCG_CTRL_IK);
+    else if (e->cfg.controller == MCG_CTRL_MOCAP) MCG_LAUNCH_PNP(MCG_CTRL_MOCAP);
+    else MCG_LAUNCH_PNP(MCG_CTRL_JOINT);
+#undef MCG_LAUNCH_PNP
     return hipGetLastError() == hipSuccess ? MCG_OK : MCG_ERR_HIP;
   }
   dim3 grid((e->cfg.n + 63) / 64);
