@@ -827,8 +827,9 @@ int mcg_reset(mcg_env* e, const uint8_t* mask, int reseed, uint64_t seed, const 
 static int launch_step(mcg_env* e, const float* actions, const mcg_step_out& o, hipStream_t s) {
   if (e->cfg.has_object) {
     dim3 grid((e->cfg.n + PNP_LANES - 1) / PNP_LANES);
-    // up to one workgroup per CU: robot wave + cube wave (DUAL); beyond that the one-wave kernels
-    const bool dual = (int)grid.x <= e->num_cu && !e->no_split;
+    // robot wave + cube wave (DUAL) at every grid size: the 157 KB of LDS allow one workgroup per CU either way, so the
+    // second wave always runs on a SIMD that would idle (measured: 16 384 envs 0.91 ms against 2.27 ms with one wave)
+    const bool dual = !e->no_split;
     const dim3 block(dual ? 128 : PNP_LANES);
 #define MCG_LAUNCH_PNP(CTRL)                                                                                                   \
   do {                                                                                                                         \

@@ -19,7 +19,7 @@ for obj, ctrl in ((False, "joint"), (False, "IK"), (False, "mocap"), (True, "joi
         g = torch.Generator(device="cuda"); g.manual_seed(1)
         pool = torch.rand(8, n, envs.action_dim, device="cuda", generator=g) * 2 - 1
         k = max(8, min(200, int(2.0e6 / n) * (1 if ctrl != "IK" else 1) // (5 if ctrl == "IK" else 1)))
-        for t in range(60): envs.step_async(pool[t % 8])
+        for t in range(max(60, k)): envs.step_async(pool[t % 8])     # sustained load first: short windows run at idle clocks
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
