@@ -465,13 +465,16 @@ MCG_DEV void cube_wave(const View& V, ModelPtr P, const PnpScratch MS, int i, in
   for (int k = 0; k < 7; k++) qlag7[k] = V.qlag(12 + k, i);
   dr[0] = V.dr(0, i); dr[1] = V.dr(1, i);
   bool touch = false;
+  MCG_TICK2_INIT();
   for (int s = 0; s < total; s++) {
     __syncthreads();                                                // S1
+    MCG_TICK2(ST_W2_WAIT1);
     real q10[10];
     static_for<10>([&](auto I) { constexpr int k = I; q10[k] = MS.ld(XCH_Q + k); });
     CubeSys<PnpScratch> CS(MS, Cb, dr);
     CS.prepare(P, q10);
     touch = CS.touch[0] && CS.touch[1];
+    MCG_TICK2(ST_W2_COLLIDE);
     const bool coupled = __any(CS.any_pad);                         // wave-uniform; the robot wave reads the same flags
     MS.st(XCH_FLAG, CS.any_pad ? 1.0 : 0.0);
     if (coupled) {                                                  // hand the (normalised, not advanced) cube over
@@ -482,7 +485,9 @@ MCG_DEV void cube_wave(const View& V, ModelPtr P, const PnpScratch MS, int i, in
       CS.finish(qlag7);
       Cb = CS.Cb;
     }
+    MCG_TICK2(ST_W2_CUBE);
     __syncthreads();                                                // S2
+    MCG_TICK2(ST_W2_WAIT2);
     if (coupled) {
       __syncthreads();                                              // S3: the robot wave has run the coupled sub-step
       cube_from_lds(MS, Cb);
@@ -501,7 +506,9 @@ MCG_DEV void pnp_substep_robot(ModelPtr P, EnvP& E, const PnpScratch MS, const W
   __syncthreads();                                                  // S1
   Robot nx;
   robot_substep<PnpScratch, NoCoupling, WLD, NoSplit, false>(P, E.R, E.qlag6, MS, nullptr, &W, &nx);
+  MCG_TICK(ST_POST);
   __syncthreads();                                                  // S2
+  MCG_TICK(ST_W1_WAIT);
   const bool coupled = __any(MS.ld(XCH_FLAG) != 0.0);
   if (coupled) {
     CoupledIO<WLD> io; io.E = E; io.W = W;

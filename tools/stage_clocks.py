@@ -17,7 +17,9 @@ NAMES = ["load", "controller", "sincos", "rne", "actuation", "crb->M", "rows: we
          "newton: build H", "newton: factor H", "newton: solve", "newton: active-set check", "euler: forces/rhs",
          "rows: arm axes in link6 frame", "rows: connects + coupling", "rows: limits",
          "coupled: initial masks", "coupled: assembly over contacts", "coupled: Schur complement", "coupled: LDL + back-substitution",
-         "coupled: consistency + line-search rows", "coupled: line search + remask"]
+         "coupled: consistency + line-search rows", "coupled: line search + remask",
+         "cube wave: waiting for q (S1)", "cube wave: collision", "cube wave: solve + finish", "cube wave: waiting at S2",
+         "robot wave: waiting at S2"]
 COUNTS = ["robot sub-steps", "robot Newton iterations", "robot line searches", "cube Newton iterations", "cube line searches",
           "coupled solves", "coupled Newton iterations", "coupled line searches", "wave-max contacts (per collision pass)"]
 fresh = "--fresh-actions" in sys.argv
