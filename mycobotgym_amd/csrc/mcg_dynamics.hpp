@@ -349,7 +349,8 @@ constexpr int LDS_M = 0;                              // packed lower triangle o
 constexpr int LDS_HEQ = NB * (NB + 1) / 2;            // H_eq = M + J^T D J over the equality (and weld) rows  (78 slots)
 constexpr int LDS_SLOTS = 2 * (NB * (NB + 1) / 2);
 // two-wave variant (SplitA / helper_substep): factor of M + hB, its reciprocal pivots, and q published for the helper wave
-constexpr int LDS_FAC = LDS_SLOTS, LDS_FDINV = LDS_FAC + NB * (NB + 1) / 2, LDS_QB = LDS_FDINV + NB, LDS_SLOTS_SPLIT = LDS_QB + NB;
+constexpr int LDS_FAC = LDS_SLOTS, LDS_FDINV = LDS_FAC + NB * (NB + 1) / 2, LDS_QB = LDS_FDINV + NB, LDS_QDB = LDS_QB + NB;
+constexpr int LDS_FS = LDS_QDB + NB, LDS_SLOTS_SPLIT = LDS_FS + NB;
 // The lane's LDS column.  The pointer carries the LDS address space explicitly: passed through structs as a generic
 // pointer the accesses degrade to flat_load/flat_store with 64-bit address arithmetic instead of ds_read/ds_write
 // with immediate offsets.
@@ -432,6 +433,58 @@ MCG_DEV void tcp_forward(ModelPtr P, const real* q6, TcpPose& X, bool want_jac) 
   }
 }
 
+// ---- P6 recursive Newton-Euler, q'' = 0: bias = Coriolis + centrifugal + gravity        (mj_rne, flg_acc=0)
+// fs <- passive (joint damping) - bias.  Depends on q (through cs / sn), qd and the model only.
+MCG_DEV void rne_bias(ModelPtr Pm, const real* cs, const real* sn, const real* qd, real* fs) {
+  real F[NB][3], Nn[NB][3];                 // net force / moment about the body origin, body frame
+  real w[NB][3], al[NB][3], ac[NB][3];      // angular velocity, angular acceleration, linear acceleration of the origin
+  static_for<NB>([&](auto I) {
+    constexpr int i = I; constexpr int p = PAR[i]; constexpr int K = AXK[i];
+    constexpr int A = (K + 1) % 3, B = (K + 2) % 3;
+    const BodyC bc = load_body(launder(Pm), i); const BodyC* b = &bc;
+    const real g = AXS[i] * qd[i];
+    if constexpr (p < 0) {
+      // static base: w_p = al_p = 0, a_p = -gravity (base frame)
+      real gb[3]; ldc<3>(launder(Pm)->gravity_base, gb);
+      rot_down<K>(cs[i], sn[i], gb, ac[i]);
+      w[i][0] = w[i][1] = w[i][2] = 0; w[i][K] = g;
+      al[i][0] = al[i][1] = al[i][2] = 0;
+    } else {
+      real t[3], accp[3], we[3];
+      cross(w[p], b->r, t);
+      accp[0] = ac[p][0]; accp[1] = ac[p][1]; accp[2] = ac[p][2];
+      cross_add(al[p], b->r, accp); cross_add(w[p], t, accp);
+      rot_down<K>(cs[i], sn[i], accp, ac[i]);
+      rot_down<K>(cs[i], sn[i], w[p], we);
+      rot_down<K>(cs[i], sn[i], al[p], al[i]);
+      al[i][A] += we[B] * g; al[i][B] -= we[A] * g;          // + (E w_p) x (g e_K)
+      w[i][0] = we[0]; w[i][1] = we[1]; w[i][2] = we[2]; w[i][K] += g;
+    }
+    real t2[3], Iw[3];
+    cross(w[i], b->mc, t2);
+    F[i][0] = b->mass * ac[i][0]; F[i][1] = b->mass * ac[i][1]; F[i][2] = b->mass * ac[i][2];
+    cross_add(al[i], b->mc, F[i]); cross_add(w[i], t2, F[i]);
+    sym_mul(b->inertia, al[i], Nn[i]); sym_mul(b->inertia, w[i], Iw);
+    cross_add(w[i], Iw, Nn[i]); cross_add(b->mc, ac[i], Nn[i]);
+    pin3(F[i]); pin3(Nn[i]);
+    MCG_FENCE();
+  });
+  static_for<NB>([&](auto I) {
+    constexpr int i = NB - 1 - I; constexpr int p = PAR[i]; constexpr int K = AXK[i];
+    const BodyC bc = load_body(launder(Pm), i); const BodyC* b = &bc;
+    fs[i] = -b->damping * qd[i] - AXS[i] * Nn[i][K];
+    if constexpr (p >= 0) {
+      real fp[3], np[3];
+      rot_up<K>(cs[i], sn[i], F[i], fp); rot_up<K>(cs[i], sn[i], Nn[i], np);
+      cross_add(b->r, fp, np);
+      for (int k = 0; k < 3; k++) { F[p][k] += fp[k]; Nn[p][k] += np[k]; }
+      pin3(F[p]); pin3(Nn[p]);
+    }
+    pin(fs[i]);
+    MCG_FENCE();
+  });
+}
+
 // ---- P3 composite rigid bodies -> joint-space inertia M (packed lower triangle, in LDS)      (mj_crb)
 // Depends on the joint angles (through cs / sn) and the model only.
 template <class LS>
@@ -508,15 +561,16 @@ MCG_DEV void crb_to_lds(ModelPtr Pm, const real* cs, const real* sn, const LS MS
     });
 }
 
-// Two-wave variant (Reach, grids of at most one workgroup per CU, where 3 of the 4 SIMDs of a CU would idle): the workgroup
-// has a second wave over the same 64 environments.  It computes what depends on the joint angles alone -- M by the composite
-// rigid body pass, then the L^T D L factor of M + hB for the Euler step -- while the main wave does the bias forces, actuation
-// and constraint rows.  Three workgroup barriers per sub-step:
-//   S1  q(t) is published in LDS              (helper may read it)
-//   S2  M(t) is in LDS                        (main wave assembles H_eq, runs the Newton solve)
+// Three-wave variant (Reach, grids of at most one workgroup per CU, where 3 of the 4 SIMDs of a CU would idle): the workgroup
+// has two more waves over the same 64 environments.  The HELPER wave computes what depends on the joint angles alone -- M by
+// the composite rigid body pass, then the L^T D L factor of M + hB for the Euler step; the RNE wave computes the bias forces;
+// the main wave does actuation and constraint rows meanwhile, then H_eq, the Newton solve and the Euler step.  Three workgroup
+// barriers per sub-step:
+//   S1  q(t), qd(t) are published in LDS      (the other waves may read them)
+//   S2  M(t) and passive - bias are in LDS    (main wave: g0, H_eq, Newton solve)
 //   S3  the factor of M + hB is in LDS        (main wave: a' = a - h (M + hB)^-1 (B a), which equals (M + hB)^-1 M a)
-struct NoSplit { static constexpr bool enabled = false; };
-struct SplitMain { static constexpr bool enabled = true; };
+struct NoSplit { static constexpr bool enabled = false; static constexpr bool rne_remote = false; };
+struct SplitMain { static constexpr bool enabled = true; static constexpr bool rne_remote = true; };
 
 // COMMIT = false: the new q / qd / qacc_warmstart go to *next and S stays as it was (speculative sub-step of the two-wave
 // PickAndPlace kernel: discarded when the helper wave's collision pass finds a pad contact).
@@ -536,56 +590,9 @@ MCG_DEV void robot_substep(ModelPtr Pm, Robot& S, real* qlag6, const LS MS, CPL*
   MCG_FENCE();
 
   MCG_TICK(ST_TRIG);
-  // ---- P6 recursive Newton-Euler, q'' = 0: bias = Coriolis + centrifugal + gravity        (mj_rne, flg_acc=0)
-  real F[NB][3], Nn[NB][3];                 // net force / moment about the body origin, body frame
-  real w[NB][3], al[NB][3], ac[NB][3];      // angular velocity, angular acceleration, linear acceleration of the origin
-  static_for<NB>([&](auto I) {
-    constexpr int i = I; constexpr int p = PAR[i]; constexpr int K = AXK[i];
-    constexpr int A = (K + 1) % 3, B = (K + 2) % 3;
-    const BodyC bc = load_body(launder(Pm), i); const BodyC* b = &bc;
-    const real g = AXS[i] * S.qd[i];
-    if constexpr (p < 0) {
-      // static base: w_p = al_p = 0, a_p = -gravity (base frame)
-      real gb[3]; ldc<3>(launder(Pm)->gravity_base, gb);
-      rot_down<K>(cs[i], sn[i], gb, ac[i]);
-      w[i][0] = w[i][1] = w[i][2] = 0; w[i][K] = g;
-      al[i][0] = al[i][1] = al[i][2] = 0;
-    } else {
-      real t[3], accp[3], we[3];
-      cross(w[p], b->r, t);
-      accp[0] = ac[p][0]; accp[1] = ac[p][1]; accp[2] = ac[p][2];
-      cross_add(al[p], b->r, accp); cross_add(w[p], t, accp);
-      rot_down<K>(cs[i], sn[i], accp, ac[i]);
-      rot_down<K>(cs[i], sn[i], w[p], we);
-      rot_down<K>(cs[i], sn[i], al[p], al[i]);
-      al[i][A] += we[B] * g; al[i][B] -= we[A] * g;          // + (E w_p) x (g e_K)
-      w[i][0] = we[0]; w[i][1] = we[1]; w[i][2] = we[2]; w[i][K] += g;
-    }
-    real t2[3], Iw[3];
-    cross(w[i], b->mc, t2);
-    F[i][0] = b->mass * ac[i][0]; F[i][1] = b->mass * ac[i][1]; F[i][2] = b->mass * ac[i][2];
-    cross_add(al[i], b->mc, F[i]); cross_add(w[i], t2, F[i]);
-    sym_mul(b->inertia, al[i], Nn[i]); sym_mul(b->inertia, w[i], Iw);
-    cross_add(w[i], Iw, Nn[i]); cross_add(b->mc, ac[i], Nn[i]);
-    pin3(F[i]); pin3(Nn[i]);
-    MCG_FENCE();
-  });
   real fs[NB];        // becomes qfrc_smooth = passive - bias + actuation
-  static_for<NB>([&](auto I) {
-    constexpr int i = NB - 1 - I; constexpr int p = PAR[i]; constexpr int K = AXK[i];
-    const BodyC bc = load_body(launder(Pm), i); const BodyC* b = &bc;
-    fs[i] = -b->damping * S.qd[i] - AXS[i] * Nn[i][K];
-    if constexpr (p >= 0) {
-      real fp[3], np[3];
-      rot_up<K>(cs[i], sn[i], F[i], fp); rot_up<K>(cs[i], sn[i], Nn[i], np);
-      cross_add(b->r, fp, np);
-      for (int k = 0; k < 3; k++) { F[p][k] += fp[k]; Nn[p][k] += np[k]; }
-      pin3(F[p]); pin3(Nn[p]);
-    }
-    pin(fs[i]);
-    MCG_FENCE();
-  });
-
+  if constexpr (SPL::rne_remote) { static_for<NB>([&](auto I) { constexpr int i = I; fs[i] = 0; }); }   // a third wave computes it meanwhile
+  else rne_bias(Pm, cs, sn, S.qd, fs);
   MCG_TICK(ST_RNE);
   // ---- P7 actuation                                                             (mj_fwdActuation)
   {
@@ -738,6 +745,10 @@ MCG_DEV void robot_substep(ModelPtr Pm, Robot& S, real* qlag6, const LS MS, CPL*
   }
 
   MCG_TICK(ST_ROWS);
+  if constexpr (SPL::enabled) {
+    __syncthreads();                                                // S2: M and passive - bias are in LDS
+    if constexpr (SPL::rne_remote) static_for<NB>([&](auto I) { constexpr int i = I; fs[i] += MS.ld(LDS_FS + i); });
+  }
   // ---- P8/P9: g0 = qfrc_smooth + J^T D aref over the equality rows                          (Newton system)
   real g0[NB];
   static_for<NB>([&](auto I) { constexpr int i = I; g0[i] = fs[i]; });
@@ -754,7 +765,6 @@ MCG_DEV void robot_substep(ModelPtr Pm, Robot& S, real* qlag6, const LS MS, CPL*
   if constexpr (WLD::enabled)
     static_for<6>([&](auto Rr) { constexpr int r = Rr; const real da = Dw * arefw[r];
       static_for<6>([&](auto I) { constexpr int j = I; g0[j] = fma(Jw[r][j], da, g0[j]); }); });
-  if constexpr (SPL::enabled) __syncthreads();                     // S2: M is in LDS
   // H_eq = M + J^T D J over the equality rows (two connects, gear coupling, mocap weld) is assembled ONCE per sub-step,
   // group by group (arm block, then each side's gripper rows: at most 24 accumulators live), and parked in LDS next to M.
   // The connect / weld Jacobians are dead from here on: the Newton iterations and the line search read H_eq back and add the
@@ -916,7 +926,7 @@ MCG_DEV void robot_substep(ModelPtr Pm, Robot& S, real* qlag6, const LS MS, CPL*
     const real qd_new = fma(h, rhs[i], S.qd[i]), q_new = fma(h, qd_new, S.q[i]);
     if constexpr (COMMIT) { S.qd[i] = qd_new; S.q[i] = q_new; S.warm[i] = a[i]; }
     else { next->qd[i] = qd_new; next->q[i] = q_new; next->warm[i] = a[i]; }
-    if constexpr (SPL::enabled) MS.st(LDS_QB + i, q_new); });
+    if constexpr (SPL::enabled) { MS.st(LDS_QB + i, q_new); MS.st(LDS_QDB + i, qd_new); } });
   MCG_TICK_PIN(S.q, NB); MCG_TICK_PIN(S.qd, NB);
   MCG_TICK(ST_EULER);
 }
@@ -944,6 +954,23 @@ MCG_DEV void helper_substep(ModelPtr Pm, const LS MS) {
     static_for<NB>([&](auto I) { constexpr int i = I; MS.st(LDS_FDINV + i, dinv[i]);
       static_for<i>([&](auto Jj) { constexpr int j = Jj; if constexpr (PAT_M.nz[i][j]) MS.st(LDS_FAC + tri(i, j), Mh[tri(i, j)]); }); });
   }
+  __syncthreads();                                                  // S3
+}
+
+// The RNE wave's share of one sub-step (see SplitMain).
+template <class LS>
+MCG_DEV void rne_substep(ModelPtr Pm, const LS MS) {
+  __syncthreads();                                                  // S1
+  real cs[NB], sn[NB], qd[NB], fs[NB];
+  {
+    const TrigC T = load_trig();
+    static_for<NB>([&](auto I) { constexpr int i = I; sincos_cw(T, AXS[i] * MS.ld(LDS_QB + i), sn[i], cs[i]); qd[i] = MS.ld(LDS_QDB + i); });
+  }
+  static_for<NB>([&](auto I) { constexpr int i = I; pin(sn[i]); pin(cs[i]); });
+  MCG_FENCE();
+  rne_bias(Pm, cs, sn, qd, fs);
+  static_for<NB>([&](auto I) { constexpr int i = I; MS.st(LDS_FS + i, fs[i]); });
+  __syncthreads();                                                  // S2
   __syncthreads();                                                  // S3
 }
 

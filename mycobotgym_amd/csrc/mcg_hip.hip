@@ -170,10 +170,10 @@ MCG_DEV void mocap_target(const Cfg& C, ModelPtr P, const real* qlag6, const flo
   normalize4(W.quat);
 }
 
-// SPLIT: two waves per 64 environments (see SplitMain in mcg_dynamics.hpp): launched when the grid has at most one workgroup
-// per CU, where the second wave runs on a SIMD that would idle.  132 KB of LDS per workgroup.
+// SPLIT: three waves per 64 environments (see SplitMain in mcg_dynamics.hpp): launched when the grid has at most one workgroup
+// per CU, where the extra waves run on SIMDs that would idle.  144 KB of LDS per workgroup.
 template <int CONTROLLER, bool SPLIT>
-__global__ __launch_bounds__(SPLIT ? 128 : 64) void step_reach_kernel(Cfg C, View V, const mcg_model* __restrict__ Pg,
+__global__ __launch_bounds__(SPLIT ? 192 : 64) void step_reach_kernel(Cfg C, View V, const mcg_model* __restrict__ Pg,
                                                                       const float* __restrict__ actions, mcg_step_out O) {
   typedef std::conditional_t<SPLIT, SplitMain, NoSplit> Split;
   __shared__ real lds[SPLIT ? LDS_SLOTS_SPLIT : LDS_SLOTS][64];
@@ -183,16 +183,17 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64) void step_reach_kernel(Cfg C, Vie
   const int i = blockIdx.x * 64 + lane;
   if (i >= C.n) return;                          // the same lanes leave in both waves: barriers stay matched
   if constexpr (SPLIT) {
-    if (threadIdx.x >= 64) {                     // helper wave: M and the Euler factor for every sub-step, nothing else
+    if (threadIdx.x >= 64) {                     // helper wave: M and the Euler factor; RNE wave: passive - bias forces
       const int total = (CONTROLLER == MCG_CTRL_IK ? C.control_steps : 1) * C.frame_skip;
-      for (int s = 0; s < total; s++) helper_substep(P, MS);
+      if (threadIdx.x < 128) { for (int s = 0; s < total; s++) helper_substep(P, MS); }
+      else { for (int s = 0; s < total; s++) rne_substep(P, MS); }
       return;
     }
   }
   MCG_TICK_INIT();
   Env E;
   load_env(V, i, E);
-  if constexpr (SPLIT) static_for<NB>([&](auto I) { constexpr int k = I; MS.st(LDS_QB + k, E.R.q[k]); });   // q(0) for the helper
+  if constexpr (SPLIT) static_for<NB>([&](auto I) { constexpr int k = I; MS.st(LDS_QB + k, E.R.q[k]); MS.st(LDS_QDB + k, E.R.qd[k]); });   // q(0), qd(0) for the other waves
   MCG_TICK(ST_LOAD);
   float act[8];
   _Pragma("unroll") for (int k = 0; k < 8; k++) {   // act_dim is 7, 4 (fetch) or 8 (mocap): static indices keep the array in registers
@@ -852,7 +853,7 @@ static int launch_step(mcg_env* e, const float* actions, const mcg_step_out& o, 
   dim3 grid((e->cfg.n + 63) / 64);
   // up to one workgroup per CU three SIMDs of every CU would idle: the two-wave variant puts a helper wave on one of them
   const bool split = (int)grid.x <= e->num_cu && !e->no_split;
-  const dim3 block(split ? 128 : 64);
+  const dim3 block(split ? 192 : 64);
 #define MCG_LAUNCH_REACH(CTRL)                                                                                                 \
   do {                                                                                                                         \
     if (split) hipLaunchKernelGGL((step_reach_kernel<CTRL, true>), grid, block, 0, s, e->cfg, e->view, e->d_model, actions, o);     \
