@@ -569,8 +569,10 @@ MCG_DEV void crb_to_lds(ModelPtr Pm, const real* cs, const real* sn, const LS MS
 //   S1  q(t), qd(t) are published in LDS      (the other waves may read them)
 //   S2  M(t) and passive - bias are in LDS    (main wave: g0, H_eq, Newton solve)
 //   S3  the factor of M + hB is in LDS        (main wave: a' = a - h (M + hB)^-1 (B a), which equals (M + hB)^-1 M a)
-struct NoSplit { static constexpr bool enabled = false; static constexpr bool rne_remote = false; };
-struct SplitMain { static constexpr bool enabled = true; static constexpr bool rne_remote = true; };
+// A split policy says which pieces other waves provide and where the exchange slots are.
+struct NoSplit { static constexpr bool enabled = false, rne_remote = false, factor_remote = false; static constexpr int QB = 0, QDB = 0, FS = 0; };
+struct SplitMain { static constexpr bool enabled = true, rne_remote = true, factor_remote = true;
+                   static constexpr int QB = LDS_QB, QDB = LDS_QDB, FS = LDS_FS; };
 
 // COMMIT = false: the new q / qd / qacc_warmstart go to *next and S stays as it was (speculative sub-step of the two-wave
 // PickAndPlace kernel: discarded when the helper wave's collision pass finds a pad contact).
@@ -747,7 +749,7 @@ MCG_DEV void robot_substep(ModelPtr Pm, Robot& S, real* qlag6, const LS MS, CPL*
   MCG_TICK(ST_ROWS);
   if constexpr (SPL::enabled) {
     __syncthreads();                                                // S2: M and passive - bias are in LDS
-    if constexpr (SPL::rne_remote) static_for<NB>([&](auto I) { constexpr int i = I; fs[i] += MS.ld(LDS_FS + i); });
+    if constexpr (SPL::rne_remote) static_for<NB>([&](auto I) { constexpr int i = I; fs[i] += MS.ld(SPL::FS + i); });
   }
   // ---- P8/P9: g0 = qfrc_smooth + J^T D aref over the equality rows                          (Newton system)
   real g0[NB];
@@ -898,7 +900,7 @@ MCG_DEV void robot_substep(ModelPtr Pm, Robot& S, real* qlag6, const LS MS, CPL*
   MCG_TICK(ST_NEWTON);
   // ---- constraint forces -> qfrc_constraint; P10 implicit-damping Euler                  (mj_Euler, mj_advance)
   real rhs[NB];
-  if constexpr (SPL::enabled) {
+  if constexpr (SPL::factor_remote) {
     __syncthreads();                                                // S3: the helper's factor of M + hB is in LDS
     real Lf[NB * (NB + 1) / 2], dinv[NB];
     static_for<NB>([&](auto I) { constexpr int i = I; dinv[i] = MS.ld(LDS_FDINV + i);
@@ -926,25 +928,25 @@ MCG_DEV void robot_substep(ModelPtr Pm, Robot& S, real* qlag6, const LS MS, CPL*
     const real qd_new = fma(h, rhs[i], S.qd[i]), q_new = fma(h, qd_new, S.q[i]);
     if constexpr (COMMIT) { S.qd[i] = qd_new; S.q[i] = q_new; S.warm[i] = a[i]; }
     else { next->qd[i] = qd_new; next->q[i] = q_new; next->warm[i] = a[i]; }
-    if constexpr (SPL::enabled) { MS.st(LDS_QB + i, q_new); MS.st(LDS_QDB + i, qd_new); } });
+    if constexpr (SPL::enabled && COMMIT) { MS.st(SPL::QB + i, q_new); MS.st(SPL::QDB + i, qd_new); } });
   MCG_TICK_PIN(S.q, NB); MCG_TICK_PIN(S.qd, NB);
   MCG_TICK(ST_EULER);
 }
 
 // The helper wave's share of one sub-step (see SplitMain).
-template <class LS>
+template <class SPL = SplitMain, class LS>
 MCG_DEV void helper_substep(ModelPtr Pm, const LS MS) {
   __syncthreads();                                                  // S1
   real cs[NB], sn[NB];
   {
     const TrigC T = load_trig();
-    static_for<NB>([&](auto I) { constexpr int i = I; sincos_cw(T, AXS[i] * MS.ld(LDS_QB + i), sn[i], cs[i]); });
+    static_for<NB>([&](auto I) { constexpr int i = I; sincos_cw(T, AXS[i] * MS.ld(SPL::QB + i), sn[i], cs[i]); });
   }
   static_for<NB>([&](auto I) { constexpr int i = I; pin(sn[i]); pin(cs[i]); });
   MCG_FENCE();
   crb_to_lds(Pm, cs, sn, MS);
   __syncthreads();                                                  // S2
-  {
+  if constexpr (SPL::factor_remote) {
     const real h = launder(Pm)->timestep;
     real Mh[NB * (NB + 1) / 2], dinv[NB];
     static_for<NB>([&](auto I) { constexpr int i = I;
@@ -953,25 +955,25 @@ MCG_DEV void helper_substep(ModelPtr Pm, const LS MS) {
     ldl_factor<PAT_M>(Mh, dinv);
     static_for<NB>([&](auto I) { constexpr int i = I; MS.st(LDS_FDINV + i, dinv[i]);
       static_for<i>([&](auto Jj) { constexpr int j = Jj; if constexpr (PAT_M.nz[i][j]) MS.st(LDS_FAC + tri(i, j), Mh[tri(i, j)]); }); });
+    __syncthreads();                                                // S3
   }
-  __syncthreads();                                                  // S3
 }
 
 // The RNE wave's share of one sub-step (see SplitMain).
-template <class LS>
+template <class SPL = SplitMain, class LS>
 MCG_DEV void rne_substep(ModelPtr Pm, const LS MS) {
   __syncthreads();                                                  // S1
   real cs[NB], sn[NB], qd[NB], fs[NB];
   {
     const TrigC T = load_trig();
-    static_for<NB>([&](auto I) { constexpr int i = I; sincos_cw(T, AXS[i] * MS.ld(LDS_QB + i), sn[i], cs[i]); qd[i] = MS.ld(LDS_QDB + i); });
+    static_for<NB>([&](auto I) { constexpr int i = I; sincos_cw(T, AXS[i] * MS.ld(SPL::QB + i), sn[i], cs[i]); qd[i] = MS.ld(SPL::QDB + i); });
   }
   static_for<NB>([&](auto I) { constexpr int i = I; pin(sn[i]); pin(cs[i]); });
   MCG_FENCE();
   rne_bias(Pm, cs, sn, qd, fs);
-  static_for<NB>([&](auto I) { constexpr int i = I; MS.st(LDS_FS + i, fs[i]); });
+  static_for<NB>([&](auto I) { constexpr int i = I; MS.st(SPL::FS + i, fs[i]); });
   __syncthreads();                                                  // S2
-  __syncthreads();                                                  // S3
+  if constexpr (SPL::factor_remote) __syncthreads();                // S3
 }
 
 // ---------------------------------------------------------------------------------- world-frame arm kinematics

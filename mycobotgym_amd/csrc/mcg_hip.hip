@@ -436,15 +436,26 @@ MCG_DEV void pnp_substep(ModelPtr P, EnvP& E, const PnpScratch MS, const WLD& W)
 // grid has at most one workgroup per CU the workgroup gets a second wave over the same 32 environments: the CUBE wave owns
 // the cube for the whole env-step while the ROBOT wave runs the robot pipeline speculatively (results held back).  Two
 // workgroup barriers per sub-step:
-//   S1  q(t) of the robot is published                 (the cube wave needs the pads' pose for the collision pass)
-//   S2  contact list, pad-contact flags are published  (both waves take the same wave-uniform decision)
+//   S1  q(t), qd(t) of the robot are published         (the cube wave needs the pads' pose for the collision pass)
+//   S2  M, passive - bias (helper and RNE waves, as in the Reach kernel) and the collision results are published
+//   S4  both sides are done                            (all waves take the same wave-uniform decision from the flags)
 // no pad contact in the wave: the robot wave commits, the cube wave has already advanced the cube.  Otherwise the cube wave
 // has left the cube untouched and published it; the robot wave discards its result, runs the coupled sub-step
 // (pnp_substep_coupled, as the one-wave kernel does) and hands the cube back (barrier S3).
 // Exchange area: the clip-polygon slots, which only the collision pass uses.
 constexpr int XCH_FLAG = LDS_POLY, XCH_T0 = LDS_POLY + 1, XCH_T1 = LDS_POLY + 2, XCH_NCON = LDS_POLY + 3;
-constexpr int XCH_CB = LDS_POLY + 4, XCH_QL7 = LDS_POLY + 23, XCH_Q = LDS_POLY + 32;
-static_assert(XCH_Q + NB <= LDS_POLY + 64, "exchange area exceeds the clip-polygon slots");
+constexpr int XCH_CB = LDS_POLY + 4, XCH_QL7 = LDS_POLY + 23;
+static_assert(XCH_QL7 + 7 <= LDS_POLY + 64, "exchange area exceeds the clip-polygon slots");
+// q(t), qd(t) for the other waves sit in the H_eq area: they are read right after S1, H_eq is only assembled after S2 (the
+// clip-polygon slots will not do: the cube wave's collision pass overwrites them while the helper and RNE waves still read)
+constexpr int XCH_Q = LDS_HEQ, XCH_QD = LDS_HEQ + NB;
+constexpr int XCH_FS = PNP_SLOTS;                 // 12 more slots: 640 x 32 lanes x 8 B = the CU's 160 KB exactly
+constexpr int PNP_SLOTS_DUAL = PNP_SLOTS + NB;
+static_assert(PNP_SLOTS_DUAL * PNP_LANES * 8 <= 160 * 1024, "LDS of a CU");
+// robot-side split of the four-wave PickAndPlace kernel: M from the helper wave, passive - bias from the RNE wave; the Euler
+// step stays with M a (no room for the factor in LDS)
+struct SplitPnp { static constexpr bool enabled = true, rne_remote = true, factor_remote = false;
+                  static constexpr int QB = XCH_Q, QDB = XCH_QD, FS = XCH_FS; };
 
 MCG_DEV void cube_to_lds(const PnpScratch MS, const Cube& Cb) {
   for (int k = 0; k < 3; k++) MS.st(XCH_CB + k, Cb.pos[k]);
@@ -481,16 +492,18 @@ MCG_DEV void cube_wave(const View& V, ModelPtr P, const PnpScratch MS, int i, in
     if (coupled) {                                                  // hand the (normalised, not advanced) cube over
       cube_to_lds(MS, CS.Cb);
       MS.st(XCH_T0, CS.touch[0] ? 1.0 : 0.0); MS.st(XCH_T1, CS.touch[1] ? 1.0 : 0.0); MS.st(XCH_NCON, (real)CS.ncon);
-    } else {
+    }
+    __syncthreads();                                                // S2 (the robot side's "M and bias ready")
+    if (!coupled) {
       CS.solve_alone();
       CS.finish(qlag7);
       Cb = CS.Cb;
     }
     MCG_TICK2(ST_W2_CUBE);
-    __syncthreads();                                                // S2
+    __syncthreads();                                                // S4: end of the sub-step
     MCG_TICK2(ST_W2_WAIT2);
     if (coupled) {
-      __syncthreads();                                              // S3: the robot wave has run the coupled sub-step
+      __syncthreads();                                              // S5: the robot wave has run the coupled sub-step
       cube_from_lds(MS, Cb);
       for (int k = 0; k < 7; k++) qlag7[k] = MS.ld(XCH_QL7 + k);
     }
@@ -504,11 +517,10 @@ MCG_DEV void cube_wave(const View& V, ModelPtr P, const PnpScratch MS, int i, in
 // the robot wave's sub-step
 template <class WLD>
 MCG_DEV void pnp_substep_robot(ModelPtr P, EnvP& E, const PnpScratch MS, const WLD& W) {
-  __syncthreads();                                                  // S1
   Robot nx;
-  robot_substep<PnpScratch, NoCoupling, WLD, NoSplit, false>(P, E.R, E.qlag6, MS, nullptr, &W, &nx);
+  robot_substep<PnpScratch, NoCoupling, WLD, SplitPnp, false>(P, E.R, E.qlag6, MS, nullptr, &W, &nx);     // S1, S2 inside
   MCG_TICK(ST_POST);
-  __syncthreads();                                                  // S2
+  __syncthreads();                                                  // S4
   MCG_TICK(ST_W1_WAIT);
   const bool coupled = __any(MS.ld(XCH_FLAG) != 0.0);
   if (coupled) {
@@ -520,33 +532,46 @@ MCG_DEV void pnp_substep_robot(ModelPtr P, EnvP& E, const PnpScratch MS, const W
     for (int k = 0; k < 6; k++) E.qlag6[k] = io.E.qlag6[k];
     cube_to_lds(MS, io.E.Cb);
     for (int k = 0; k < 7; k++) MS.st(XCH_QL7 + k, io.E.qlag7[k]);
-    static_for<NB>([&](auto I) { constexpr int k = I; MS.st(XCH_Q + k, E.R.q[k]); });
-    __syncthreads();                                                // S3
+    static_for<NB>([&](auto I) { constexpr int k = I; MS.st(XCH_Q + k, E.R.q[k]); MS.st(XCH_QD + k, E.R.qd[k]); });
+    __syncthreads();                                                // S5
   } else {
-    static_for<NB>([&](auto I) { constexpr int k = I; E.R.q[k] = nx.q[k]; E.R.qd[k] = nx.qd[k]; E.R.warm[k] = nx.warm[k]; MS.st(XCH_Q + k, nx.q[k]); });
+    static_for<NB>([&](auto I) { constexpr int k = I; E.R.q[k] = nx.q[k]; E.R.qd[k] = nx.qd[k]; E.R.warm[k] = nx.warm[k];
+                                 MS.st(XCH_Q + k, nx.q[k]); MS.st(XCH_QD + k, nx.qd[k]); });
   }
 }
 
+// the helper / RNE waves of the four-wave PickAndPlace kernel: same barriers as the cube wave
+MCG_DEV void pnp_side_wave(ModelPtr P, const PnpScratch MS, int total, bool rne) {
+  for (int s = 0; s < total; s++) {
+    if (rne) rne_substep<SplitPnp>(P, MS); else helper_substep<SplitPnp>(P, MS);      // S1, S2 inside
+    __syncthreads();                                                // S4
+    if (__any(MS.ld(XCH_FLAG) != 0.0)) __syncthreads();             // S5 (coupled sub-step)
+  }
+  __syncthreads();                                                  // end of the env-step
+}
+
 template <int CONTROLLER, bool DUAL>
-__global__ __launch_bounds__(DUAL ? 128 : PNP_LANES) void step_pnp_kernel(Cfg C, View V, const mcg_model* __restrict__ Pg,
+__global__ __launch_bounds__(DUAL ? 256 : PNP_LANES) void step_pnp_kernel(Cfg C, View V, const mcg_model* __restrict__ Pg,
                                                              const float* __restrict__ actions, mcg_step_out O) {
-  __shared__ real lds[PNP_SLOTS][PNP_LANES];
+  __shared__ real lds[DUAL ? PNP_SLOTS_DUAL : PNP_SLOTS][PNP_LANES];
   const int lane = DUAL ? (threadIdx.x & 63) : threadIdx.x;
-  if (DUAL && lane >= PNP_LANES) return;         // DUAL: two waves of 32 active lanes (threads 0-31 and 64-95)
+  if (DUAL && lane >= PNP_LANES) return;         // DUAL: four waves of 32 active lanes: robot, cube, helper (M), RNE
   const PnpScratch MS(&lds[0][lane]);
   const ModelPtr P = as_model_ptr(Pg);
   const int i = blockIdx.x * PNP_LANES + lane;
   if (i >= C.n) return;                          // the same lanes leave in both waves: barriers stay matched
   if constexpr (DUAL) {
     if (threadIdx.x >= 64) {
-      cube_wave(V, P, MS, i, (CONTROLLER == MCG_CTRL_IK ? C.control_steps : 1) * C.frame_skip);
+      const int total = (CONTROLLER == MCG_CTRL_IK ? C.control_steps : 1) * C.frame_skip;
+      if (threadIdx.x < 128) cube_wave(V, P, MS, i, total);
+      else pnp_side_wave(P, MS, total, threadIdx.x >= 192);
       return;
     }
   }
   MCG_TICK_INIT();
   EnvP E;
   load_envp(V, i, E);
-  if constexpr (DUAL) static_for<NB>([&](auto I) { constexpr int k = I; MS.st(XCH_Q + k, E.R.q[k]); });   // q(0) for the cube wave
+  if constexpr (DUAL) static_for<NB>([&](auto I) { constexpr int k = I; MS.st(XCH_Q + k, E.R.q[k]); MS.st(XCH_QD + k, E.R.qd[k]); });   // q(0), qd(0) for the other waves
   MCG_TICK(ST_LOAD);
   E.touch = false;
   auto substep = [&](const auto& W) { if constexpr (DUAL) pnp_substep_robot(P, E, MS, W); else pnp_substep(P, E, MS, W); };
@@ -838,7 +863,7 @@ static int launch_step(mcg_env* e, const float* actions, const mcg_step_out& o, 
     // robot wave + cube wave (DUAL) at every grid size: the 157 KB of LDS allow one workgroup per CU either way, so the
     // second wave always runs on a SIMD that would idle (measured: 16 384 envs 0.91 ms against 2.27 ms with one wave)
     const bool dual = !e->no_split;
-    const dim3 block(dual ? 128 : PNP_LANES);
+    const dim3 block(dual ? 256 : PNP_LANES);
 #define MCG_LAUNCH_PNP(CTRL)                                                                                                   \
   do {                                                                                                                         \
     if (dual) hipLaunchKernelGGL((step_pnp_kernel<CTRL, true>), grid, block, 0, s, e->cfg, e->view, e->d_model, actions, o);       \
