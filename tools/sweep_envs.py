@@ -17,13 +17,13 @@ for obj, ctrl in ((False, "joint"), (False, "IK"), (False, "mocap"), (True, "joi
         envs = MyCobotVecEnv(n, has_object=obj, controller_type=ctrl, reward_type="dense")
         envs.reset(seed=0)
         g = torch.Generator(device="cuda"); g.manual_seed(1)
-        pool = torch.rand(8, n, envs.action_dim, device="cuda", generator=g) * 2 - 1
+        pool = torch.rand(16, n, envs.action_dim, device="cuda", generator=g) * 2 - 1     # as bench.py: 16 resident action batches
         k = max(8, min(200, int(2.0e6 / n) * (1 if ctrl != "IK" else 1) // (5 if ctrl == "IK" else 1)))
-        for t in range(max(60, k)): envs.step_async(pool[t % 8])     # sustained load first: short windows run at idle clocks
+        for t in range(max(60, k, 3000 * 8192 // n)): envs.step_async(pool[t % 16])     # ~1 s of sustained load first: short windows run at idle clocks
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for t in range(k): envs.step_async(pool[t % 8])
+        for t in range(k): envs.step_async(pool[t % 16])
         e1.record(); torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / k
         row = {"task": "pnp" if obj else "reach", "controller": ctrl, "envs": n, "ms_per_step": ms, "env_steps_per_sec": n / ms * 1e3}
