@@ -570,8 +570,11 @@ MCG_DEV void crb_to_lds(ModelPtr Pm, const real* cs, const real* sn, const LS MS
 //   S2  M(t) and passive - bias are in LDS    (main wave: g0, H_eq, Newton solve)
 //   S3  the factor of M + hB is in LDS        (main wave: a' = a - h (M + hB)^-1 (B a), which equals (M + hB)^-1 M a)
 // A split policy says which pieces other waves provide and where the exchange slots are.
-struct NoSplit { static constexpr bool enabled = false, rne_remote = false, factor_remote = false; static constexpr int QB = 0, QDB = 0, FS = 0; };
-struct SplitMain { static constexpr bool enabled = true, rne_remote = true, factor_remote = true;
+// early_heq: the J^T D J part of H_eq is assembled (and the constraint part of g0 formed) BEFORE barrier S2, while the main wave
+// would otherwise wait for M; build_H then adds M on the fly.
+struct NoSplit { static constexpr bool enabled = false, rne_remote = false, factor_remote = false, early_heq = false;
+                 static constexpr int QB = 0, QDB = 0, FS = 0; };
+struct SplitMain { static constexpr bool enabled = true, rne_remote = true, factor_remote = true, early_heq = true;
                    static constexpr int QB = LDS_QB, QDB = LDS_QDB, FS = LDS_FS; };
 
 // COMMIT = false: the new q / qd / qacc_warmstart go to *next and S stays as it was (speculative sub-step of the two-wave
@@ -747,34 +750,16 @@ MCG_DEV void robot_substep(ModelPtr Pm, Robot& S, real* qlag6, const LS MS, CPL*
   }
 
   MCG_TICK(ST_ROWS);
-  if constexpr (SPL::enabled) {
-    __syncthreads();                                                // S2: M and passive - bias are in LDS
-    if constexpr (SPL::rne_remote) static_for<NB>([&](auto I) { constexpr int i = I; fs[i] += MS.ld(SPL::FS + i); });
-  }
-  // ---- P8/P9: g0 = qfrc_smooth + J^T D aref over the equality rows                          (Newton system)
-  real g0[NB];
-  static_for<NB>([&](auto I) { constexpr int i = I; g0[i] = fs[i]; });
-  static_for<2>([&](auto Sd) {
-    constexpr int sd = Sd;
-    constexpr int idx[9] = {0, 1, 2, 3, 4, 5, 6 + 2 * sd, 7 + 2 * sd, 10 + sd};
-    static_for<3>([&](auto Kk) {
-      constexpr int k = Kk; constexpr int ncol = (k == 1) ? 6 : 9;
-      static_for<ncol>([&](auto A_) { constexpr int a = A_;
-        g0[idx[a]] = fma(Dc[sd] * Jc[sd][k][a], arefc[sd][k], g0[idx[a]]); });
-    });
-  });
-  g0[6] += Dj * arefj; g0[8] -= Dj * arefj;
-  if constexpr (WLD::enabled)
-    static_for<6>([&](auto Rr) { constexpr int r = Rr; const real da = Dw * arefw[r];
-      static_for<6>([&](auto I) { constexpr int j = I; g0[j] = fma(Jw[r][j], da, g0[j]); }); });
   // H_eq = M + J^T D J over the equality rows (two connects, gear coupling, mocap weld) is assembled ONCE per sub-step,
   // group by group (arm block, then each side's gripper rows: at most 24 accumulators live), and parked in LDS next to M.
   // The connect / weld Jacobians are dead from here on: the Newton iterations and the line search read H_eq back and add the
   // active limit rows' diagonal, the Euler step needs M only.
+  auto assemble_heq = [&](auto WithM) {
+    constexpr bool WITH_M = WithM;
   {
     real acc[21];
     static_for<6>([&](auto A_) { constexpr int a = A_;
-      static_for<a + 1>([&](auto B_) { constexpr int b = B_; acc[tri(a, b)] = MS.ld(LDS_M + tri(a, b)); }); });
+      static_for<a + 1>([&](auto B_) { constexpr int b = B_; acc[tri(a, b)] = WITH_M ? MS.ld(LDS_M + tri(a, b)) : 0.0; }); });
     static_for<2>([&](auto Sd) { constexpr int sd = Sd;
       static_for<3>([&](auto Kk) { constexpr int k = Kk;
         static_for<6>([&](auto A_) { constexpr int a = A_; const real ja = Dc[sd] * Jc[sd][k][a];
@@ -793,7 +778,7 @@ MCG_DEV void robot_substep(ModelPtr Pm, Robot& S, real* qlag6, const LS MS, CPL*
       constexpr int a = 6 + Ga; constexpr int i = idx[a];
       real row[9];
       static_for<a + 1>([&](auto B_) { constexpr int b = B_; constexpr int j = idx[b];
-        if constexpr (PAT_M.nz[i][j]) row[b] = MS.ld(LDS_M + tri(i, j)); else row[b] = 0.0; });
+        if constexpr (PAT_M.nz[i][j] && WITH_M) row[b] = MS.ld(LDS_M + tri(i, j)); else row[b] = 0.0; });
       static_for<2>([&](auto Kk) { constexpr int k = 2 * Kk;            // the y row has no gripper entries
         const real ja = Dc[sd] * Jc[sd][k][a];
         static_for<a + 1>([&](auto B_) { constexpr int b = B_; row[b] = fma(ja, Jc[sd][k][b], row[b]); }); });
@@ -802,11 +787,37 @@ MCG_DEV void robot_substep(ModelPtr Pm, Robot& S, real* qlag6, const LS MS, CPL*
     });
   });
   MS.st(LDS_HEQ + tri(8, 6), -Dj);                                      // ... and -Dj on (8,6) (structurally zero in M)
+  };
+  // ---- P8/P9: g0 = qfrc_smooth + J^T D aref over the equality rows                          (Newton system)
+  real g0[NB];
+  static_for<NB>([&](auto I) { constexpr int i = I; g0[i] = 0; });
+  static_for<2>([&](auto Sd) {
+    constexpr int sd = Sd;
+    constexpr int idx[9] = {0, 1, 2, 3, 4, 5, 6 + 2 * sd, 7 + 2 * sd, 10 + sd};
+    static_for<3>([&](auto Kk) {
+      constexpr int k = Kk; constexpr int ncol = (k == 1) ? 6 : 9;
+      static_for<ncol>([&](auto A_) { constexpr int a = A_;
+        g0[idx[a]] = fma(Dc[sd] * Jc[sd][k][a], arefc[sd][k], g0[idx[a]]); });
+    });
+  });
+  g0[6] += Dj * arefj; g0[8] -= Dj * arefj;
+  if constexpr (WLD::enabled)
+    static_for<6>([&](auto Rr) { constexpr int r = Rr; const real da = Dw * arefw[r];
+      static_for<6>([&](auto I) { constexpr int j = I; g0[j] = fma(Jw[r][j], da, g0[j]); }); });
+  if constexpr (SPL::early_heq) assemble_heq(std::false_type{});      // J^T D J only: M is not there yet
+  if constexpr (SPL::enabled) {
+    __syncthreads();                                                // S2: M and passive - bias are in LDS
+    if constexpr (SPL::rne_remote) static_for<NB>([&](auto I) { constexpr int i = I; fs[i] += MS.ld(SPL::FS + i); });
+  }
+  static_for<NB>([&](auto I) { constexpr int i = I; g0[i] += fs[i]; });
+  if constexpr (!SPL::early_heq) assemble_heq(std::true_type{});
   auto build_H = [&](real* H, const bool* act_) {
     static_for<NB>([&](auto I) { constexpr int i = I;
       static_for<i + 1>([&](auto Jj) { constexpr int j = Jj;
-        if constexpr (PAT_E.nz[i][j]) H[tri(i, j)] = MS.ld(LDS_HEQ + tri(i, j));
-        else if constexpr (PAT_H.nz[i][j]) H[tri(i, j)] = 0.0; }); });
+        if constexpr (PAT_E.nz[i][j]) {
+          H[tri(i, j)] = MS.ld(LDS_HEQ + tri(i, j));
+          if constexpr (SPL::early_heq && PAT_M.nz[i][j]) H[tri(i, j)] += MS.ld(LDS_M + tri(i, j));
+        } else if constexpr (PAT_H.nz[i][j]) H[tri(i, j)] = 0.0; }); });
     static_for<10>([&](auto I) { constexpr int j = I; H[tri(j, j)] += act_[j] ? Dl[j] : 0.0; });
   };
 

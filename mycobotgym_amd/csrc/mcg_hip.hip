@@ -454,7 +454,7 @@ constexpr int PNP_SLOTS_DUAL = PNP_SLOTS + NB;
 static_assert(PNP_SLOTS_DUAL * PNP_LANES * 8 <= 160 * 1024, "LDS of a CU");
 // robot-side split of the four-wave PickAndPlace kernel: M from the helper wave, passive - bias from the RNE wave; the Euler
 // step stays with M a (no room for the factor in LDS)
-struct SplitPnp { static constexpr bool enabled = true, rne_remote = true, factor_remote = false;
+struct SplitPnp { static constexpr bool enabled = true, rne_remote = true, factor_remote = false, early_heq = false;
                   static constexpr int QB = XCH_Q, QDB = XCH_QD, FS = XCH_FS; };
 
 MCG_DEV void cube_to_lds(const PnpScratch MS, const Cube& Cb) {
