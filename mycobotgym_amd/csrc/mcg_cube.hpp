@@ -358,7 +358,7 @@ struct CubeSys {
     }
     ncon = CL.n;
 #ifdef MCG_STAGE_CLOCKS
-    { int mx = 0; for (int c = 0; __any(c < ncon); c++) mx = c + 1; if (threadIdx.x == 0) sh_stage[ST_COUNT + 1 + CN_CONTACTS] += mx; }   // wave-max contacts
+    { int mx = 0; for (int c = 0; __any(c < ncon); c++) mx = c + 1; if ((threadIdx.x & 63) == 0) atomicAdd(&g_stage_clocks[ST_COUNT + CN_CONTACTS], (unsigned long long)mx); }   // wave-max contacts
 #endif
     // Lanes with fewer contacts than their wave-mates still walk the longer list with zero weights: give them clean
     // zeros to multiply (uninitialised LDS may hold NaN / inf, and 0 * NaN would poison the sums).

@@ -39,16 +39,16 @@ enum { ST_LOAD = 0, ST_CTRL, ST_TRIG, ST_RNE, ST_ACT, ST_CRB, ST_ROWS, ST_G0, ST
        ST_COUPLED, ST_CUBE_FIN, ST_POST, ST_N_BUILD, ST_N_FACTOR, ST_N_SOLVE, ST_N_CHECK, ST_E_RHS, ST_R_AX5, ST_R_CONNECT, ST_R_LIMITS, ST_C_MASK, ST_C_ASSEMBLE, ST_C_SCHUR, ST_C_SOLVE, ST_C_CHECK, ST_C_LS, ST_W2_WAIT1, ST_W2_COLLIDE, ST_W2_CUBE, ST_W2_WAIT2, ST_W1_WAIT, ST_COUNT,
        CN_SUBSTEP = 0, CN_NEWTON_IT, CN_LINESEARCH, CN_CUBE_IT, CN_CUBE_LS, CN_COUPLED, CN_COUPLED_IT, CN_COUPLED_LS, CN_CONTACTS, CN_COUNT };
 #ifdef MCG_STAGE_CLOCKS
-__device__ unsigned long long g_stage_clocks[ST_COUNT + CN_COUNT];      // stage clocks, then event counts (per wave)
-__shared__ unsigned long long sh_stage[ST_COUNT + 1 + CN_COUNT];
-#define MCG_TICK_INIT() do { if (threadIdx.x == 0) { for (int k_ = 0; k_ < ST_COUNT + 1 + CN_COUNT; k_++) sh_stage[k_] = 0; sh_stage[ST_COUNT] = __builtin_readcyclecounter(); } } while (0)
-#define MCG_TICK(k) do { if (threadIdx.x == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); sh_stage[k] += t_ - sh_stage[ST_COUNT]; sh_stage[ST_COUNT] = t_; } } while (0)
-// second wave of a two-wave workgroup (lane 0 = thread 64): its own time base, added straight to the global table
-__shared__ unsigned long long sh_last2;
-#define MCG_TICK2_INIT() do { if (threadIdx.x == 64) sh_last2 = __builtin_readcyclecounter(); } while (0)
-#define MCG_TICK2(k) do { if (threadIdx.x == 64) { const unsigned long long t_ = __builtin_readcyclecounter(); atomicAdd(&g_stage_clocks[k], t_ - sh_last2); sh_last2 = t_; } } while (0)
-#define MCG_TICK_FLUSH() do { if (threadIdx.x == 0) { for (int k_ = 0; k_ < ST_COUNT; k_++) atomicAdd(&g_stage_clocks[k_], sh_stage[k_]); for (int k_ = 0; k_ < CN_COUNT; k_++) atomicAdd(&g_stage_clocks[ST_COUNT + k_], sh_stage[ST_COUNT + 1 + k_]); } } while (0)
-#define MCG_COUNT(k) do { if (threadIdx.x == 0) sh_stage[ST_COUNT + 1 + (k)] += 1; } while (0)
+__device__ unsigned long long g_stage_clocks[ST_COUNT + CN_COUNT];      // stage clocks, then event counts (summed over waves)
+__device__ unsigned long long g_tick_last[4096 * 4];                    // last time stamp of (workgroup, wave): no LDS is used,
+                                                                         // the PickAndPlace kernels need all 160 KB of it
+#define MCG_TICK_SLOT_ (g_tick_last[(blockIdx.x & 4095) * 4 + (threadIdx.x >> 6)])
+#define MCG_TICK_INIT() do { if ((threadIdx.x & 63) == 0) MCG_TICK_SLOT_ = __builtin_readcyclecounter(); } while (0)
+#define MCG_TICK(k) do { if ((threadIdx.x & 63) == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); atomicAdd(&g_stage_clocks[k], t_ - MCG_TICK_SLOT_); MCG_TICK_SLOT_ = t_; } } while (0)
+#define MCG_TICK2_INIT() MCG_TICK_INIT()
+#define MCG_TICK2(k) MCG_TICK(k)
+#define MCG_TICK_FLUSH() do {} while (0)
+#define MCG_COUNT(k) do { if (threadIdx.x == 0) atomicAdd(&g_stage_clocks[ST_COUNT + (k)], 1ull); } while (0)
 // a stage's results must exist before its tick: arithmetic is otherwise sunk past the clock read towards its uses
 #define MCG_TICK_PIN(arr, n) do { for (int k_ = 0; k_ < (n); k_++) asm volatile("" : "+v"((arr)[k_])); } while (0)
 #else
