@@ -775,7 +775,10 @@ struct CubeSys {
         const bool neg = f < 0;
         lo = sel(neg, al, lo); hi = sel(neg, hi, al);
         const real nw = al - f / sl;
-        al = sel(nw > lo && nw < hi, nw, 0.5 * (lo + hi));
+        const real nx = sel(nw > lo && nw < hi, nw, 0.5 * (lo + hi));
+        const bool moved = fabs(nx - al) > 1e-15 * fmax(1.0, fabs(al));     // on the root's own linear piece Newton stays put
+        al = nx;
+        if (!__any(moved && !conv && !beyond)) break;                         // wave-uniform exit
       }
       const real alpha = sel(beyond, 2.0, al);
       for (int i = 0; i < NB; i++) ar[i] = sel(conv, ar[i], ar[i] + alpha * pr[i]);
