@@ -224,3 +224,24 @@ def test_mocap_weld_rest_pose_has_no_residual(po):
     assert np.abs(d.get("efc_pos", (224,))[:6]).max() < 1e-12           # FK(EEF; qpos0) == mocap rest pose, mocap.xml:3
     tcp = tab["body_name"].index("gripper_tcp")
     assert np.allclose(d.get("xpos", (32, 3))[tcp], tab["body_pos"][tab["body_name"].index("robot0:mocap")], atol=1e-8)
+
+
+@pytest.mark.parametrize("variant", ["mycobot280_mocap", "mycobot280_mocap_exactmesh"])
+def test_mocap_keyframe_gripper_deflections_are_an_equilibrium(po, variant):
+    """Second known answer in the same keyframe (mycobot280_mocap.xml:7): its six gripper angles (5e-5 ... 3e-4 rad) are the
+    sag of the closed-loop gripper under gravity against the finger actuator's affine bias (-100 len), the gear coupling and the
+    two soft connects.  The restated gripper must keep them: the gear joints to the keyframe's rounding (1e-6 relative), the
+    finger and hinge joints, which feel the connects' regularisation (invweight0 of the whole arm), to 2e-3."""
+    tab = load_json(variant)
+    d = po.OracleData(po.OracleModel(tab))
+    key = tab["keys"][0]
+    d.set_state(qpos=key["qpos"], qvel=key["qvel"], ctrl=key["ctrl"])
+    d.set_mocap(key["mpos"], key["mquat"])
+    d.forward()
+    g0 = np.array(d.qpos[6:12])
+    assert np.all(np.abs(g0) > 4e-5) and np.all(np.abs(g0) < 4e-4)
+    d.step(6000)
+    g1 = np.array(d.qpos[6:12])
+    rel = np.abs(g1 - g0) / np.abs(g0)
+    assert rel[0] < 5e-6 and rel[2] < 5e-6            # gear R, gear L
+    assert rel[[1, 3, 4, 5]].max() < 2e-3             # fingers, hinges
