@@ -35,7 +35,8 @@ def test_reference_known_answers_fixture(built):
 def test_oracle_regression_vectors(built):
     """One env-step from reset is far inside the predictability horizon, so these replay to ~1e-9 on any x86 host."""
     gold = json.load(open(os.path.join(GOLD, "oracle_regression.json")))
-    for key, (has_object, controller) in {"reach_joint": (False, "joint"), "reach_ik": (False, "IK"), "pnp_joint": (True, "joint")}.items():
+    for key, (has_object, controller) in {"reach_joint": (False, "joint"), "reach_ik": (False, "IK"), "pnp_joint": (True, "joint"),
+                                           "reach_mocap": (False, "mocap")}.items():
         g = gold[key]
         ora = make_oracle(4, has_object=has_object, controller_type=controller, reward_type="dense", seed=2024, n_threads=1)
         obs, ag, dg = ora.reset(seed=2024)

@@ -30,7 +30,7 @@ def rollout(has_object, controller, steps, n=4, seed=2024):
 def main():
     data = {"_note": "oracle regression vectors (this repo's C restatement, NOT MuJoCo); tools/make_golden.py",
             "reach_joint": rollout(False, "joint", 2), "reach_ik": rollout(False, "IK", 1),
-            "pnp_joint": rollout(True, "joint", 2)}
+            "pnp_joint": rollout(True, "joint", 2), "reach_mocap": rollout(False, "mocap", 2)}
     path = os.path.join(ROOT, "tests", "golden", "oracle_regression.json")
     with open(path, "w") as f:
         json.dump(data, f)
