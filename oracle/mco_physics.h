@@ -5,14 +5,18 @@
  * (`mujoco.mj_step(model, data, nstep=frame_skip)` at /root/reference/mycobotgym/envs/mycobot.py:170,189
  * and `mj_forward` at :213,229,453) for the model class the MyCobot scene needs: a tree of
  * bodies with hinge / free joints, affine `general` actuators over joints or fixed tendons,
- * connect / joint equalities, joint limits, box contacts, soft constraints solved by a primal
- * Newton method, semi-implicit Euler with implicit joint damping.
+ * connect / joint / weld equalities, mocap bodies, joint limits, box contacts, soft constraints solved
+ * by a primal Newton method, semi-implicit Euler with implicit joint damping.
  *
  * PARITY UNPINNED: MuJoCo 2.3.2 (requirements.txt:4) is a third-party dependency that is absent
  * from /root/reference and from this image, and the reference ships no tests or golden vectors
  * for this path.  Every rule below is restated from the published MuJoCo algorithm as recalled
- * (all marked [RECALL]); it is pinned only by the reference-internal
- * known answers of SURVEY.md Appendix E (tests/test_oracle_known_answers.py).
+ * (all marked [RECALL]); it is pinned only by the reference's own data
+ * (tests/test_oracle_known_answers.py): the known answers of SURVEY.md Appendix E (forward kinematics,
+ * mesh volumes, id table) and the settled `fetch_env` keyframe of mycobot280_mocap.xml:6-9, which is a
+ * statics known answer -- the gripper's six deflections are reproduced (gear joints to 1e-6 relative)
+ * and the arm hangs on the weld at the keyframe if and only if the weld's six rows are equally stiff.
+ * Not reproduced: the cube's rest height in the keyframes (contacts 2x too stiff).
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may call this.
  */
