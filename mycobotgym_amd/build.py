@@ -8,7 +8,8 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(_HERE)
 SRC = os.path.join(_HERE, "csrc", "mcg_hip.hip")
-DEPS = [SRC, os.path.join(_HERE, "csrc", "mcg_dynamics.hpp"), os.path.join(_HERE, "csrc", "model_gen.h"),
+DEPS = [SRC, os.path.join(_HERE, "csrc", "mcg_dynamics.hpp"), os.path.join(_HERE, "csrc", "mcg_cube.hpp"),
+        os.path.join(_HERE, "csrc", "model_gen.h"),
         os.path.join(ROOT, "include", "mcg.h")]
 OUT = os.path.join(_HERE, "libmycobot_hip.so")
 
