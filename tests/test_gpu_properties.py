@@ -279,3 +279,33 @@ def test_ragged_env_counts_with_multi_wave_kernels(torch_cuda, has_object, n):
         e, flags_equal, _ = step_errors(envs, ora, rng.uniform(-1, 1, (n, 7)).astype(np.float32))
         assert flags_equal and np.median(e) < 1e-9 and e.max() < 1e-5
     envs.close()
+
+
+def test_long_random_rollouts_stay_finite(torch_cuda):
+    """Every task / controller / fetch combination, 2048 envs, 150 random env-steps (three episodes, auto-resets, pad contacts
+    in the fetch PickAndPlace starts): nothing may go non-finite, hang or trip the bad-state guard into a reset storm."""
+    torch = torch_cuda
+    from mycobotgym_amd import MyCobotVecEnv
+    n = 2048
+    for obj in (False, True):
+        for ctrl in ("joint", "IK", "mocap"):
+            for fetch in ((False,) if ctrl == "joint" else (False, True)):
+                envs = MyCobotVecEnv(n, has_object=obj, controller_type=ctrl, fetch_env=fetch,
+                                     reward_type="reward_shaping" if obj else "dense",
+                                     domain_randomization={"mass": (0.5, 2.0), "friction": (0.5, 1.5)} if obj else None)
+                envs.reset(seed=0)
+                g = torch.Generator(device="cuda"); g.manual_seed(0)
+                steps = 150 if ctrl != "IK" else 60
+                len_sum = 0.0; len_cnt = 0
+                for t in range(steps):
+                    a = torch.rand(n, envs.action_dim, device="cuda", generator=g) * 2 - 1
+                    obs, rew, term, trunc, info = envs.step(a)
+                    if t % 25 == 24:
+                        assert torch.isfinite(obs["observation"]).all() and torch.isfinite(rew).all(), (obj, ctrl, fetch, t)
+                        assert float(obs["observation"].abs().max()) < 5.0
+                    done = term | trunc
+                    if done.any():
+                        len_sum += float(info["episode"]["l"][done].float().sum()); len_cnt += int(done.sum())
+                if steps >= 100:
+                    assert len_cnt >= 2 * n and len_sum / len_cnt > 40      # random policies rarely succeed: most episodes hit the time limit
+                envs.close()
