@@ -1,22 +1,34 @@
 #!/usr/bin/env python3
-"""bench.py -- env-steps/sec of the MyCobot Reach rollout hot path on N MI355X (BASELINE.json metric).
+"""bench.py -- env-steps/sec of the MyCobot rollout hot path on N MI355X (BASELINE.json metric).
 
     python bench.py --gpus 1 --steps 1000 --warmup 100
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
 A "step" is one env.step() of every environment (one launch of the fused step kernel = controller + 20 physics
-sub-steps + observation + reward + termination + TimeLimit + auto-reset).  Workload = BASELINE.json configs[1]:
-Reach, 8192 envs per GPU, free-space dynamics, `joint` controller (SURVEY 8(d) "Config 2", primary), dense reward,
-actions ~ U(-1,1) float32 already resident in HBM, auto-reset on.  Weak scaling: every rank owns 8192 envs keyed by
-global env id; there is no collective on the step path (RCCL is used once, after the timed region, to reduce the
-episode statistics for logging).  The IK controller (100 sub-steps per step) is reported as a secondary figure.
+sub-steps + observation + reward + termination + TimeLimit + auto-reset).  Headline workload = BASELINE.json
+configs[1]: Reach, 8192 envs per GPU, free-space dynamics, `joint` controller (SURVEY 8(d) "Config 2", primary), dense
+reward, actions ~ U(-1,1) float32 already resident in HBM, auto-reset on.
+
+Episodes are DESYNCHRONISED by default: every env starts at its own random point of its 50-step episode, as in any training
+run after its first few hundred steps, so a short timed window is representative (with lock-stepped episodes all 8192 envs
+reset on the same step and a 20-step window measures one phase of the episode only; `--lockstep` keeps that mode and the
+default run reports it next to the headline figure).
+
+Weak scaling: every rank owns 8192 envs keyed by global env id; there is no collective on the step path (RCCL is used
+once, after the timed region, to reduce the episode statistics for logging: mycobotgym_amd.sharding.reduce_episode_stats).
+
+The default 1-GPU run also times, as `secondary` entries with their own `roofline`: Reach with the IK controller (100
+sub-steps per step), PickAndPlace (configs[2]: cube resting on the table, random actions), PickAndPlace during a scripted
+grasp (pad contacts: the coupled robot + cube solve), and PickAndPlace with per-reset domain randomisation (configs[4]'s
+per-GPU workload).
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import platform
 import sys
 import time
 
@@ -24,35 +36,116 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 N_ENVS_PER_GPU = 8192
-# Algorithmic (compulsory) HBM bytes per env-step, SURVEY.md 8(d): Reach with the cube's state dropped:
-# B = 2*S + A + O, S = 46 doubles + counters, A = 28 B, O = 135 B  ->  939 B.   (DESIGN.md "Bytes per env-step")
-BYTES_PER_ENV_STEP = 939
+# Algorithmic (compulsory) HBM bytes per env-step, SURVEY.md 8(d): B = 2*S + A + O.  Reach with the cube's state dropped:
+# S = 46 doubles + counters, A = 28 B, O = 135 B -> 939 B; PickAndPlace: 1363 B.   (DESIGN.md "Bytes per env-step")
+ALGO_BYTES = {"reach": 939, "pnp": 1363}
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 FP64_VECTOR_PEAK_TFLOPS = 78.6  # 256 CUs x 4 SIMDs x 16 lanes/clk x 2 FLOP x 2.4 GHz; the 16 lanes/clk (4.02 clk per wave64
                                 # v_fma_f64 per SIMD) is measured: tools/microbench/issue_rate.hip, profiles/r01/issue_rate.log
 
+# name -> (task, controller, domain randomisation, scripted grasp)
+CASES = {
+    "reach-joint": ("reach", "joint", False, False),
+    "reach-IK": ("reach", "IK", False, False),
+    "reach-mocap": ("reach", "mocap", False, False),
+    "pnp-joint": ("pnp", "joint", False, False),
+    "pnp-IK": ("pnp", "IK", False, False),
+    "pnp-mocap": ("pnp", "mocap", False, False),
+    "pnp-joint-dr": ("pnp", "joint", True, False),
+    "pnp-joint-grasp": ("pnp", "joint", False, True),
+}
+DEFAULT_SECONDARY = ("reach-IK", "pnp-joint", "pnp-joint-grasp", "pnp-joint-dr")
 
-def cpu_baseline(controller: str, budget_envs: int, steps: int):
-    """The CPU oracle (kind "port": this repo's C restatement, NOT MuJoCo) on the host cores this job may use."""
+
+def describe(case, n, lockstep):
+    task, controller, dr, grasp = CASES[case]
+    sub = 100 if controller == "IK" else 20
+    head = (f"MyCobot Reach, {n} envs/GPU, no contacts (free-space dynamics), " if task == "reach" else
+            f"MyCobot PickAndPlace, {n} envs/GPU, contacts on (cube-table/ground/pads, pyramidal condim 4), "
+            + ("per-reset domain randomisation (cube mass x U(0.5,2), sliding friction x U(0.5,1.5)), " if dr else "")
+            + ("scripted grasp (every env closing its gripper on the cube: pad contacts in the timed window, no TimeLimit), " if grasp else ""))
+    return head + (f"controller={controller}, {sub} physics sub-steps per env-step, dense reward, auto-reset, TimeLimit 50, "
+                   + ("lock-stepped episodes" if lockstep else "desynchronised episodes (per-env random initial elapsed in [0,50))"))
+
+
+def cpu_info():
+    model = platform.processor() or ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip(); break
+    except OSError:
+        pass
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = os.cpu_count() or 1
+    return {"nproc": os.cpu_count() or 1, "usable_cores": usable, "cpu_model": model}
+
+
+def cpu_baseline(controller: str):
+    """The CPU oracle (kind "port": this repo's C restatement, NOT MuJoCo -- unavailable offline) on the host cores this
+    job may use, at 1 thread and at all usable cores; bounded samples of the headline workload."""
     import numpy as np
     from tests.common import make_oracle
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        cores = os.cpu_count() or 1
-    cores = min(cores, 16)     # a one-GPU box's CPU share is 16 cores
-    ora = make_oracle(budget_envs, controller_type=controller, reward_type="dense", seed=0, n_threads=cores)
-    ora.reset(seed=0)
-    rng = np.random.default_rng(0)
-    acts = [rng.uniform(-1, 1, (budget_envs, ora.act_dim)).astype(np.float32) for _ in range(4)]
-    ora.step(acts[0])
-    t0 = time.perf_counter()
-    for t in range(steps):
-        ora.step(acts[t % 4])
-    dt = time.perf_counter() - t0
-    return {"value": budget_envs * steps / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": f"{budget_envs} envs x {steps} steps, Reach/{controller}, OpenMP over envs, {dt:.1f}s wall; "
-                      "this repo's C float64 restatement, not MuJoCo (unavailable offline)"}
+    info = cpu_info()
+
+    def timed(n_envs, steps, threads):
+        ora = make_oracle(n_envs, controller_type=controller, reward_type="dense", seed=0, n_threads=threads)
+        ora.reset(seed=0)
+        rng = np.random.default_rng(0)
+        ora.set_state(elapsed=rng.integers(0, 50, n_envs).astype(np.int32))       # desynchronised, like the GPU run
+        acts = [rng.uniform(-1, 1, (n_envs, ora.act_dim)).astype(np.float32) for _ in range(4)]
+        ora.step(acts[0])
+        t0 = time.perf_counter()
+        for t in range(steps):
+            ora.step(acts[t % 4])
+        dt = time.perf_counter() - t0
+        return n_envs * steps / dt, dt
+
+    cores = info["usable_cores"]
+    v1, dt1 = timed(512, 60, 1)
+    vn, dtn = timed(8192, 60, cores)
+    return {"value": vn, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": f"8192 envs x 60 steps, Reach/{controller}, OpenMP over envs on {cores} threads, {dtn:.1f}s wall; "
+                      "this repo's C float64 restatement, not MuJoCo (unavailable offline)",
+            "one_thread": {"value": v1, "unit": "env-steps/s", "cores": 1, "sample": f"512 envs x 60 steps, {dt1:.1f}s wall"},
+            **info}
+
+
+def load_pmc(case, n):
+    """Counter figures for `case` from profiles/pmc_latest.json (written by tools/summarize_profile.py from rocprofv3 --pmc
+    passes of this same command); None when the counters were collected on another size."""
+    path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        pj = json.load(f).get("cases", {}).get(case)
+    if not pj or pj.get("n_envs") != n:
+        return None
+    return pj
+
+
+def roofline(case, n, kernel_ms):
+    task = CASES[case][0]
+    algo = ALGO_BYTES[task] * n
+    achieved = algo / (kernel_ms * 1e-3) / 1e9
+    pj = load_pmc(case, n)
+    src = ("profiles/pmc_latest.json[" + case + "]: " + pj.get("note", "")) if pj else None
+    out = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+           "traffic": pj.get("hbm_bytes_per_launch") if pj else None, "traffic_source": src,
+           "kernel": "step_reach_kernel" if task == "reach" else "step_pnp_kernel", "kernel_ms": kernel_ms,
+           "algorithmic_bytes_per_launch": algo,
+           "note": "nominal roofline only: with all sub-steps fused the path moves ~1 KB per env-step and is bound by "
+                   "dependent FP64 VALU issue, not by HBM (SURVEY 8(d)); see DESIGN.md"}
+    if pj and pj.get("f64_flops_per_launch"):
+        # secondary (the binding) roofline, SURVEY 8(d): FP64 vector FLOP/s
+        tf = pj["f64_flops_per_launch"] / (kernel_ms * 1e-3) / 1e12
+        out["valu_f64"] = {"achieved": tf, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_VECTOR_PEAK_TFLOPS,
+                           "flops_per_launch": pj["f64_flops_per_launch"],
+                           "source": "SQ_INSTS_VALU_{FMA,ADD,MUL,TRANS}_F64 x active lanes, " + (src or "")}
+    return out
 
 
 def main():
@@ -60,16 +153,23 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--case", default=None, choices=sorted(CASES), help="workload by name (overrides --task/--controller/--dr/--scripted-grasp)")
     ap.add_argument("--controller", default="joint", choices=["joint", "IK", "mocap"])
     ap.add_argument("--task", default="reach", choices=["reach", "pnp"],
                     help="reach = BASELINE configs[1] (the headline metric); pnp = configs[2], PickAndPlace with contacts")
     ap.add_argument("--dr", action="store_true", help="PickAndPlace with per-reset domain randomisation (configs[4])")
     ap.add_argument("--scripted-grasp", action="store_true",
                     help="PickAndPlace from the 'gripper closing over the cube' state (pad contacts in the timed window)")
+    ap.add_argument("--lockstep", action="store_true", help="all episodes start together (every env resets on the same step)")
     ap.add_argument("--envs-per-gpu", type=int, default=N_ENVS_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
     args = ap.parse_args()
+    case = args.case
+    if case is None:
+        case = args.task + "-" + args.controller + ("-dr" if args.dr else "") + ("-grasp" if args.scripted_grasp else "")
+        if case not in CASES:
+            raise SystemExit(f"no such workload: {case} (have {sorted(CASES)})")
 
     import torch
     import torch.distributed as dist
@@ -94,20 +194,25 @@ def main():
         raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     dev = torch.device("cuda", local_rank)
     from mycobotgym_amd import MyCobotVecEnv
+    from mycobotgym_amd.sharding import reduce_episode_stats, shard
 
     n = args.envs_per_gpu
     K, W = args.steps, args.warmup
+    env_offset, total_envs = shard(rank, world, n)
 
-    def run(controller, steps, warmup):
-        pnp = args.task == "pnp"
+    def run(case, steps, warmup, lockstep):
+        task, controller, dr, grasp = CASES[case]
+        pnp = task == "pnp"
         envs = MyCobotVecEnv(n, has_object=pnp, controller_type=controller, reward_type="dense", device=dev,
-                             seed=0, env_id_offset=rank * n,
-                             domain_randomization={"mass": (0.5, 2.0), "friction": (0.5, 1.5)} if (pnp and args.dr) else None,
-                             max_episode_steps=10 ** 9 if args.scripted_grasp else 50)
+                             seed=0, env_id_offset=env_offset,
+                             domain_randomization={"mass": (0.5, 2.0), "friction": (0.5, 1.5)} if dr else None,
+                             max_episode_steps=10 ** 9 if grasp else 50)
         envs.reset(seed=0)
         g = torch.Generator(device=dev); g.manual_seed(1234 + rank)
+        if not lockstep and not grasp:      # every env at its own point of its episode
+            envs.set_state(elapsed=torch.randint(0, 50, (n,), device=dev, generator=g, dtype=torch.int32))
         pool = torch.rand(16, n, envs.action_dim, device=dev, generator=g) * 2 - 1     # resident action batches
-        if pnp and args.scripted_grasp and controller == "joint":
+        if grasp:
             from mycobotgym_amd.scenarios import grasp_state
             st = grasp_state(n, seed=rank)
             act = torch.as_tensor(st.pop("action"), device=dev)
@@ -136,72 +241,43 @@ def main():
             tt = torch.tensor([dt], dtype=torch.float64, device=red_dev or dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
-        # logging path: episode statistics reduced over ranks with RCCL, off the timed region
+        # logging path: episode statistics of the last step reduced over ranks (RCCL), off the timed region
         b = envs._buf
-        stats = torch.stack([b["ep_return"].sum(), b["ep_length"].double().sum(), b["is_success"].double().sum()])
-        if world > 1:
-            if red_dev: stats = stats.to(red_dev)
-            dist.all_reduce(stats, op=dist.ReduceOp.SUM)
+        stats = reduce_episode_stats(b["ep_return"], b["ep_length"], b["is_success"], b["truncated"], device=red_dev)
         envs.close()
-        return dt, kernel_ms, stats.tolist()
+        return dt, kernel_ms, stats
 
-    dt, kernel_ms, stats = run(args.controller, K, W)
-    total_envs = n * world
-    value = total_envs * K / dt
-    substeps = 100 if args.controller == "IK" else 20
+    def entry(case, steps, warmup, lockstep):
+        dt, kernel_ms, stats = run(case, steps, warmup, lockstep)
+        sub = 100 if CASES[case][1] == "IK" else 20
+        v = total_envs * steps / dt
+        return {"case": case, "workload": describe(case, n, lockstep), "env_steps_per_sec": v, "ms_per_step": dt / steps * 1e3,
+                "steps": steps, "warmup": warmup, "physics_substeps_per_sec": v * sub,
+                "roofline": roofline(case, n, kernel_ms) if rank == 0 else None, "episode_stats_last_step": stats}
+
+    main_e = entry(case, K, W, args.lockstep)
+    task, controller = CASES[case][0], CASES[case][1]
     out = {
-        "metric": "env-steps/sec (whole node), MyCobot Reach, N_envs=8192/GPU" if args.task == "reach" else
+        "metric": "env-steps/sec (whole node), MyCobot Reach, N_envs=8192/GPU" if task == "reach" else
                   "env-steps/sec (whole node), MyCobot PickAndPlace, N_envs=8192/GPU",
-        "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
-        "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "value": main_e["env_steps_per_sec"], "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
+        "ms_per_step": main_e["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
-        "config": {"workload": (f"MyCobot Reach, {n} envs/GPU, no contacts (free-space dynamics), controller={args.controller}, "
-                                if args.task == "reach" else
-                                f"MyCobot PickAndPlace, {n} envs/GPU, contacts on (cube-table/ground/pads, pyramidal condim 4), "
-                                f"{'domain randomisation, ' if args.dr else ''}{'scripted grasp, ' if args.scripted_grasp else ''}controller={args.controller}, ") +
-                               f"{substeps} physics sub-steps per env-step, dense reward, auto-reset, TimeLimit 50",
-                   "envs_per_gpu": n, "total_envs": total_envs, "controller": args.controller,
+        "config": {"workload": main_e["workload"], "case": case, "envs_per_gpu": n, "total_envs": total_envs,
+                   "controller": controller, "episodes": "lockstep" if args.lockstep else "desynchronised",
                    "parallelism": f"env-sharded x{world}, no step-path collective"},
-        "physics_substeps_per_sec": value * substeps,
+        "physics_substeps_per_sec": main_e["physics_substeps_per_sec"],
+        "roofline": main_e["roofline"], "episode_stats_last_step": main_e["episode_stats_last_step"],
     }
+    if world == 1 and not args.no_secondary and case == "reach-joint" and not args.lockstep:
+        # bounded so that the default run still finishes within a few minutes (the grasp case runs ~10 ms per step)
+        k2, w2 = max(min(K, 200) // 2, 20), max(min(W, 100) // 2, 5)
+        out["lockstep"] = {k: v for k, v in entry(case, K, W, True).items() if k != "roofline"}
+        out["secondary"] = [entry(c, k2 if c != "pnp-joint-grasp" else min(k2, 40), w2 if c != "pnp-joint-grasp" else 5, False)
+                            for c in DEFAULT_SECONDARY]
     if rank == 0:
-        algo_bytes = BYTES_PER_ENV_STEP * n
-        achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
-        traffic = None; src = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_latest.json" if args.task == "reach" else "pmc_latest_pnp.json")
-        flops = None
-        if os.path.exists(pmc):
-            with open(pmc) as f:
-                pj = json.load(f)
-            if (pj.get("controller") == args.controller and pj.get("n_envs") == n and pj.get("task", "reach") == args.task
-                    and not args.scripted_grasp):       # the counters were collected on the default workload of this task
-                traffic = pj.get("hbm_bytes_per_launch"); src = "profiles/" + os.path.basename(pmc) + ": " + pj.get("note", "")
-                flops = pj.get("f64_flops_per_launch")
-        out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                           "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": src,
-                           "kernel": "step_reach_kernel", "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": algo_bytes,
-                           "note": "nominal roofline only: with all sub-steps fused the path moves ~1 KB per env-step and is "
-                                   "bound by dependent FP64 VALU issue, not by HBM (SURVEY 8(d)); see DESIGN.md"}
-        if args.task == "pnp":
-            out["roofline"]["kernel"] = "step_pnp_kernel"
-            out["roofline"]["algorithmic_bytes_per_launch"] = 1363 * n       # PickAndPlace B = 1363 B per env-step
-            out["roofline"]["achieved"] = 1363 * n / (kernel_ms * 1e-3) / 1e9
-            out["roofline"]["frac"] = out["roofline"]["achieved"] / HBM_PEAK_GBPS
-        if flops:
-            # secondary (the binding) roofline, SURVEY 8(d): FP64 vector FLOP/s.  Peak = 1024 SIMDs x 16 lanes/clk x 2 x 2.4 GHz;
-            # the 16 lanes/clk is measured here (tools/microbench/issue_rate.hip: 4.02 clk per wave64 v_fma_f64 per SIMD).
-            tf = flops / (kernel_ms * 1e-3) / 1e12
-            out["roofline"]["valu_f64"] = {"achieved": tf, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                           "frac": tf / FP64_VECTOR_PEAK_TFLOPS, "flops_per_launch": flops,
-                                           "source": "SQ_INSTS_VALU_{FMA,ADD,MUL,TRANS}_F64 x active lanes, " + (src or "")}
-        if not args.no_secondary and world == 1 and args.task == "reach":
-            other = "joint" if args.controller == "IK" else "IK"
-            dt2, k2, _ = run(other, max(K // 5, 20), max(W // 5, 5))
-            out["secondary"] = {"controller": other, "env_steps_per_sec": n * max(K // 5, 20) / dt2, "kernel_ms": k2,
-                                "physics_substeps_per_sec": n * max(K // 5, 20) / dt2 * (100 if other == "IK" else 20)}
-        if not args.no_cpu_baseline and world == 1 and args.task == "reach":
-            out["cpu_baseline"] = cpu_baseline(args.controller, 8192, 40)
-        out["episode_stats"] = {"sum_return": stats[0], "sum_length": stats[1], "sum_success": stats[2]}
+        if not args.no_cpu_baseline and world == 1 and task == "reach":
+            out["cpu_baseline"] = cpu_baseline(controller)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MCG_ABI_VERSION 2
+#define MCG_ABI_VERSION 3
 
 enum { MCG_OK = 0, MCG_ERR_ARG = 1, MCG_ERR_HIP = 2, MCG_ERR_UNSUPPORTED = 3 };
 enum { MCG_CTRL_JOINT = 0, MCG_CTRL_IK = 1, MCG_CTRL_MOCAP = 2 };   /* controller_type "joint" | "IK" | "mocap" */
@@ -71,11 +71,14 @@ typedef struct mcg_model {
   double weld_par[10], weld_diag;   /* solver numbers as in limit_par; the six rows share one weight */
   double weld_anchor[3];            /* weld point on the robot, link6 frame */
   double weld_relpos[3], weld_relquat[4], weld_torquescale;
+  double target0[3];                /* MJCF position of site `target0`: what stage_rewards reads unless rendering (mycobot.py:422, 309-311) */
 } mcg_model;
 
 typedef struct mcg_config {
   int32_t n_envs;
-  int32_t has_object;          /* 0 = Reach, 1 = PickAndPlace                       (mycobot.py:33) */
+  int32_t has_object;          /* 0 = Reach, 1 = PickAndPlace                       (mycobot.py:33).  Reach with reward_type =
+                                  MCG_REWARD_SHAPING keeps the cube as a hidden free body (geom and site size zero,
+                                  mycobot.py:475-481): stage_rewards reads its site and contacts (mycobot.py:402-448) */
   int32_t controller;          /* MCG_CTRL_*                                       (mycobot.py:36) */
   int32_t fetch_env;           /*                                                  (mycobot.py:41) */
   int32_t reward_type;         /* MCG_REWARD_*                                     (mycobot.py:42) */
@@ -122,6 +125,8 @@ typedef struct mcg_state {
   int32_t* elapsed;  /* [N] */
   int32_t* episode;  /* [N]       per-env episode counter (RNG stream position) */
   double* dr_scale;  /* [2, N]    domain-randomisation scales of the current episode: cube mass, sliding friction */
+  double* ep_return; /* [N]       running return of the episode in flight (Monitor's "r" when it ends) */
+  int32_t* ep_length;/* [N]       running length of the episode in flight (Monitor's "l") */
 } mcg_state;
 
 typedef struct mcg_env mcg_env;
@@ -143,6 +148,9 @@ int mcg_reset(mcg_env* env, const uint8_t* mask /* [N] device or NULL = all */, 
 int mcg_step(mcg_env* env, const float* actions /* [N, A] row-major, device */, const mcg_step_out* out, void* stream);
 int mcg_get_state(mcg_env* env, const mcg_state* dst, void* stream);
 int mcg_set_state(mcg_env* env, const mcg_state* src, void* stream);
+/* base seed of the reset / domain-randomisation streams (changed by mcg_reset with reseed != 0): part of a checkpoint */
+uint64_t mcg_get_seed(const mcg_env* env);
+int mcg_set_seed(mcg_env* env, uint64_t seed);
 int mcg_compute_reward(const double* achieved /* [n,3] device */, const double* desired, int n, int reward_type,
                        double threshold, double* out, void* stream);
 

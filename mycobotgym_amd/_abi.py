@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("MCG_LIB") or os.path.join(_HERE, "libmycobot_hip.so")
 
 MCG_OK, MCG_ERR_ARG, MCG_ERR_HIP, MCG_ERR_UNSUPPORTED = 0, 1, 2, 3
 CTRL_JOINT, CTRL_IK, CTRL_MOCAP = 0, 1, 2
-ABI_VERSION = 2
+ABI_VERSION = 3
 REWARD_SPARSE, REWARD_DENSE, REWARD_SHAPING = 0, 1, 2
 
 d = C.c_double
@@ -46,6 +46,7 @@ class McgModel(C.Structure):
         ("geom_friction0", d * 3),
         ("base_quat", d * 4), ("weld_on", d), ("weld_par", d * 10), ("weld_diag", d), ("weld_anchor", d * 3),
         ("weld_relpos", d * 3), ("weld_relquat", d * 4), ("weld_torquescale", d),
+        ("target0", d * 3),
     ]
 
     @classmethod
@@ -84,12 +85,13 @@ class McgStepOut(C.Structure):
 
 
 class McgState(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in ("qpos", "qvel", "ctrl", "warm", "qpos_lag", "goal", "elapsed", "episode", "dr_scale")]
+    _fields_ = [(n, C.c_void_p) for n in ("qpos", "qvel", "ctrl", "warm", "qpos_lag", "goal", "elapsed", "episode", "dr_scale",
+                                          "ep_return", "ep_length")]
 
 
 EXPORTS = ("mcg_abi_version", "mcg_last_error", "mcg_default_model", "mcg_create", "mcg_destroy", "mcg_obs_dim",
            "mcg_action_dim", "mcg_nq", "mcg_nv", "mcg_reset", "mcg_step", "mcg_get_state", "mcg_set_state",
-           "mcg_compute_reward", "mcg_time_steps")
+           "mcg_compute_reward", "mcg_time_steps", "mcg_get_seed", "mcg_set_seed")
 
 _lib = None
 
@@ -120,6 +122,9 @@ def load():
     L.mcg_get_state.argtypes = [C.c_void_p, C.POINTER(McgState), C.c_void_p]
     L.mcg_set_state.argtypes = [C.c_void_p, C.POINTER(McgState), C.c_void_p]
     L.mcg_compute_reward.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_void_p]
+    if hasattr(L, "mcg_get_seed"):        # absent only from pre-v3 builds selected through MCG_LIB for A/B timing
+        L.mcg_get_seed.argtypes = [C.c_void_p]; L.mcg_get_seed.restype = C.c_uint64
+        L.mcg_set_seed.argtypes = [C.c_void_p, C.c_uint64]
     L.mcg_time_steps.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(McgStepOut), C.c_int, C.c_void_p, C.POINTER(C.c_float)]
     _lib = L
     return L

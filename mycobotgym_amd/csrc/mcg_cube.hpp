@@ -553,6 +553,10 @@ struct CubeSys {
   // Hc (21) and the right-hand sides stay in registers.  The Schur complement uses Hc = L D L^T and keeps W_i = L^-1 Cm_i
   // in place of Cm_i: S = G - sum_d W_i[d] W_j[d] / D[d].
   static constexpr int GA = LDS_ROW, CM = LDS_ROW + NB * (NB + 1) / 2;
+#ifndef MCG_FULL_STEPS
+#define MCG_FULL_STEPS 3
+#endif
+  static constexpr int FULL_STEPS = MCG_FULL_STEPS;
   static_assert(NB * (NB + 1) / 2 + 60 <= MAXCON * 12, "G and Cm must fit in the line-search row area");
   struct Coupled {                 // one contact, as the coupled solve sees it
     CubeRows RC; PadRows RP;
@@ -742,6 +746,18 @@ struct CubeSys {
       conv = conv || finish;
       MCG_TICK(ST_C_CHECK);
       if (!__any(!conv)) break;
+      // The first FULL_STEPS iterations take the full Newton step and re-mask there (semismooth Newton): when the active set
+      // settles this way the line search is never run, and a step that lands on a consistent set is the exact minimiser whatever
+      // path led to it.  Unit steps may cycle between two sets, so later iterations use the exact line search, which converges
+      // from any point.
+      if (it < FULL_STEPS) {
+        for (int i = 0; i < NB; i++) ar[i] = sel(conv, ar[i], xr[i]);
+        _Pragma("unroll") for (int d = 0; d < 6; d++) ac[d] = sel(conv, ac[d], xc[d]);
+        _Pragma("unroll") for (int j = 0; j < 10; j++) { const bool now = (sgl[j] != 0) && (sgl[j] * ar[j] - arefl[j] < 0); actl[j] = sel(conv, actl[j], now); }
+        remask(1.0, conv);
+        MCG_TICK(ST_C_LS);
+        continue;
+      }
       // line search (bisection): smooth part = robot quadratic with H0 = M + equality rows (no limits), cube diag M
       MCG_COUNT(CN_COUPLED_LS);
       real lin0 = 0, quad = 0;

@@ -30,6 +30,7 @@ int fail(int code, const char* fmt, const char* a = "") { snprintf(g_err, sizeof
 struct Cfg {
   int n, has_object, controller, fetch, reward_type, frame_skip, control_steps, max_episode_steps;
   int target_in_the_air, auto_reset, nq, nv, obs_dim, act_dim, dr_enable, block_gripper;
+  int hidden;            // Reach with reward_shaping: the cube stays in the physics as a hidden free body (mycobot.py:475-481)
   double dr_mass[2], dr_fric[2], qpos0_cube[7];
   double distance_threshold, height_offset, igx[3], dt, grip_center, grip_range;
   double init_qpos[19], init_qvel[18], init_ctrl[7];
@@ -332,7 +333,7 @@ MCG_DEV void reset_envp(const Cfg& C, int i, EnvP& E, bool doit) {
   }
   real oxy[2] = {C.igx[0], C.igx[1]}, goal[3] = {0, 0, 0};
   uint32_t draw = 0;
-  bool need = true; int tries = 0;
+  bool need = !C.hidden; int tries = 0;             // hidden cube (Reach): reset_model places nothing (mycobot.py:216: `if self.has_object`)
   do {                                              // object position (mycobot.py:217-219)
     real g[3]; sample_goal(C, i, E.episode, draw, g);
     const bool rej = sqrt((g[0] - C.igx[0]) * (g[0] - C.igx[0]) + (g[1] - C.igx[1]) * (g[1] - C.igx[1])) < 0.1;
@@ -341,6 +342,7 @@ MCG_DEV void reset_envp(const Cfg& C, int i, EnvP& E, bool doit) {
     need = need && rej && (tries + 1 < 1000);
     tries++;
   } while (__any(need));
+  const real cxy[2] = {sel(C.hidden, C.init_qpos[12], oxy[0]), sel(C.hidden, C.init_qpos[13], oxy[1])};
   need = true; tries = 0;
   do {                                              // goal (mycobot.py:231-233)
     real g[3]; sample_goal(C, i, E.episode, draw, g);
@@ -353,7 +355,7 @@ MCG_DEV void reset_envp(const Cfg& C, int i, EnvP& E, bool doit) {
   for (int k = 0; k < NB; k++) { E.R.q[k] = sel(doit, C.init_qpos[k], E.R.q[k]); E.R.qd[k] = sel(doit, C.init_qvel[k], E.R.qd[k]); }
   for (int k = 0; k < 7; k++) E.R.ctrl[k] = sel(doit, C.init_ctrl[k], E.R.ctrl[k]);
   for (int k = 0; k < 6; k++) { E.qlag6[k] = sel(doit, C.init_qpos[k], E.qlag6[k]); E.Cb.vel[k] = sel(doit, C.init_qvel[12 + k], E.Cb.vel[k]); }
-  E.Cb.pos[0] = sel(doit, oxy[0], E.Cb.pos[0]); E.Cb.pos[1] = sel(doit, oxy[1], E.Cb.pos[1]); E.Cb.pos[2] = sel(doit, C.init_qpos[14], E.Cb.pos[2]);
+  E.Cb.pos[0] = sel(doit, cxy[0], E.Cb.pos[0]); E.Cb.pos[1] = sel(doit, cxy[1], E.Cb.pos[1]); E.Cb.pos[2] = sel(doit, C.init_qpos[14], E.Cb.pos[2]);
   {   // mj_forward normalises the stored quaternion
     real q[4] = {C.init_qpos[15], C.init_qpos[16], C.init_qpos[17], C.init_qpos[18]};
     const real nq = sqrt(q[0]*q[0] + q[1]*q[1] + q[2]*q[2] + q[3]*q[3]);
@@ -385,6 +387,14 @@ MCG_DEV void observe_pnp(const Cfg& C, ModelPtr P, const EnvP& E, real* obs, rea
   }
   obs[9] = E.R.q[6]; obs[10] = E.R.q[8];
   obs[23] = E.R.qd[6] * C.dt; obs[24] = E.R.qd[8] * C.dt;
+}
+
+// Reach with a hidden cube: the observation is Reach's 10 numbers (grip_pos, gripper_state, grip_velp, gripper_vel -- the
+// object entries are empty when has_object is false, mycobot.py:258-259, 368-371) and the achieved goal is the gripper's position.
+MCG_DEV void hide_object(real* obs, real* ag) {
+  const real o[10] = {obs[0], obs[1], obs[2], obs[9], obs[10], obs[20], obs[21], obs[22], obs[23], obs[24]};
+  for (int k = 0; k < 10; k++) obs[k] = o[k];
+  for (int k = 0; k < 3; k++) ag[k] = o[k];
 }
 
 // The coupled sub-step (a finger pad touches the cube: robot and cube accelerations are solved together) is rare and
@@ -640,20 +650,24 @@ __global__ __launch_bounds__(DUAL ? 256 : PNP_LANES) void step_pnp_kernel(Cfg C,
   }
   real obs[25], ag[3];
   observe_pnp(C, P, E, obs, ag);
-  real dx = ag[0] - E.goal[0], dy = ag[1] - E.goal[1], dz = ag[2] - E.goal[2];
-  const real dist = sqrt(dx * dx + dy * dy + dz * dz);
-  const bool succ = dist < C.distance_threshold;
-  real rew = sel(C.reward_type == MCG_REWARD_SPARSE, -(real)(float)(dist > C.distance_threshold), -dist);
+  real rew_shaped = 0;
   if (C.reward_type == MCG_REWARD_SHAPING) {
     // stage_rewards (mycobot.py:402-448): reach 0.2 (1 - tanh d), grasp 0.5 iff both pads touch the cube, lift
     // 0.5 + 0.4 (1 - tanh d_obj,target); the target0 site stays at its MJCF position unless rendering (Appendix D-8)
     const real gx = obs[0] - obs[3], gy = obs[1] - obs[4], gz = obs[2] - obs[5];
     const real r_reach = (1 - tanh(sqrt(gx * gx + gy * gy + gz * gz))) * 0.2;
     const real r_grasp = E.touch ? 0.5 : 0.0;
-    const real tx = obs[3] - -0.15, ty = obs[4] - 0.0, tz = obs[5] - 0.21;
+    const real tx = obs[3] - P->target0[0], ty = obs[4] - P->target0[1], tz = obs[5] - P->target0[2];
     const real r_lift = E.touch ? 0.5 + (1 - tanh(sqrt(tx * tx + ty * ty + tz * tz))) * (0.9 - 0.5) : 0.0;
-    rew = fmax(fmax(r_reach, r_grasp), r_lift) * 100;
+    rew_shaped = fmax(fmax(r_reach, r_grasp), r_lift) * 100;
   }
+  if (C.hidden) hide_object(obs, ag);
+  const int D = C.obs_dim;
+  real dx = ag[0] - E.goal[0], dy = ag[1] - E.goal[1], dz = ag[2] - E.goal[2];
+  const real dist = sqrt(dx * dx + dy * dy + dz * dz);
+  const bool succ = dist < C.distance_threshold;
+  real rew = sel(C.reward_type == MCG_REWARD_SPARSE, -(real)(float)(dist > C.distance_threshold), -dist);
+  rew = sel(C.reward_type == MCG_REWARD_SHAPING, rew_shaped, rew);
   E.elapsed++; E.eplen++; E.epret += rew;
   const bool term = succ, trunc = succ || (E.elapsed >= C.max_episode_steps);
   if (O.reward) O.reward[i] = rew;
@@ -665,17 +679,18 @@ __global__ __launch_bounds__(DUAL ? 256 : PNP_LANES) void step_pnp_kernel(Cfg C,
   const bool done = (term || trunc) && C.auto_reset;
   if (__any(done)) {
     if (done) {
-      if (O.final_obs) for (int k = 0; k < 25; k++) O.final_obs[(size_t)i * 25 + k] = obs[k];
+      if (O.final_obs) for (int k = 0; k < 25; k++) if (k < D) O.final_obs[(size_t)i * D + k] = obs[k];
       if (O.final_achieved) for (int k = 0; k < 3; k++) O.final_achieved[(size_t)i * 3 + k] = ag[k];
       if (O.final_desired) for (int k = 0; k < 3; k++) O.final_desired[(size_t)i * 3 + k] = E.goal[k];
     }
     reset_envp(C, i, E, done);
     real obs2[25], ag2[3];
     observe_pnp(C, P, E, obs2, ag2);
+    if (C.hidden) hide_object(obs2, ag2);
     for (int k = 0; k < 25; k++) obs[k] = sel(done, obs2[k], obs[k]);
     for (int k = 0; k < 3; k++) ag[k] = sel(done, ag2[k], ag[k]);
   }
-  write_obs(O, i, 25, obs, ag, E.goal);
+  write_obs(O, i, D, obs, ag, E.goal);
   store_envp(V, i, E);
   MCG_TICK(ST_POST);
   MCG_TICK_FLUSH();
@@ -694,7 +709,8 @@ __global__ __launch_bounds__(PNP_LANES) void reset_pnp_kernel(Cfg C, View V, con
   store_envp(V, i, E);
   real obs[25], ag[3];
   observe_pnp(C, P, E, obs, ag);
-  write_obs(O, i, 25, obs, ag, E.goal);
+  if (C.hidden) hide_object(obs, ag);
+  write_obs(O, i, C.obs_dim, obs, ag, E.goal);
 }
 
 // compute_reward on batched goals (mycobot.py:289-298) -- the HER entry point
@@ -716,6 +732,8 @@ __global__ void copy_state_kernel(View V, mcg_state S, int to_engine) {
   CP(qpos, qpos, V.nq) CP(qvel, qvel, V.nv) CP(ctrl, ctrl, 7) CP(warm, warm, V.nv) CP(qpos_lag, qlag, V.nq) CP(goal, goal, 3)
   CP(dr_scale, dr, 2)
 #undef CP
+  if (S.ep_return) { if (to_engine) V.epret(i) = S.ep_return[i]; else S.ep_return[i] = V.epret(i); }
+  if (S.ep_length) { if (to_engine) V.eplen(i) = S.ep_length[i]; else S.ep_length[i] = V.eplen(i); }
   if (S.elapsed) { if (to_engine) V.elapsed(i) = S.elapsed[i]; else S.elapsed[i] = V.elapsed(i); }
   if (S.episode) { if (to_engine) V.episode(i) = S.episode[i]; else S.episode[i] = V.episode(i); }
 }
@@ -753,7 +771,6 @@ int mcg_create(const mcg_config* c, const mcg_model* model, int device, mcg_env*
       return fail(MCG_ERR_ARG, "mcg_create: the mocap controller goes with the mocap model variants (mcg_default_model 2 / 3), joint and IK with 0 / 1%s");
   }
   if (c->controller == MCG_CTRL_JOINT && c->fetch_env) return fail(MCG_ERR_ARG, "Joint controller not supported for Fetch env%s");  // mycobot.py:96
-  if (c->reward_type == MCG_REWARD_SHAPING && !c->has_object) return fail(MCG_ERR_UNSUPPORTED, "mcg_create: reward_shaping reads the cube, which the Reach engine drops (SURVEY D-7)%s");
   if (c->reward_type < MCG_REWARD_SPARSE || c->reward_type > MCG_REWARD_SHAPING) return fail(MCG_ERR_ARG, "mcg_create: bad reward_type%s");
   {
     const mcg_model* mm = model ? model : &kDefaultModels[0];
@@ -772,10 +789,14 @@ int mcg_create(const mcg_config* c, const mcg_model* model, int device, mcg_env*
   if (!e) return fail(MCG_ERR_ARG, "mcg_create: out of host memory%s");
   const mcg_model* m = model ? model : &kDefaultModels[0];
   Cfg& C = e->cfg;
-  C.n = c->n_envs; C.has_object = c->has_object; C.controller = c->controller; C.fetch = c->fetch_env;
+  // Reach + reward_shaping: stage_rewards reads the cube's site and its pad contacts (mycobot.py:402-448), and the reference only
+  // HIDES the cube in Reach (geom and site size := 0, mycobot.py:475-481) -- body, mass and free joint stay.  Those ids run the
+  // PickAndPlace kernels on a model whose cube has zero half-size, with Reach's observation, goal and reset.
+  C.hidden = (c->reward_type == MCG_REWARD_SHAPING && !c->has_object) ? 1 : 0;
+  C.n = c->n_envs; C.has_object = (c->has_object || C.hidden) ? 1 : 0; C.controller = c->controller; C.fetch = c->fetch_env;
   C.reward_type = c->reward_type; C.frame_skip = c->frame_skip; C.control_steps = c->control_steps;
   C.max_episode_steps = c->max_episode_steps; C.target_in_the_air = c->target_in_the_air; C.auto_reset = c->auto_reset;
-  C.nq = c->has_object ? 19 : 12; C.nv = c->has_object ? 18 : 12;
+  C.nq = C.has_object ? 19 : 12; C.nv = C.has_object ? 18 : 12;
   C.obs_dim = c->has_object ? 25 : 10;
   C.act_dim = c->controller == MCG_CTRL_MOCAP ? (c->fetch_env ? 4 : 8)
             : (c->controller == MCG_CTRL_IK && c->fetch_env) ? 4 : 7;                 // mycobot.py:84-103
@@ -812,7 +833,11 @@ int mcg_create(const mcg_config* c, const mcg_model* model, int device, mcg_env*
     std::vector<double> ones((size_t)2 * C.n, 1.0);
     err = hipMemcpy(e->view.d + (size_t)(2 * C.nq + 2 * C.nv + 11) * C.n, ones.data(), ones.size() * sizeof(double), hipMemcpyHostToDevice);
   }
-  if (err == hipSuccess) err = hipMemcpy(e->d_model, m, sizeof(mcg_model), hipMemcpyHostToDevice);
+  if (err == hipSuccess) {
+    mcg_model mm = *m;
+    if (C.hidden) mm.cube_half[0] = mm.cube_half[1] = mm.cube_half[2] = 0.0;       // model.geom_size[object0] = 0
+    err = hipMemcpy(e->d_model, &mm, sizeof(mcg_model), hipMemcpyHostToDevice);
+  }
   if (err != hipSuccess) { mcg_destroy(e); return fail(MCG_ERR_HIP, "mcg_create: %s", hipGetErrorString(err)); }
   *out = e;
   return MCG_OK;
@@ -920,6 +945,8 @@ static int copy_state(mcg_env* e, const mcg_state* s, int to_engine, void* strea
   return MCG_OK;
 }
 int mcg_get_state(mcg_env* e, const mcg_state* dst, void* stream) { return copy_state(e, dst, 0, stream); }
+uint64_t mcg_get_seed(const mcg_env* e) { return e ? (uint64_t)e->cfg.seed : 0; }
+int mcg_set_seed(mcg_env* e, uint64_t seed) { if (!e) return fail(MCG_ERR_ARG, "mcg_set_seed: null handle%s"); e->cfg.seed = seed; return MCG_OK; }
 int mcg_set_state(mcg_env* e, const mcg_state* src, void* stream) { return copy_state(e, src, 1, stream); }
 
 int mcg_compute_reward(const double* achieved, const double* desired, int n, int reward_type, double threshold,

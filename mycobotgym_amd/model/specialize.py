@@ -187,6 +187,9 @@ def specialize(m: dict) -> dict:
     i6, R, p = weld_frames[m["site_body"][s]]
     assert i6 == 5 and np.allclose(R, np.eye(3)) and np.allclose(m["site_quat"][s], [1, 0, 0, 0])
     out["site_eef"] = p + np.asarray(m["site_pos"][s])
+    # site target0 hangs on the world body: stage_rewards reads its MJCF position unless the env is rendering (mycobot.py:422, 309-311)
+    out["target0"] = (np.asarray(m["site_pos"][m["site_name"].index("target0")], dtype=np.float64)
+                      if "target0" in m["site_name"] else np.array([-0.15, 0.0, 0.21]))
 
     # --- mocap weld (mocap.xml:15-20): body1 = the mocap body (static), body2 = gripper_tcp, welded into link6
     out["weld_on"] = 0.0

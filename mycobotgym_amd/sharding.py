@@ -19,12 +19,15 @@ def shard(rank: int, world: int, envs_per_rank: int):
 
 
 def reduce_episode_stats(ep_return: torch.Tensor, ep_length: torch.Tensor, is_success: torch.Tensor,
-                         done: torch.Tensor, group=None) -> dict:
+                         done: torch.Tensor, group=None, device=None) -> dict:
     """Sum over all ranks of [finished episodes, their returns, lengths, successes] -> host dict.
-    One 32-byte all_reduce; call it once per logging interval, never per step."""
+    One 32-byte all_reduce; call it once per logging interval, never per step.  `device`: where the four numbers are
+    reduced (default: where the inputs live -- the GPU, i.e. RCCL; "cpu" for a gloo group)."""
     d = done.to(torch.float64)
     stats = torch.stack([d.sum(), (ep_return.double() * d).sum(), (ep_length.double() * d).sum(),
                          (is_success.double() * d).sum()])
+    if device is not None:
+        stats = stats.to(device)
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=group)
     n, r, l, s = stats.tolist()

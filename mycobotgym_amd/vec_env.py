@@ -86,8 +86,15 @@ class MyCobotVecEnv:
         self._lib = _abi.load()
         if not torch.cuda.is_available():
             raise _abi.McgError("no GPU visible to PyTorch-ROCm; MyCobotVecEnv has no CPU path")
+        if model_path is not None:          # the registry's kwarg (mycobotgym/__init__.py:12): only the built-in, precompiled assets exist here
+            want = f"mycobot280{'_mocap' if controller_type == 'mocap' else ''}.xml"
+            if os.path.basename(str(model_path)) != want:
+                raise ValueError(f"model_path {model_path!r}: this engine runs the precompiled {want} only (compile another MJCF with "
+                                 "tools/compile_model.py and pass it as model=McgModel.from_spec(...))")
         self.num_envs = int(num_envs)
         self.has_object, self.fetch_env = bool(has_object), bool(fetch_env)
+        # Reach + reward_shaping keeps the (hidden) cube in the physics: stage_rewards reads it (mycobot.py:402-448, 475-481)
+        self.hidden_object = (not self.has_object) and reward_type == "reward_shaping"
         self.controller_type, self.reward_type = controller_type, reward_type
         self.distance_threshold = float(distance_threshold)
         self.frame_skip, self.control_steps = int(frame_skip), int(control_steps)
@@ -95,7 +102,7 @@ class MyCobotVecEnv:
         self.obj_range = obj_range
 
         mocap = controller_type == "mocap"
-        qpos, qvel, ctrl, igx, height = initial_state(self.has_object, self.fetch_env, mesh_inertia, mocap)
+        qpos, qvel, ctrl, igx, height = initial_state(self.has_object or self.hidden_object, self.fetch_env, mesh_inertia, mocap)
         self.initial_gripper_xpos, self.height_offset = igx, height
         cfg = _abi.McgConfig()
         cfg.n_envs = self.num_envs; cfg.has_object = int(self.has_object)
@@ -172,10 +179,11 @@ class MyCobotVecEnv:
         self._needs_reset = False
         return self._obs(), {}
 
-    def step(self, actions):
+    def step(self, actions, copy: bool = True):
         """actions: float32 [N, A] (device tensor; numpy / CPU tensors are copied over).
-        -> (obs, reward[N] f64, terminated[N] bool, truncated[N] bool, info).  Returned tensors are the engine's
-        output buffers and are overwritten by the next call -- clone what you keep."""
+        -> (obs, reward[N], terminated[N] bool, truncated[N] bool, info).  Like the reference (mycobot.py:280-282) the returned
+        arrays are fresh copies; ``copy=False`` hands out the engine's output buffers instead, which the next call overwrites
+        (``step_async`` is the raw, packaging-free variant).  The sparse reward is float32, dense / shaped float64 (mycobot.py:293-298)."""
         if self._needs_reset:
             raise RuntimeError("Cannot call env.step() before calling env.reset()")     # OrderEnforcing [RECALL]
         a = torch.as_tensor(actions, dtype=torch.float32, device=self.device).contiguous()
@@ -183,7 +191,9 @@ class MyCobotVecEnv:
             raise ValueError(f"actions must have shape {(self.num_envs, self.action_dim)}, got {tuple(a.shape)}")
         with torch.cuda.device(self.device):
             _abi.check(self._lib.mcg_step(self._h, C.c_void_p(a.data_ptr()), C.byref(self._out), self._stream()), "mcg_step")
-        b = self._buf
+        b = {k: v.clone() for k, v in self._buf.items()} if copy else self._buf
+        if self.reward_type == "sparse":
+            b = dict(b, reward=b["reward"].float())
         terminated, truncated = b["terminated"], b["truncated"]
         done = truncated          # truncated = is_success | time-limit, so it already covers terminated (D-4)
         info = {"is_success": b["is_success"],
@@ -191,7 +201,8 @@ class MyCobotVecEnv:
                                       "desired_goal": b["final_desired"]},
                 "_final_observation": done,
                 "episode": {"r": b["ep_return"], "l": b["ep_length"]}, "_episode": done}
-        return self._obs(), b["reward"], terminated, truncated, info
+        obs = {"observation": b["obs"], "achieved_goal": b["achieved_goal"], "desired_goal": b["desired_goal"]}
+        return obs, b["reward"], terminated, truncated, info
 
     def step_async(self, actions: torch.Tensor) -> dict:
         """Launch one step on the current stream and return the raw output buffers (no Python-side packaging).
@@ -223,17 +234,24 @@ class MyCobotVecEnv:
                 "qpos_lag": torch.zeros(self.nq, n, **f64), "goal": torch.zeros(3, n, **f64),
                 "elapsed": torch.zeros(n, dtype=torch.int32, device=dev),
                 "episode": torch.zeros(n, dtype=torch.int32, device=dev),
-                "dr_scale": torch.ones(2, n, **f64)}
+                "dr_scale": torch.ones(2, n, **f64), "ep_return": torch.zeros(n, **f64),
+                "ep_length": torch.zeros(n, dtype=torch.int32, device=dev)}
 
     def get_state(self) -> dict:
-        """SoA tensors [dim, N] (the engine's layout): qpos qvel ctrl warm qpos_lag goal elapsed episode."""
+        """SoA tensors [dim, N] (the engine's layout): qpos qvel ctrl warm qpos_lag goal elapsed episode dr_scale, the running
+        episode statistics ep_return / ep_length, and `seed` (the base seed of the reset streams, a one-element int64 tensor): everything a
+        freshly constructed engine needs to continue this one's trajectories, auto-resets included."""
         s = self._state_bufs()
         st = _abi.McgState(**{k: v.data_ptr() for k, v in s.items()})
         with torch.cuda.device(self.device):
             _abi.check(self._lib.mcg_get_state(self._h, C.byref(st), self._stream()), "mcg_get_state")
+        seed = int(self._lib.mcg_get_seed(self._h))
+        s["seed"] = torch.tensor([seed - 2 ** 64 if seed >= 2 ** 63 else seed], dtype=torch.int64)     # uint64 carried in an int64 tensor
         return s
 
     def set_state(self, **state):
+        if state.get("seed") is not None:
+            _abi.check(self._lib.mcg_set_seed(self._h, C.c_uint64(int(torch.as_tensor(state["seed"]).reshape(-1)[0]) & (2 ** 64 - 1))), "mcg_set_seed")
         keep = {}
         for k, ref in self._state_bufs().items():
             if k in state and state[k] is not None:

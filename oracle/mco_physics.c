@@ -487,6 +487,11 @@ static void make_constraint(const mco_model* m, mco_data* d) {
          * 3-5 (43x softer) the equilibrium residual is rotation-dominated instead and the arm leaves the keyframe
          * (tests/test_oracle_known_answers.py).  The common value = the translational weight is an assumption [unpinned]. */
         d->efc_diagApprox[i] = m->body_invweight0[m->eq_obj1[id]][0] + m->body_invweight0[m->eq_obj2[id]][0];
+        if (m->rule[0] == 1) {            /* study switch: the rule as recalled from mj_diagApprox (rows 3-5 rotational) */
+          int first = i; while (first > 0 && d->efc_type[first - 1] == MCO_EFC_EQUALITY && d->efc_id[first - 1] == id) first--;
+          int part = (i - first) > 2;
+          d->efc_diagApprox[i] = m->body_invweight0[m->eq_obj1[id]][part] + m->body_invweight0[m->eq_obj2[id]][part];
+        }
       } else
         d->efc_diagApprox[i] = m->dof_invweight0[m->jnt_dofadr[m->eq_obj1[id]]] + m->dof_invweight0[m->jnt_dofadr[m->eq_obj2[id]]];
     } else if (d->efc_type[i] == MCO_EFC_LIMIT) {
@@ -501,6 +506,7 @@ static void make_constraint(const mco_model* m, mco_data* d) {
         int j = i - con->efc_address;
         double fri = con->friction[j / 2];
         d->efc_diagApprox[i] = tran + fri * fri * (j < 4 ? tran : rot);
+        if (m->rule[2] == 1) d->efc_diagApprox[i] = tran;
       }
     }
   }
@@ -514,6 +520,8 @@ static void make_constraint(const mco_model* m, mco_data* d) {
       int size = m->eq_type[d->efc_id[i]] == MCO_EQ_WELD ? 6 : 3;     /* a weld's six rows share one impedance likewise */
       double ss = 0; for (int r = 0; r < size; r++) ss += d->efc_pos[first + r] * d->efc_pos[first + r];
       pos = sqrt(ss);
+      if (size == 6 && m->rule[1] == 1) pos = d->efc_pos[i];
+      if (size == 6 && m->rule[1] == 2) pos = d->efc_margin[i];
     }
     double imp = get_impedance(solimp, pos, d->efc_margin[i]);
     if (imp < MINIMP) imp = MINIMP; if (imp > MAXIMP) imp = MAXIMP;
@@ -536,6 +544,8 @@ static void make_constraint(const mco_model* m, mco_data* d) {
     if (con->dim > 1) {
       int a = con->efc_address;
       double Rpy = 2 * con->friction[0] * con->friction[0] * d->efc_R[a];
+      if (m->rule[3] == 1) continue;
+      if (m->rule[3] == 2) Rpy *= 2;
       if (Rpy < MINVAL) Rpy = MINVAL;
       for (int j = 0; j < 2 * (con->dim - 1); j++) d->efc_R[a + j] = Rpy;
     }
@@ -842,7 +852,7 @@ typedef struct { const char* name; size_t off; int count; int is_int; } field_t;
 #define MF_D(f) { #f, offsetof(mco_model, f), (int)(sizeof(((mco_model*)0)->f) / sizeof(double)), 0 }
 static const field_t model_fields[] = {
   MF_I(nbody), MF_I(njnt), MF_I(nq), MF_I(nv), MF_I(ngeom), MF_I(nsite), MF_I(nu), MF_I(neq), MF_I(ntendon),
-  MF_I(nexclude), MF_I(enable_contact), MF_I(collide_scope_geom), MF_D(timestep), MF_D(gravity), MF_D(meaninertia),
+  MF_I(nexclude), MF_I(enable_contact), MF_I(collide_scope_geom), MF_I(rule), MF_D(timestep), MF_D(gravity), MF_D(meaninertia),
   MF_I(body_parent), MF_I(body_rootid), MF_I(body_weldid), MF_I(body_dofadr), MF_I(body_dofnum), MF_I(body_mocapid),
   MF_D(body_pos), MF_D(body_quat), MF_D(body_ipos), MF_D(body_iquat), MF_D(body_mass), MF_D(body_inertia),
   MF_I(jnt_type), MF_I(jnt_body), MF_I(jnt_qposadr), MF_I(jnt_dofadr), MF_I(jnt_limited),

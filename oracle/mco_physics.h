@@ -52,6 +52,13 @@ typedef struct mco_model {
   double timestep, gravity[3], meaninertia;
   int enable_contact;            /* 0: collision stage skipped (Reach / free-space configs) */
   int collide_scope_geom;        /* >= 0: only pairs that involve this geom collide (the build's scoped set: the cube) */
+  /* Study switches (oracle/rule_study.py): alternatives to [RECALL] rules the reference's keyframes can discriminate.
+   * All zero = the adopted rule set, which is what the HIP kernels implement and every parity test runs.
+   *   rule[0] weld diagApprox   0 one common (translational) weight for the six rows | 1 translational rows 0-2, rotational rows 3-5
+   *   rule[1] weld impedance    0 one impedance at the 6-norm of the residual | 1 one per row at |pos_row| | 2 fixed at solimp[0]
+   *   rule[2] pyramid diagApprox 0 tran + mu_k^2 (tran | rot) | 1 tran
+   *   rule[3] pyramid R         0 Rpy = 2 mu^2 R(first edge) on all edges | 1 each edge keeps its own R | 2 Rpy = 4 mu^2 R(first edge) */
+  int rule[8];
   /* bodies */
   int body_parent[MCO_MAXBODY], body_rootid[MCO_MAXBODY], body_weldid[MCO_MAXBODY];
   int body_dofadr[MCO_MAXBODY], body_dofnum[MCO_MAXBODY];

@@ -36,10 +36,15 @@ def make_oracle(n, has_object=False, controller_type="joint", fetch_env=False, r
     from oracle import pyoracle as po
     from mycobotgym_amd.vec_env import initial_state
     mocap = controller_type == "mocap"
-    tab = table if table is not None else load_json(table_name(has_object, mesh_inertia, mocap))
+    hidden = (not has_object) and reward_type == "reward_shaping"      # Reach keeps the cube, hidden (mycobot.py:475-481)
+    tab = table if table is not None else load_json(table_name(has_object or hidden, mesh_inertia, mocap))
+    if hidden:
+        tab = json.loads(json.dumps(tab))
+        tab["geom_size"][tab["geom_name"].index("object0")] = [0.0, 0.0, 0.0]        # self.model.geom_size[object_id] = 0
+    has_cube = has_object or hidden
     # the build's scoped collision set: pairs involving the cube
-    model = po.OracleModel(tab, enable_contact=has_object, scope_geom=tab["geom_name"].index("object0") if has_object else -1)
-    qpos, qvel, ctrl, igx, height = initial_state(has_object, fetch_env, mesh_inertia, mocap)
+    model = po.OracleModel(tab, enable_contact=has_cube, scope_geom=tab["geom_name"].index("object0") if has_cube else -1)
+    qpos, qvel, ctrl, igx, height = initial_state(has_cube, fetch_env, mesh_inertia, mocap)
     ctrl = ctrl[7 - tab["nu"]:]                  # the oracle's ctrl has the model's nu entries (mocap model: the finger only)
     cfg = po.EnvConfig()
     cfg.n_envs = n; cfg.has_object = int(has_object)
@@ -56,7 +61,7 @@ def make_oracle(n, has_object=False, controller_type="joint", fetch_env=False, r
     cfg.frame_skip = frame_skip; cfg.control_steps = control_steps; cfg.max_episode_steps = max_episode_steps
     cfg.target_in_the_air = int(target_in_the_air); cfg.auto_reset = int(auto_reset)
     cfg.eef_site = tab["site_name"].index("EEF")
-    cfg.obj_site = tab["site_name"].index("object0") if has_object else -1
+    cfg.obj_site = tab["site_name"].index("object0") if has_cube else -1
     cfg.obj_jnt = tab["jnt_name"].index("object0:joint") if has_object else -1
     cfg.grip_jnt[0] = tab["jnt_name"].index("robot0:right_gear_joint")
     cfg.grip_jnt[1] = tab["jnt_name"].index("robot0:left_gear_joint")
@@ -64,7 +69,7 @@ def make_oracle(n, has_object=False, controller_type="joint", fetch_env=False, r
     cfg.finger_jnt[0] = tab["jnt_name"].index("right_finger_joint"); cfg.finger_jnt[1] = tab["jnt_name"].index("left_finger_joint")
     cfg.n_threads = n_threads or min(os.cpu_count() or 1, 16)
     cfg.pad_geom[0] = cfg.pad_geom[1] = cfg.obj_geom = -1
-    if has_object:
+    if has_cube:
         cfg.pad_geom[0] = tab["geom_name"].index("right_finger_layer"); cfg.pad_geom[1] = tab["geom_name"].index("left_finger_layer")
         cfg.obj_geom = tab["geom_name"].index("object0")
     cfg.distance_threshold = distance_threshold; cfg.height_offset = height

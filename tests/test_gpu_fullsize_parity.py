@@ -1,0 +1,173 @@
+"""GPU parity at BASELINE's full size and below env-step granularity (round-2 additions).
+
+* PickAndPlace at N = 8192 (the size where the grid is exactly one 160 KB-LDS workgroup per CU): determinism and finiteness over
+  60 steps for the joint / IK / mocap controllers, and oracle parity of one env-step from identical state on a 256-env subset
+  that visits every lane position and 248 of the 256 workgroups (stride 31), moved to the CPU oracle through get_state / set_state.
+* The IK controller below env-step granularity: frame_skip = 1 engines, so that one env.step is control_steps x (one
+  damped-least-squares solve + ONE physics sub-step); ctrl[:6] -- the solve's output, accumulated -- is compared after every step
+  from identical state (utils.py:499-556, mycobot.py:162-170).
+* Tolerances per controller, tied to what is measured (printed by each test): joint / mocap / PickAndPlace-joint env-steps from
+  identical state agree to 1e-8 in the worst env; the 100-sub-step IK env-step amplifies rounding chaotically, so its error
+  quantiles are bounded by 10x the oracle's own sensitivity to a 1e-14 perturbation, measured in the same test.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+N_FULL = 8192
+
+
+@pytest.fixture(scope="module")
+def torch_cuda(built):
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a visible MI355X"
+    return torch
+
+
+def _actions(rng, n, dim, controller):
+    a = rng.uniform(-1, 1, (n, dim)).astype(np.float32)
+    if controller == "mocap" and dim == 8:      # orientation commands around the gripper's rest orientation
+        a[:, 3:7] = (np.array([0.70710678, 0, 0, 0.70710678]) + 0.3 * rng.normal(size=(n, 4))).astype(np.float32)
+    return a
+
+
+@pytest.mark.parametrize("controller", ["joint", "IK", "mocap"])
+def test_pickandplace_full_size(torch_cuda, controller):
+    torch = torch_cuda
+    from mycobotgym_amd import MyCobotVecEnv
+    from tests.common import make_oracle
+    steps = {"joint": 60, "IK": 52, "mocap": 60}[controller]
+    probe = 23                                   # the env-step that is also checked against the oracle
+    idx = (np.arange(256) * 31).astype(np.int64)             # lanes 0..31 all visited, workgroups spread over the grid
+    rng = np.random.default_rng(17)
+    acts = [_actions(rng, N_FULL, 8 if controller == "mocap" else 7, controller) for _ in range(steps)]
+    runs, snap = [], None
+    for rep in range(2):
+        envs = MyCobotVecEnv(N_FULL, has_object=True, controller_type=controller, reward_type="dense", seed=5)
+        envs.reset(seed=5)
+        outs = []
+        for t in range(steps):
+            if rep == 0 and t == probe:
+                snap = {k: v.clone() for k, v in envs.get_state().items()}
+            obs, rew, term, trunc, info = envs.step(torch.as_tensor(acts[t]))
+            outs.append((obs["observation"].clone(), rew.clone(), trunc.clone(), obs["desired_goal"].clone(),
+                         info["final_observation"]["observation"].clone()))
+        runs.append(outs)
+        envs.close()
+    for a_, b_ in zip(*runs):
+        for x, y in zip(a_, b_):
+            assert torch.equal(x, y)                          # two engines, same seed: bit-identical
+    for o, r, tr, g, f in runs[0]:
+        assert torch.isfinite(o).all() and torch.isfinite(r).all()
+    assert runs[0][49][2].all()                               # TimeLimit(50) at 8192 envs
+    cube_z = runs[0][-1][0][:, 5]
+    assert (cube_z > 0.19).float().mean() > 0.99              # the cubes are on the table (or lifted), not through it
+
+    # ---- one env-step from identical state against the oracle, on the subset
+    ora = make_oracle(256, has_object=True, controller_type=controller, reward_type="dense", seed=5)
+    ora.reset(seed=5)
+    sub = {k: v.cpu().numpy() for k, v in snap.items()}
+    ctrl = sub["ctrl"][:, idx].T.copy()
+    if ora.model.nu < 7: ctrl = ctrl[:, 7 - ora.model.nu:]
+    ora.set_state(qpos=sub["qpos"][:, idx].T.copy(), qvel=sub["qvel"][:, idx].T.copy(), ctrl=ctrl,
+                  warm=sub["warm"][:, idx].T.copy(), qpos_lag=sub["qpos_lag"][:, idx].T.copy(), goal=sub["goal"][:, idx].T.copy(),
+                  elapsed=sub["elapsed"][idx].copy(), episode=sub["episode"][idx].copy())
+    o = ora.step(acts[probe][idx])
+    hip_obs = runs[0][probe][0].cpu().numpy()[idx]
+    hip_rew = runs[0][probe][1].cpu().numpy()[idx]
+    done = o["truncated"].astype(bool)
+    assert np.array_equal(runs[0][probe][2].cpu().numpy()[idx], done)
+    keep = ~done                                              # (an auto-reset draws from the env's GLOBAL id, which the subset oracle does not share)
+    err = np.abs(hip_obs[keep] - o["obs"][keep]).max(axis=1)
+    err = np.maximum(err, np.abs(hip_rew[keep] - o["reward"][keep]))
+    ncon = [int(ora.data(i).get("ncon", (1,), np.int32)[0]) for i in range(256)]
+    print(f"\n[pnp {controller} @8192] env-step {probe} from identical state, {keep.sum()} envs of the stride-31 subset: "
+          f"median {np.median(err):.2e} p90 {np.quantile(err, 0.9):.2e} max {err.max():.2e}; contacts per env {sorted(set(ncon))}")
+    if controller == "IK":
+        assert np.median(err) < 1e-9 and np.quantile(err, 0.9) < 1e-6
+    else:
+        assert err.max() < 1e-8
+
+
+@pytest.mark.parametrize("control_steps", [1, 5])
+def test_ik_solves_teacher_forced(torch_cuda, control_steps):
+    """frame_skip = 1: env.step = control_steps x (IK solve -> ctrl += dq -> ONE sub-step).  State re-synchronised before
+    every step; ctrl[:6] after the step is the accumulated output of the damped-least-squares solves."""
+    from tests.common import make_pair, sync_oracle_to, step_errors
+    n = 256
+    for fetch in (False, True):
+        envs, ora = make_pair(n, controller_type="IK", fetch_env=fetch, reward_type="dense", seed=13, frame_skip=1,
+                              control_steps=control_steps, max_episode_steps=10 ** 9)
+        envs.reset(seed=13); ora.reset(seed=13)
+        rng = np.random.default_rng(8)
+        worst = dict(obs=0.0, ctrl=0.0, qpos=0.0, qvel=0.0)
+        for t in range(300 if control_steps == 1 else 120):
+            if t % 20 == 0:
+                a = rng.uniform(-1, 1, (n, envs.action_dim)).astype(np.float32)
+            sync_oracle_to(envs, ora)
+            e, flags_equal, o = step_errors(envs, ora, a)
+            assert flags_equal
+            st, so = envs.get_state(), ora.get_state()
+            worst["obs"] = max(worst["obs"], e.max())
+            worst["ctrl"] = max(worst["ctrl"], np.abs(st["ctrl"].cpu().numpy().T[:, :6] - so["ctrl"][:, :6]).max())
+            worst["qpos"] = max(worst["qpos"], np.abs(st["qpos"].cpu().numpy().T - so["qpos"]).max())
+            worst["qvel"] = max(worst["qvel"], np.abs(st["qvel"].cpu().numpy().T - so["qvel"]).max())
+        print(f"\n[IK{' fetch' if fetch else ''}, control_steps={control_steps}, frame_skip=1] teacher-forced x {n} envs: {worst}")
+        assert worst["ctrl"] < 1e-11                 # |dq| per solve is O(0.1): 11 digits
+        assert worst["obs"] < 1e-9 and worst["qpos"] < 1e-9 and worst["qvel"] < 1e-7
+        envs.close()
+
+
+def _quantiles(e):
+    return np.array([np.median(e), np.quantile(e, 0.9), np.quantile(e, 0.99), e.max()])
+
+
+@pytest.mark.parametrize("controller,has_object", [("joint", False), ("mocap", False), ("joint", True)])
+def test_env_step_worst_case_bounds(torch_cuda, controller, has_object):
+    """20-sub-step env-steps from identical state: the WORST env of 100 x 256 samples (measured 3e-11 / 2e-12 / 1e-13)."""
+    from tests.common import make_pair, sync_oracle_to, step_errors
+    n = 256
+    envs, ora = make_pair(n, has_object=has_object, controller_type=controller, reward_type="dense", seed=1)
+    envs.reset(seed=1); ora.reset(seed=1)
+    rng = np.random.default_rng(42)
+    errs = []
+    for t in range(100):
+        sync_oracle_to(envs, ora)
+        e, flags_equal, o = step_errors(envs, ora, _actions(rng, n, envs.action_dim, controller))
+        assert flags_equal
+        errs.append(e)
+    errs = np.concatenate(errs)
+    q = _quantiles(errs)
+    print(f"\n[{'pnp' if has_object else 'reach'} {controller}] env-step from identical state, {errs.size} samples: "
+          f"median {q[0]:.2e} p90 {q[1]:.2e} p99 {q[2]:.2e} max {q[3]:.2e}")
+    assert q[3] < 1e-8 and q[0] < 1e-13
+    envs.close()
+
+
+def test_ik_env_step_error_is_the_oracles_own_sensitivity(torch_cuda):
+    """100 sub-steps of the stiff servos amplify rounding: the HIP-vs-oracle error of one IK env-step from identical state is
+    compared, quantile by quantile, with the oracle's own response to a 1e-14 perturbation of the same states."""
+    from tests.common import make_pair, make_oracle, sync_oracle_to, step_errors
+    n = 256
+    envs, ora = make_pair(n, controller_type="IK", reward_type="dense", seed=1)
+    twin = make_oracle(n, controller_type="IK", reward_type="dense", seed=1)
+    envs.reset(seed=1); ora.reset(seed=1); twin.reset(seed=1)
+    rng = np.random.default_rng(42); prng = np.random.default_rng(0)
+    e_hip, e_twin = [], []
+    for t in range(60):
+        sync_oracle_to(envs, ora)
+        s = ora.get_state()
+        s["qpos"] = s["qpos"] + 1e-14 * np.sign(prng.normal(size=s["qpos"].shape))
+        twin.set_state(**s)
+        a = rng.uniform(-1, 1, (n, 7)).astype(np.float32)
+        e, flags_equal, o = step_errors(envs, ora, a)
+        ot = twin.step(a)
+        e_hip.append(e); e_twin.append(np.abs(ot["obs"] - o["obs"]).max(axis=1))
+    qh, qt = _quantiles(np.concatenate(e_hip)), _quantiles(np.concatenate(e_twin))
+    print("\n[reach IK] one env-step from identical state, quantiles (median p90 p99 max):")
+    print("   hip vs oracle           :", " ".join(f"{x:.2e}" for x in qh))
+    print("   oracle vs oracle + 1e-14:", " ".join(f"{x:.2e}" for x in qt))
+    assert np.all(qh[:3] <= 10 * qt[:3] + 1e-13)
+    assert qh[3] <= 10 * qt[3] + 1e-13 or qh[3] < 1e-6
+    assert qh[0] < 1e-10
+    envs.close()

@@ -122,7 +122,9 @@ def test_exact_mesh_variant_and_fetch(torch_cuda):
             sync_oracle_to(envs, ora)
             e, flags, _ = step_errors(envs, ora, rng.uniform(-1, 1, (128, envs.action_dim)).astype(np.float32))
             assert flags; errs.append(e)
-        assert np.median(np.concatenate(errs)) < 1e-9
+        errs = np.concatenate(errs)
+        if kw["controller_type"] == "joint": assert errs.max() < 1e-8
+        else: assert np.median(errs) < 3e-8 and np.quantile(errs, 0.99) < 1e-2      # fetch keyframe = a near-singular wrist pose: measured median 3.6e-10
         envs.close()
 
 
@@ -140,7 +142,7 @@ def test_block_gripper(torch_cuda):
             assert flags; errs.append(e)
             q = envs.get_state()["qpos"]
             assert (q[7] == 0).all() and (q[9] == 0).all()
-        assert np.median(np.concatenate(errs)) < 1e-9
+        assert np.concatenate(errs).max() < 1e-8
         envs.close()
 
 
@@ -164,21 +166,15 @@ def test_bad_state_recovers(torch_cuda):
 
 
 def test_every_v0_id_constructs_and_steps(torch_cuda):
-    """The 30 `-v0` registrations of the reference (mycobotgym/__init__.py:26-45): 25 build an engine and step, the five
-    Reach-RewardShaping ids are rejected with a reason."""
+    """The 30 `-v0` registrations of the reference (mycobotgym/__init__.py:26-45): every one builds an engine and steps (the five
+    Reach-RewardShaping ids keep the cube as a hidden free body, mycobot.py:475-481)."""
     torch = torch_cuda
     from mycobotgym_amd import make
     from mycobotgym_amd.registry import REGISTRY
     ids = sorted(k for k in REGISTRY if k.endswith("-v0"))
     assert len(ids) == 30
-    from mycobotgym_amd._abi import McgError
     built_ids = 0
     for env_id in ids:
-        if not REGISTRY[env_id]["has_object"] and REGISTRY[env_id]["reward_type"] == "reward_shaping":
-            # stage_rewards reads the cube, which the Reach engine drops (hidden, unobserved: SURVEY D-7): rejected loudly
-            with pytest.raises(McgError, match="reward_shaping"):
-                make(env_id, num_envs=16)
-            continue
         built_ids += 1
         envs = make(env_id, num_envs=16)
         obs, _ = envs.reset(seed=1)
@@ -192,7 +188,7 @@ def test_every_v0_id_constructs_and_steps(torch_cuda):
         assert envs.action_dim == want, env_id
         assert obs["observation"].shape == (16, 25 if REGISTRY[env_id]["has_object"] else 10)
         envs.close()
-    assert built_ids == 25          # 30 minus the five Reach-RewardShaping ids
+    assert built_ids == 30
 
 
 @pytest.mark.parametrize("controller", ["joint", "IK", "mocap"])
@@ -219,8 +215,9 @@ def test_two_wave_and_one_wave_kernels_agree(torch_cuda, controller, monkeypatch
     errs = np.concatenate(errs)
     print(f"\n[{controller}] two-wave vs one-wave kernels, one env-step from identical state: median {np.median(errs):.2e} "
           f"p99 {np.quantile(errs, 0.99):.2e} max {errs.max():.2e}")
-    # the servo-driven controllers are chaotic: same criterion as HIP-vs-oracle in test_gpu_parity.py
-    assert np.median(errs) < 1e-9 and np.quantile(errs, 0.99) < 1e-4
+    # the servo-driven controllers are chaotic: same criteria as HIP-vs-oracle in test_gpu_parity.py
+    if controller == "IK": assert np.median(errs) < 3e-10 and np.quantile(errs, 0.99) < 1e-3
+    else: assert errs.max() < 1e-8
     # a grid beyond one workgroup per CU takes the one-wave path by itself
     big = MyCobotVecEnv(64 * 300, has_object=False, controller_type=controller, reward_type="dense")
     o, _ = big.reset(seed=1)
@@ -260,7 +257,7 @@ def test_two_wave_and_one_wave_pickandplace_kernels_agree(torch_cuda, controller
     errs = np.concatenate(errs)
     print(f"\n[{controller}] PickAndPlace two-wave vs one-wave, one env-step from identical state: median {np.median(errs):.2e} "
           f"p99 {np.quantile(errs, 0.99):.2e} max {errs.max():.2e}; env-steps with both pads on the cube: {touched}")
-    assert np.median(errs) < 1e-9 and np.quantile(errs, 0.99) < 1e-4
+    assert errs.max() < 1e-8
     if controller == "joint":
         assert touched > 0
     a_env.close(); b_env.close()
@@ -277,7 +274,7 @@ def test_ragged_env_counts_with_multi_wave_kernels(torch_cuda, has_object, n):
     for t in range(4):
         sync_oracle_to(envs, ora)
         e, flags_equal, _ = step_errors(envs, ora, rng.uniform(-1, 1, (n, 7)).astype(np.float32))
-        assert flags_equal and np.median(e) < 1e-9 and e.max() < 1e-5
+        assert flags_equal and e.max() < 1e-8
     envs.close()
 
 

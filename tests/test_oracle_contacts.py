@@ -58,12 +58,21 @@ def test_edge_contact_and_tilted_cube(po):
     assert _contacts(d)[0] == 2
 
 
-def test_rest_height_matches_model_prediction_not_keyframe(po):
+def _rest_penetration(po, rules=None):
     tab, om, d = _scene(po, [-0.05, 0.0, 0.21])
+    if rules:
+        r = np.zeros(8, dtype=np.int32)
+        for k, v in rules.items(): r[k] = v
+        om._set_i("rule", r)
     d.step(1500)
-    pen = 0.21 - d.qpos[14]
     assert abs(d.qvel[14]) < 1e-10 and np.abs(d.qvel[12:18]).max() < 1e-9
-    # analytic: 4 contacts x 6 rows, D = 1 / (2 mu^2 R), R = (1 - imp) / imp * tran (1 + mu^2), aref = K imp pen
+    return 0.21 - d.qpos[14]
+
+
+def test_rest_height_is_the_closed_form_of_the_restated_rules(po):
+    """The settled cube sits where the restated rules say: m g = 4 contacts x 6 pyramid edges x D K imp pen with
+    D = 1 / (2 mu^2 R), R = (1 - imp) / imp * tran (1 + mu^2) (all [RECALL])."""
+    pen = _rest_penetration(po)
     K, imp_d0, imp_d1, width = 9551.195, 0.9495, 0.9745, 0.001
     def residual(p):
         x = p / width; imp = imp_d0 + 2 * x * x * (imp_d1 - imp_d0)
@@ -73,7 +82,23 @@ def test_rest_height_matches_model_prediction_not_keyframe(po):
     for _ in range(80):
         mid = 0.5 * (lo + hi); lo, hi = (mid, hi) if residual(mid) < 0 else (lo, mid)
     assert abs(pen - lo) < 2e-9
-    assert 9.4e-6 < pen < 9.8e-6                      # the keyframes say 1.9e-5: unpinned [RECALL] factor ~2
+
+
+REF_PEN = (1.85e-5, 1.95e-5)      # both keyframes store z = 0.209981 (mycobot280.xml:6, mycobot280_mocap.xml:7)
+
+
+@pytest.mark.xfail(strict=True, reason="known answer NOT reproduced: the restated [RECALL] contact rules give 9.59e-6, the reference's "
+                   "keyframes 1.9e-5 (2x softer); oracle/RULE_STUDY.md lists the single-rule changes that would close it, none of "
+                   "which the recalled MuJoCo source supports")
+def test_rest_height_reference_keyframe(po):
+    pen = _rest_penetration(po)
+    assert REF_PEN[0] <= pen <= REF_PEN[1]
+
+
+def test_rest_height_candidate_rule_reproduces_the_keyframe(po):
+    """oracle/RULE_STUDY.md, K1: of the enumerated constraint-rule variants exactly one lands in the keyframes' window."""
+    hits = [(r2, r3) for r2 in (0, 1) for r3 in (0, 1, 2) if REF_PEN[0] <= _rest_penetration(po, {2: r2, 3: r3}) <= REF_PEN[1]]
+    assert hits == [(0, 2)]
 
 
 def test_friction_holds_then_slides(po):

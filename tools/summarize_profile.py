@@ -1,16 +1,19 @@
 #!/usr/bin/env python3
-"""Condense the rocprofv3 outputs of tools/profile_r.sh into profiles/<tag>_summary.{json,md} and profiles/pmc_latest.json.
+"""Condense the rocprofv3 outputs of tools/profile_case.sh into profiles/<tag>/summary_<case>.json and merge the counter
+figures into profiles/pmc_latest.json (keyed by bench.py case name).     python tools/summarize_profile.py <tag> <case>
 
 FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE under-reports wide coalesced reads by exactly 2x
 (MI355X_MICROARCH.md, HBM section), so read bytes are reported both raw and x2-corrected.
 """
 import csv, glob, json, os, statistics, sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
-task = sys.argv[2] if len(sys.argv) > 2 else "reach"        # reach | pnp
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+case = sys.argv[2] if len(sys.argv) > 2 else "reach-joint"   # a bench.py case name
+task = case.split("-")[0]                                     # reach | pnp
+ctrl_id = {"joint": 0, "IK": 1, "mocap": 2}[case.split("-")[1]]
 root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
-src = os.path.join(root, "gpurun_out", tag)
-KERNEL = "step_reach_kernel<0" if task == "reach" else "step_pnp_kernel<0"      # joint controller; any variant (<0, true> = two-wave)
+src = os.path.join(root, "gpurun_out", tag, case)
+KERNEL = ("step_reach_kernel<%d" if task == "reach" else "step_pnp_kernel<%d") % ctrl_id      # any variant (<0, true> = multi-wave)
 LANES = 64 if task == "reach" else 32           # active lanes per wave (PNP_LANES)
 ALGO_BYTES = 939 if task == "reach" else 1363
 
@@ -61,12 +64,22 @@ if "SQ_INSTS_VALU_FMA_F64" in c:
     summary["f64"] = {"flops_per_launch": flops, "flops_per_env_step": flops / n_envs,
                       "fma": c["SQ_INSTS_VALU_FMA_F64"], "add": c.get("SQ_INSTS_VALU_ADD_F64", 0),
                       "mul": c.get("SQ_INSTS_VALU_MUL_F64", 0), "trans": c.get("SQ_INSTS_VALU_TRANS_F64", 0)}
-os.makedirs(os.path.join(root, "profiles"), exist_ok=True)
-json.dump(summary, open(os.path.join(root, "profiles", f"{tag}_summary.json"), "w"), indent=1)
+try:
+    summary["bench_line"] = json.loads(open(os.path.join(src, "bench.json")).read().strip().splitlines()[-1])
+except Exception:
+    pass
+os.makedirs(os.path.join(root, "profiles", tag), exist_ok=True)
+json.dump(summary, open(os.path.join(root, "profiles", tag, f"summary_{case}.json"), "w"), indent=1)
+for f in glob.glob(os.path.join(src, "stats/*/*_kernel_stats.csv")):
+    import shutil; shutil.copy(f, os.path.join(root, "profiles", tag, f"kernel_stats_{case}.csv"))
 if "hbm" in summary:
-    name = "pmc_latest.json" if task == "reach" else "pmc_latest_pnp.json"
-    json.dump({"task": task, "controller": "joint", "n_envs": n_envs, "hbm_bytes_per_launch": summary["hbm"]["bytes_per_launch_corrected"],
-               "f64_flops_per_launch": flops,
-               "note": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH_SIZE x2 (gfx950), tag {tag}"},
-              open(os.path.join(root, "profiles", name), "w"), indent=1)
+    path = os.path.join(root, "profiles", "pmc_latest.json")
+    allc = {"cases": {}}
+    if os.path.exists(path):
+        old = json.load(open(path))
+        if "cases" in old: allc = old
+    allc["cases"][case] = {"n_envs": n_envs, "hbm_bytes_per_launch": summary["hbm"]["bytes_per_launch_corrected"],
+                           "f64_flops_per_launch": flops, "kernel_avg_us": summary["kernel_trace"]["avg_us"],
+                           "note": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH_SIZE x2 (gfx950), tag {tag}"}
+    json.dump(allc, open(path, "w"), indent=1)
 print(json.dumps(summary, indent=1))
