@@ -81,7 +81,21 @@ def cpu_info():
         usable = len(os.sched_getaffinity(0))
     except AttributeError:
         usable = os.cpu_count() or 1
-    return {"nproc": os.cpu_count() or 1, "usable_cores": usable, "cpu_model": model}
+    quota = None                         # the box's CPU share is a cgroup bandwidth quota, invisible to the affinity mask
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:               # cgroup v2: "<quota> <period>" or "max <period>"
+            q, per = f.read().split()
+            if q != "max": quota = int(q) / int(per)
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f: q = int(f.read())
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f: per = int(f.read())
+            if q > 0: quota = q / per
+        except (OSError, ValueError):
+            pass
+    if quota is not None:
+        usable = max(1, min(usable, int(quota + 0.5)))
+    return {"nproc": os.cpu_count() or 1, "usable_cores": usable, "cgroup_cpu_quota": quota, "cpu_model": model}
 
 
 def cpu_baseline(controller: str):
@@ -104,7 +118,7 @@ def cpu_baseline(controller: str):
         dt = time.perf_counter() - t0
         return n_envs * steps / dt, dt
 
-    cores = info["usable_cores"]
+    cores = min(info["usable_cores"], 16)       # a one-GPU box's CPU share is 16 cores, whatever the affinity mask says (256 on the pool's hosts)
     v1, dt1 = timed(512, 60, 1)
     vn, dtn = timed(8192, 60, cores)
     return {"value": vn, "unit": "env-steps/s", "cores": cores, "kind": "port",

@@ -62,8 +62,9 @@ typedef struct mcg_model {
   double site_eef[3];               /* EEF site in the link6 frame */
   /* PickAndPlace only */
   double cube_half[3], table_pos[3], table_half[3], pad_box[2][6];
-  double contact_par[3][15];        /* table-cube, right pad-cube, left pad-cube: the 10 solver numbers | friction[5] */
-  double contact_diag[3][2];        /* summed body_invweight0 (translational, rotational) */
+  double contact_par[5][15];        /* table-cube, right pad-cube, left pad-cube, table-right pad, table-left pad: the 10 solver
+                                       numbers | friction[5].  The ground plane carries the table's (default) parameters. */
+  double contact_diag[5][2];        /* summed body_invweight0 (translational, rotational) of the pair */
   double geom_friction0[3];         /* sliding friction of the table, pad and cube geoms (re-mixed under domain randomisation) */
   /* mocap variant only (mycobot280_mocap.xml): weld between the mocap body and gripper_tcp */
   double base_quat[4];              /* orientation of the arm's base body: start of the xquat chain */

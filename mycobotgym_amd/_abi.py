@@ -41,8 +41,8 @@ class McgModel(C.Structure):
         ("act_forcerange", (d * 2) * 7), ("tendon_coef", d * 2),
         ("site_eef", d * 3),
         ("cube_half", d * 3), ("table_pos", d * 3), ("table_half", d * 3), ("pad_box", (d * 6) * 2),
-        ("contact_par", (d * 15) * 3),
-        ("contact_diag", (d * 2) * 3),
+        ("contact_par", (d * 15) * 5),
+        ("contact_diag", (d * 2) * 5),
         ("geom_friction0", d * 3),
         ("base_quat", d * 4), ("weld_on", d), ("weld_par", d * 10), ("weld_diag", d), ("weld_anchor", d * 3),
         ("weld_relpos", d * 3), ("weld_relquat", d * 4), ("weld_torquescale", d),

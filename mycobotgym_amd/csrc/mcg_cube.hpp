@@ -26,7 +26,10 @@ constexpr int LDS_WJ = LDS_ACT + MAXCON;                    // world axis + anch
 constexpr int PNP_SLOTS = LDS_WJ + 60;
 typedef LaneScratchT<PNP_LANES> PnpScratch;
 
-enum { PAIR_TABLE_CUBE = 0, PAIR_PADR_CUBE = 1, PAIR_PADL_CUBE = 2 };   // rows of mcg_model.contact_par / contact_diag
+// rows of mcg_model.contact_par / contact_diag.  The ground plane carries the table's parameters (both are default geoms).
+// TABLE_PAD*: a finger pad on the table top or on the ground (mycobot280_main.xml:81,87-88,195-199,222-225): rows in the robot's
+// dofs only; they route the sub-step through the coupled solver like the pad-cube contacts do.
+enum { PAIR_TABLE_CUBE = 0, PAIR_PADR_CUBE = 1, PAIR_PADL_CUBE = 2, PAIR_TABLE_PADR = 3, PAIR_TABLE_PADL = 4 };
 
 struct Cube {
   real pos[3], quat[4], vel[6], warm[6];     // vel = world linear velocity, body-frame angular velocity (MuJoCo free joint)
@@ -247,8 +250,8 @@ struct CubeSys {
   unsigned long long pm_bits;                  // the model pointer's bits, for stages reached through the robot's hook
   MCG_DEV CubeSys(const LS s_, const Cube& c, const real* d) : S(s_), Cb(c), pm_bits(0) { dr[0] = d[0]; dr[1] = d[1]; }
   real h, Rc[9], Md[6], damp[6], fs[6];
-  real B_tc, B_pc, mu_tc[3], mu_pc[3];
-  int ncon; bool any_pad, solved, touch[2];    // touch: this forward pass has a right / left pad-cube contact
+  real B_tc, B_pc, B_tp, mu_tc[3], mu_pc[3], mu_tp[3];
+  int ncon; bool any_pad, solved, touch[2];    // touch: this forward pass has a right / left pad-cube contact; any_pad: any pad contact
   real a_c[6];
 
   // ------------------------------------------------------------------------------------------------- prepare
@@ -272,7 +275,8 @@ struct CubeSys {
     const real ft = Q->geom_friction0[0], fp = Q->geom_friction0[1] * dr[1], fcb = Q->geom_friction0[2] * dr[1];
     mu_tc[0] = mu_tc[1] = fmax(ft, fcb); mu_tc[2] = Q->contact_par[PAIR_TABLE_CUBE][12];
     mu_pc[0] = mu_pc[1] = fmax(fp, fcb); mu_pc[2] = Q->contact_par[PAIR_PADR_CUBE][12];
-    B_tc = Q->contact_par[PAIR_TABLE_CUBE][1]; B_pc = Q->contact_par[PAIR_PADR_CUBE][1];
+    mu_tp[0] = mu_tp[1] = fmax(ft, fp); mu_tp[2] = Q->contact_par[PAIR_TABLE_PADR][12];
+    B_tc = Q->contact_par[PAIR_TABLE_CUBE][1]; B_pc = Q->contact_par[PAIR_PADR_CUBE][1]; B_tp = Q->contact_par[PAIR_TABLE_PADR][1];
   }
 
   MCG_DEV ModelPtr model() const {                // wave-uniform pointer rebuilt as a scalar
@@ -280,12 +284,12 @@ struct CubeSys {
     return (ModelPtr)(((unsigned long long)hi << 32) | lo);
   }
   // contacts, joint frames and per-contact solver numbers are already in LDS (the caller ran prepare()): take them over
-  MCG_DEV void adopt(ModelPtr Pm, int ncon_, bool touch0, bool touch1) {
+  MCG_DEV void adopt(ModelPtr Pm, int ncon_, bool touch0, bool touch1, bool any_pad_) {
     pm_bits = (unsigned long long)Pm;
     derive(Pm);
     solved = false;
     _Pragma("unroll") for (int k = 0; k < 6; k++) a_c[k] = Cb.warm[k];
-    ncon = ncon_; touch[0] = touch0; touch[1] = touch1; any_pad = touch0 || touch1;
+    ncon = ncon_; touch[0] = touch0; touch[1] = touch1; any_pad = any_pad_;      // any_pad also covers table / ground - pad contacts
   }
   MCG_DEV void prepare(ModelPtr Pm, const real* qr) {
     pm_bits = (unsigned long long)Pm;
@@ -299,23 +303,19 @@ struct CubeSys {
     solved = false;
     _Pragma("unroll") for (int k = 0; k < 6; k++) a_c[k] = Cb.warm[k];
 
-    // ---- P4 collision, in the oracle's pair order: ground-cube, table-cube, right pad-cube, left pad-cube
+    // ---- P4 collision over the primitive geoms, in the oracle's pair order (the cap of MAXCON contacts then cuts the same tail):
+    // ground-pads, ground-cube, table-pads, table-cube, right pad-cube, left pad-cube
     ContactList<LS> CL{S, 0};
     real hc[3]; ldc<3>(Q->cube_half, hc);
-    if (__any(Cb.pos[2] < 0.05)) {
-      const bool low = Cb.pos[2] < 0.05;
-      const real far[3] = {Cb.pos[0], Cb.pos[1], low ? Cb.pos[2] : 1.0};
-      ground_box(CL, far, Rc, hc, PAIR_TABLE_CUBE);
-    }
-    {
-      real tp[3], th[3]; ldc<3>(Q->table_pos, tp); ldc<3>(Q->table_half, th);
-      const real Rt[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-      const real dx = Cb.pos[0] - tp[0], dy = Cb.pos[1] - tp[1], dz = Cb.pos[2] - tp[2];
-      const real rs = sqrt(dot3(th, th)) + sqrt(dot3(hc, hc));
-      const bool near = dx*dx + dy*dy + dz*dz <= rs*rs;
-      if (__any(near)) box_box(CL, near, tp, Rt, th, Cb.pos, Rc, hc, PAIR_TABLE_CUBE);
-    }
+    real tp[3], th[3]; ldc<3>(Q->table_pos, tp); ldc<3>(Q->table_half, th);
+    any_pad = false; touch[0] = touch[1] = false;
     // world frames of the arm joints and of the two gear / finger joints (mj_kinematics for the pads' chain)
+    real Rs[2][9], pc[2][3], ph[2][3];
+    _Pragma("unroll") for (int sd = 0; sd < 2; sd++) {     // defined values for lanes / waves whose pads are not posed
+      _Pragma("unroll") for (int k = 0; k < 9; k++) Rs[sd][k] = (k % 4 == 0) ? 1.0 : 0.0;
+      pc[sd][0] = pc[sd][1] = 0.0; pc[sd][2] = 1.0; ph[sd][0] = ph[sd][1] = ph[sd][2] = 0.0;
+    }
+    bool reach, padlive;
     {
       const TrigC T = load_trig();
       real R[9], p[3];
@@ -333,28 +333,68 @@ struct CubeSys {
       };
       static_for<6>([&](auto I) { constexpr int i = I; real r[3]; ldc<3>(Q->body[i].r, r); joint(i, AXK[i], AXS[i], r, qr[i], R, p); });
       const real dxe = p[0] - Cb.pos[0], dye = p[1] - Cb.pos[1], dze = p[2] - Cb.pos[2];
-      const bool reach = dxe*dxe + dye*dye + dze*dze < 0.2 * 0.2;      // link6 origin within 20 cm of the cube
-      any_pad = false; touch[0] = touch[1] = false;
-      if (__any(reach)) {
+      reach = dxe*dxe + dye*dye + dze*dze < 0.2 * 0.2;                  // link6 origin within 20 cm of the cube
+      // a pad's far corner is at most 0.16 m from the link6 origin: pads can only touch the table / the ground from within 0.17 m
+      real dtab = 0;
+      _Pragma("unroll") for (int k = 0; k < 3; k++) { const real e = fmax(fabs(p[k] - tp[k]) - th[k], 0.0); dtab = fma(e, e, dtab); }
+      padlive = reach || dtab < 0.17 * 0.17 || p[2] < 0.17;
+      if (__any(padlive)) {
         static_for<2>([&](auto Sd) {
           constexpr int sd = Sd; constexpr int g = 6 + 2 * sd, f = 7 + 2 * sd;
-          real Rs[9], ps[3];
-          _Pragma("unroll") for (int k = 0; k < 9; k++) Rs[k] = R[k];
+          real ps[3];
+          _Pragma("unroll") for (int k = 0; k < 9; k++) Rs[sd][k] = R[k];
           _Pragma("unroll") for (int k = 0; k < 3; k++) ps[k] = p[k];
-          real r[3]; ldc<3>(Q->body[g].r, r); joint(g, 1, AXS[g], r, qr[g], Rs, ps);
-          ldc<3>(Q->body[f].r, r); joint(f, 1, AXS[f], r, qr[f], Rs, ps);
+          real r[3]; ldc<3>(Q->body[g].r, r); joint(g, 1, AXS[g], r, qr[g], Rs[sd], ps);
+          ldc<3>(Q->body[f].r, r); joint(f, 1, AXS[f], r, qr[f], Rs[sd], ps);
           real pb[6]; ldc<6>(Q->pad_box[sd], pb);
-          real pc[3];
-          _Pragma("unroll") for (int k = 0; k < 3; k++) pc[k] = ps[k] + Rs[3*k]*pb[0] + Rs[3*k+1]*pb[1] + Rs[3*k+2]*pb[2];
-          const real dx = Cb.pos[0] - pc[0], dy = Cb.pos[1] - pc[1], dz = Cb.pos[2] - pc[2];
-          const real rs = sqrt(pb[3]*pb[3] + pb[4]*pb[4] + pb[5]*pb[5]) + sqrt(dot3(hc, hc));
-          const bool near = reach && (dx*dx + dy*dy + dz*dz <= rs*rs);
-          const int before = CL.n;
-          if (__any(near)) box_box(CL, near, pc, Rs, pb + 3, Cb.pos, Rc, hc, PAIR_PADR_CUBE + sd);
-          touch[sd] = CL.n > before;
-          any_pad = any_pad || touch[sd];
+          _Pragma("unroll") for (int k = 0; k < 3; k++) { pc[sd][k] = ps[k] + Rs[sd][3*k]*pb[0] + Rs[sd][3*k+1]*pb[1] + Rs[sd][3*k+2]*pb[2]; ph[sd][k] = pb[3 + k]; }
         });
       }
+    }
+    // ground plane: pads, cube
+    if (__any(padlive && (pc[0][2] < 0.02 || pc[1][2] < 0.02))) {
+      static_for<2>([&](auto Sd) { constexpr int sd = Sd;
+        const bool low = padlive && pc[sd][2] < 0.02;
+        const real far[3] = {pc[sd][0], pc[sd][1], low ? pc[sd][2] : 1.0};
+        const int before = CL.n;
+        ground_box(CL, far, Rs[sd], ph[sd], PAIR_TABLE_PADR + sd);
+        any_pad = any_pad || (CL.n > before); });
+    }
+    if (__any(Cb.pos[2] < 0.05)) {
+      const bool low = Cb.pos[2] < 0.05;
+      const real far[3] = {Cb.pos[0], Cb.pos[1], low ? Cb.pos[2] : 1.0};
+      ground_box(CL, far, Rc, hc, PAIR_TABLE_CUBE);
+    }
+    // table: pads, cube.  The table is a static axis-aligned box: its three face axes are separating axes of the SAT, so
+    // "the pad's extent along one of them clears the table" skips the pair with the result the full test would give.
+    const real Rt[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    static_for<2>([&](auto Sd) { constexpr int sd = Sd;
+      bool near = padlive;
+      _Pragma("unroll") for (int k = 0; k < 3; k++) {
+        const real ext = fabs(Rs[sd][3*k]) * ph[sd][0] + fabs(Rs[sd][3*k+1]) * ph[sd][1] + fabs(Rs[sd][3*k+2]) * ph[sd][2];
+        near = near && !(fabs(pc[sd][k] - tp[k]) - (th[k] + ext) > 0);
+      }
+      if (__any(near)) {
+        const int before = CL.n;
+        box_box(CL, near, tp, Rt, th, pc[sd], Rs[sd], ph[sd], PAIR_TABLE_PADR + sd);
+        any_pad = any_pad || (CL.n > before);
+      } });
+    {
+      const real dx = Cb.pos[0] - tp[0], dy = Cb.pos[1] - tp[1], dz = Cb.pos[2] - tp[2];
+      const real rs = sqrt(dot3(th, th)) + sqrt(dot3(hc, hc));
+      const bool near = dx*dx + dy*dy + dz*dz <= rs*rs;
+      if (__any(near)) box_box(CL, near, tp, Rt, th, Cb.pos, Rc, hc, PAIR_TABLE_CUBE);
+    }
+    // pads - cube
+    if (__any(reach)) {
+      static_for<2>([&](auto Sd) { constexpr int sd = Sd;
+        const real dx = Cb.pos[0] - pc[sd][0], dy = Cb.pos[1] - pc[sd][1], dz = Cb.pos[2] - pc[sd][2];
+        const real rs = sqrt(dot3(ph[sd], ph[sd])) + sqrt(dot3(hc, hc));
+        const bool near = reach && (dx*dx + dy*dy + dz*dz <= rs*rs);
+        const int before = CL.n;
+        if (__any(near)) box_box(CL, near, pc[sd], Rs[sd], ph[sd], Cb.pos, Rc, hc, PAIR_PADR_CUBE + sd);
+        touch[sd] = CL.n > before;
+        any_pad = any_pad || touch[sd]; });
     }
     ncon = CL.n;
 #ifdef MCG_STAGE_CLOCKS
@@ -372,18 +412,25 @@ struct CubeSys {
     // ---- P5 per-contact solver numbers (the 6 pyramid rows of a contact share D and the position term)
     real par_t[15], par_p[15];
     ldc<15>(Q->contact_par[PAIR_TABLE_CUBE], par_t); ldc<15>(Q->contact_par[PAIR_PADR_CUBE], par_p);
+    const bool any_tp = __any(any_pad);      // wave-uniform: table / ground - pad contacts may exist
     for (int c = 0; __any(c < ncon); c++) {
       const int b = LDS_CON + c * CON_STRIDE;
       const real dist = S.ld(b + 12);
       const int type = sel((c < ncon), (int)S.ld(b + 15), 0);
-      const bool pad = type != PAIR_TABLE_CUBE;
-      const real imp = sel(pad, impedance(par_p, dist), impedance(par_t, dist));
-      const real tran = pad ? (type == PAIR_PADR_CUBE ? Q->contact_diag[PAIR_PADR_CUBE][0] : Q->contact_diag[PAIR_PADL_CUBE][0])
-                            : Q->contact_diag[PAIR_TABLE_CUBE][0];
-      const real m0 = sel(pad, mu_pc[0], mu_tc[0]);
+      const bool padcube = type == PAIR_PADR_CUBE || type == PAIR_PADL_CUBE, tabpad = type >= PAIR_TABLE_PADR;
+      real imp = sel(padcube, impedance(par_p, dist), impedance(par_t, dist));
+      real kk = sel(padcube, par_p[0], par_t[0]);
+      real m0 = sel(padcube, mu_pc[0], mu_tc[0]);
+      real tran = sel(type == PAIR_PADR_CUBE, Q->contact_diag[PAIR_PADR_CUBE][0],
+                      sel(type == PAIR_PADL_CUBE, Q->contact_diag[PAIR_PADL_CUBE][0], Q->contact_diag[PAIR_TABLE_CUBE][0]));
+      if (any_tp) {
+        real par_tp[10]; ldc<10>(Q->contact_par[PAIR_TABLE_PADR], par_tp);
+        imp = sel(tabpad, impedance(par_tp, dist), imp); kk = sel(tabpad, par_tp[0], kk); m0 = sel(tabpad, mu_tp[0], m0);
+        tran = sel(type == PAIR_TABLE_PADR, Q->contact_diag[PAIR_TABLE_PADR][0], sel(type == PAIR_TABLE_PADL, Q->contact_diag[PAIR_TABLE_PADL][0], tran));
+      }
       const real Rn = fmax(MINVAL, (1 - imp) * tran * (1 + m0*m0) / imp);
       const real Rpy = fmax(MINVAL, 2 * m0*m0 * Rn);
-      if (c < ncon) { S.st(b + 13, 1.0 / Rpy); S.st(b + 14, (pad ? par_p[0] : par_t[0]) * imp * dist); }
+      if (c < ncon) { S.st(b + 13, 1.0 / Rpy); S.st(b + 14, kk * imp * dist); }
     }
   }
 
@@ -568,13 +615,23 @@ struct CubeSys {
     K.type = sel((c < ncon), (int)S.ld(b + 15), 0);
     K.D = sel((c < ncon), S.ld(b + 13), 0.0); K.kterm = S.ld(b + 14);
     K.mask = sel((c < ncon), (int)S.ld(LDS_ACT + c), 0);
-    K.pad = K.type != PAIR_TABLE_CUBE;
-    K.side = sel(K.type == PAIR_PADL_CUBE, 1, 0);
+    K.pad = K.type != PAIR_TABLE_CUBE;                                   // the contact has rows in the robot's dofs
+    const bool tabpad = K.type >= PAIR_TABLE_PADR;                       // ... and none in the cube's (table / ground - pad)
+    K.side = sel((K.type == PAIR_PADL_CUBE || K.type == PAIR_TABLE_PADL), 1, 0);
     rows_cube(c, K.RC);
     rows_pad(c, K.side, K.RP);
-    if (!K.pad) _Pragma("unroll") for (int j = 0; j < 8; j++) { K.RP.Jn[j] = 0; K.RP.J1[j] = 0; K.RP.J2[j] = 0; K.RP.Jt[j] = 0; }
-    _Pragma("unroll") for (int k = 0; k < 3; k++) K.mu[k] = sel(K.pad, mu_pc[k], mu_tc[k]);
-    K.Bc = sel(K.pad, B_pc, B_tc);
+    // pad-cube: the pad is geom1 (rows_pad carries that minus sign); table-pad: the pad is geom2, its rows enter with +
+    // (selects, not products with 0: the joint-frame slots of a side whose pads were not posed hold stale LDS contents)
+    _Pragma("unroll") for (int j = 0; j < 8; j++) {
+      K.RP.Jn[j] = sel(K.pad, sel(tabpad, -K.RP.Jn[j], K.RP.Jn[j]), 0.0); K.RP.J1[j] = sel(K.pad, sel(tabpad, -K.RP.J1[j], K.RP.J1[j]), 0.0);
+      K.RP.J2[j] = sel(K.pad, sel(tabpad, -K.RP.J2[j], K.RP.J2[j]), 0.0); K.RP.Jt[j] = sel(K.pad, sel(tabpad, -K.RP.Jt[j], K.RP.Jt[j]), 0.0);
+    }
+    _Pragma("unroll") for (int d = 0; d < 6; d++) {
+      K.RC.Jn[d] = sel(tabpad, 0.0, K.RC.Jn[d]); K.RC.J1[d] = sel(tabpad, 0.0, K.RC.J1[d]);
+      K.RC.J2[d] = sel(tabpad, 0.0, K.RC.J2[d]); K.RC.Jt[d] = sel(tabpad, 0.0, K.RC.Jt[d]);
+    }
+    _Pragma("unroll") for (int k = 0; k < 3; k++) K.mu[k] = sel(tabpad, mu_tp[k], sel(K.pad, mu_pc[k], mu_tc[k]));
+    K.Bc = sel(tabpad, B_tp, sel(K.pad, B_pc, B_tc));
   }
   // the four basis dot products of a contact with a (cube 6-vector, robot 8-vector of the contact's side)
   MCG_DEV static void bdots(const Coupled& K, const real* vc, const real* v8, real* o) {

@@ -401,7 +401,7 @@ MCG_DEV void hide_object(real* obs, real* ag) {
 // large.  It lives out of line, on a COPY of the env, so that its code and its live ranges stay out of the hot path's
 // register allocation (inlined, it doubled the cost of the uncoupled robot pipeline) and the env struct itself never
 // has its address taken.  The collision results stay where they are (LDS); the cheap derived numbers are recomputed.
-template <class WLD> struct CoupledIO { EnvP E; WLD W; int ncon; bool touch[2]; };
+template <class WLD> struct CoupledIO { EnvP E; WLD W; int ncon; bool touch[2], any_pad; };
 template <class WLD>
 __device__ __noinline__ void pnp_substep_coupled(unsigned long long model_bits, CoupledIO<WLD>* io, unsigned lds_column) {
   const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)model_bits), hi = __builtin_amdgcn_readfirstlane((unsigned)(model_bits >> 32));
@@ -409,7 +409,7 @@ __device__ __noinline__ void pnp_substep_coupled(unsigned long long model_bits, 
   const PnpScratch MS((LdsPtr)(uintptr_t)lds_column);
   EnvP E = io->E;
   CubeSys<PnpScratch> CS(MS, E.Cb, E.dr);       // E.Cb holds the quaternion the caller's collision pass normalised
-  CS.adopt(P, io->ncon, io->touch[0], io->touch[1]);
+  CS.adopt(P, io->ncon, io->touch[0], io->touch[1], io->any_pad);
   const WLD W = io->W;
   robot_substep<PnpScratch, CubeSys<PnpScratch>, WLD>(P, E.R, E.qlag6, MS, &CS, &W);     // its hook runs the coupled solve
   CS.finish(E.qlag7);
@@ -427,7 +427,7 @@ MCG_DEV void pnp_substep(ModelPtr P, EnvP& E, const PnpScratch MS, const WLD& W)
   MCG_TICK(ST_COLLIDE);
   E.touch = CS.touch[0] && CS.touch[1];        // contacts of this forward pass: what check_contact sees after the step
   if (__any(CS.any_pad)) {                     // wave-uniform
-    CoupledIO<WLD> io; io.E = E; io.E.Cb = CS.Cb; io.W = W; io.ncon = CS.ncon; io.touch[0] = CS.touch[0]; io.touch[1] = CS.touch[1];
+    CoupledIO<WLD> io; io.E = E; io.E.Cb = CS.Cb; io.W = W; io.ncon = CS.ncon; io.touch[0] = CS.touch[0]; io.touch[1] = CS.touch[1]; io.any_pad = CS.any_pad;
     pnp_substep_coupled<WLD>((unsigned long long)P, &io, (unsigned)(uintptr_t)MS.base);
     const bool touch = E.touch;
     E = io.E; E.touch = touch;
@@ -536,7 +536,7 @@ MCG_DEV void pnp_substep_robot(ModelPtr P, EnvP& E, const PnpScratch MS, const W
   if (coupled) {
     CoupledIO<WLD> io; io.E = E; io.W = W;
     cube_from_lds(MS, io.E.Cb);
-    io.ncon = (int)MS.ld(XCH_NCON); io.touch[0] = MS.ld(XCH_T0) != 0.0; io.touch[1] = MS.ld(XCH_T1) != 0.0;
+    io.ncon = (int)MS.ld(XCH_NCON); io.touch[0] = MS.ld(XCH_T0) != 0.0; io.touch[1] = MS.ld(XCH_T1) != 0.0; io.any_pad = MS.ld(XCH_FLAG) != 0.0;
     pnp_substep_coupled<WLD>((unsigned long long)P, &io, (unsigned)(uintptr_t)MS.base);
     E.R = io.E.R;
     for (int k = 0; k < 6; k++) E.qlag6[k] = io.E.qlag6[k];

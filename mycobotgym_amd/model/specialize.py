@@ -227,13 +227,14 @@ def specialize(m: dict) -> dict:
             pads.append(np.concatenate([p + np.asarray(m["geom_pos"][g]), np.asarray(m["geom_size"][g])]))
         out["pad_box"] = np.array(pads)      # centre (finger frame) | half sizes
         cp = []
-        for (ga, gb) in ((gt, gc), (gr, gc), (gl, gc)):
+        for (ga, gb) in ((gt, gc), (gr, gc), (gl, gc), (gt, gr), (gt, gl)):
             condim, fri, solref, solimp = mix_contact(m, ga, gb)
             assert condim == 4
             cp.append(np.concatenate([_solparams(solref, solimp, h), fri]))
-        out["contact_par"] = np.array(cp)    # rows: table-cube, right pad-cube, left pad-cube
+        out["contact_par"] = np.array(cp)    # rows: table-cube, right pad-cube, left pad-cube, table-right pad, table-left pad
         bt = lambda g: biw[m["geom_body"][g]]
-        out["contact_diag"] = np.array([[bt(ga)[0] + bt(gc)[0], bt(ga)[1] + bt(gc)[1]] for ga in (gt, gr, gl)])
+        out["contact_diag"] = np.array([[bt(ga)[0] + bt(gb)[0], bt(ga)[1] + bt(gb)[1]]
+                                        for (ga, gb) in ((gt, gc), (gr, gc), (gl, gc), (gt, gr), (gt, gl))])
         out["cube_invweight"] = np.array([diw[12], diw[15]])
         out["geom_friction0"] = np.array([m["geom_friction"][gt][0], m["geom_friction"][gr][0], m["geom_friction"][gc][0]])
         # structural facts the cube kernels rely on: CoM at the body origin, principal axes = body axes

@@ -219,7 +219,8 @@ void mco_collision(const mco_model* m, mco_data* d) {
   for (int g1 = 0; g1 < m->ngeom; g1++) for (int g2 = g1 + 1; g2 < m->ngeom; g2++) {
     int t1 = m->geom_type[g1], t2 = m->geom_type[g2];
     if (t1 == MCO_GEOM_MESH || t2 == MCO_GEOM_MESH) continue;           /* convex-mesh collision: out of scope */
-    if (m->collide_scope_geom >= 0 && g1 != m->collide_scope_geom && g2 != m->collide_scope_geom) continue;
+    if (m->collide_scope_geom >= 0 && g1 != m->collide_scope_geom && g2 != m->collide_scope_geom
+        && !(m->collide_extra[g1] && m->collide_extra[g2] && m->collide_extra[g1] != m->collide_extra[g2])) continue;
     if (filtered(m, g1, g2)) continue;
     if (t1 == MCO_GEOM_PLANE && t2 == MCO_GEOM_BOX) plane_box(m, d, g1, g2);
     else if (t1 == MCO_GEOM_BOX && t2 == MCO_GEOM_BOX) {

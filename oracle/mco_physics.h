@@ -51,7 +51,8 @@ typedef struct mco_model {
   int nbody, njnt, nq, nv, ngeom, nsite, nu, neq, ntendon, nexclude;
   double timestep, gravity[3], meaninertia;
   int enable_contact;            /* 0: collision stage skipped (Reach / free-space configs) */
-  int collide_scope_geom;        /* >= 0: only pairs that involve this geom collide (the build's scoped set: the cube) */
+  int collide_scope_geom;        /* >= 0: only pairs that involve this geom collide (the build's scoped set: the cube) ... */
+  int collide_extra[48];         /* ... plus pairs of one geom flagged 1 (static: ground plane, table) and one flagged 2 (finger pad) */
   /* Study switches (oracle/rule_study.py): alternatives to [RECALL] rules the reference's keyframes can discriminate.
    * All zero = the adopted rule set, which is what the HIP kernels implement and every parity test runs.
    *   rule[0] weld diagApprox   0 one common (translational) weight for the six rows | 1 translational rows 0-2, rotational rows 3-5

@@ -91,6 +91,13 @@ class OracleModel:
         si("nexclude", [len(table["excludes"])])
         si("enable_contact", [int(enable_contact)])
         si("collide_scope_geom", [int(scope_geom)])
+        if scope_geom >= 0:        # the build's scoped set also holds finger pad <-> table / ground plane (box-box, plane-box)
+            extra = [0] * table["ngeom"]
+            for g in range(table["ngeom"]):
+                if table["geom_type"][g] == 7: continue
+                if table["body_weldid"][table["geom_body"][g]] == 0: extra[g] = 1
+                elif table["geom_name"][g] in ("right_finger_layer", "left_finger_layer"): extra[g] = 2
+            si("collide_extra", extra)
         sd("timestep", [table["opt"]["timestep"]]); sd("gravity", table["opt"]["gravity"])
         for k in ("body_parent", "body_rootid", "body_weldid", "body_dofadr", "body_dofnum", "jnt_type", "jnt_body",
                   "jnt_qposadr", "jnt_dofadr", "dof_body", "dof_jnt", "dof_parent", "geom_type", "geom_body",

@@ -142,3 +142,24 @@ def compare_step(envs, ora, actions, keys=("obs", "achieved", "desired", "reward
         err = max(err, float(np.abs(f["observation"].cpu().numpy()[done] - o["final_obs"][done]).max()))
         assert np.array_equal(info["episode"]["l"].cpu().numpy()[done], o["ep_length"][done])
     return err
+
+
+def twin_errors(twin, state, actions, o_ref, prng, eps=1e-14):
+    """The oracle's own sensitivity: a second oracle steps from `state` (the reference's state before its step) with qpos
+    perturbed by +-eps; returns its per-env max abs observation difference from the reference's outputs `o_ref`."""
+    s = dict(state)
+    s["qpos"] = state["qpos"] + eps * np.sign(prng.normal(size=state["qpos"].shape))
+    twin.set_state(**s)
+    ot = twin.step(actions)
+    return np.abs(ot["obs"] - o_ref["obs"]).max(axis=1)
+
+
+def assert_within_oracle_sensitivity(e_hip, e_twin, what="", factor=10.0):
+    """Chaotic env-steps (100 sub-steps of the stiff servos, contact make / break): HIP-vs-oracle error quantiles must not exceed
+    `factor` x the oracle-vs-perturbed-oracle quantiles of the same states."""
+    e_hip, e_twin = np.concatenate(e_hip), np.concatenate(e_twin)
+    q = lambda e: np.array([np.median(e), np.quantile(e, 0.9), np.quantile(e, 0.99)])
+    qh, qt = q(e_hip), q(e_twin)
+    print(f"\n{what} quantiles (median p90 p99 | max): hip-vs-oracle " + " ".join(f"{x:.2e}" for x in qh) + f" | {e_hip.max():.2e};  "
+          "oracle-vs-oracle+1e-14 " + " ".join(f"{x:.2e}" for x in qt) + f" | {e_twin.max():.2e}")
+    assert np.all(qh <= factor * qt + 1e-13), (what, qh, qt)

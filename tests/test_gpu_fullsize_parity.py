@@ -35,7 +35,7 @@ def _actions(rng, n, dim, controller):
 def test_pickandplace_full_size(torch_cuda, controller):
     torch = torch_cuda
     from mycobotgym_amd import MyCobotVecEnv
-    from tests.common import make_oracle
+    from tests.common import make_oracle, twin_errors, assert_within_oracle_sensitivity
     steps = {"joint": 60, "IK": 52, "mocap": 60}[controller]
     probe = 23                                   # the env-step that is also checked against the oracle
     idx = (np.arange(256) * 31).astype(np.int64)             # lanes 0..31 all visited, workgroups spread over the grid
@@ -72,6 +72,7 @@ def test_pickandplace_full_size(torch_cuda, controller):
     ora.set_state(qpos=sub["qpos"][:, idx].T.copy(), qvel=sub["qvel"][:, idx].T.copy(), ctrl=ctrl,
                   warm=sub["warm"][:, idx].T.copy(), qpos_lag=sub["qpos_lag"][:, idx].T.copy(), goal=sub["goal"][:, idx].T.copy(),
                   elapsed=sub["elapsed"][idx].copy(), episode=sub["episode"][idx].copy())
+    state = ora.get_state()
     o = ora.step(acts[probe][idx])
     hip_obs = runs[0][probe][0].cpu().numpy()[idx]
     hip_rew = runs[0][probe][1].cpu().numpy()[idx]
@@ -84,7 +85,10 @@ def test_pickandplace_full_size(torch_cuda, controller):
     print(f"\n[pnp {controller} @8192] env-step {probe} from identical state, {keep.sum()} envs of the stride-31 subset: "
           f"median {np.median(err):.2e} p90 {np.quantile(err, 0.9):.2e} max {err.max():.2e}; contacts per env {sorted(set(ncon))}")
     if controller == "IK":
-        assert np.median(err) < 1e-9 and np.quantile(err, 0.9) < 1e-6
+        twin = make_oracle(256, has_object=True, controller_type=controller, reward_type="dense", seed=5); twin.reset(seed=5)
+        te = twin_errors(twin, state, acts[probe][idx], o, np.random.default_rng(3))
+        assert_within_oracle_sensitivity([err], [te[keep]], "[pnp IK @8192 env-step]")
+        assert np.median(err) < 1e-9
     else:
         assert err.max() < 1e-8
 

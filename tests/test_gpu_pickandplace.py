@@ -29,7 +29,7 @@ def test_reset_bit_exact_with_object(torch_cuda, controller):
     envs.close()
 
 
-def _substep_run(torch, n, steps, prepare=None, seed=5):
+def _substep_run(torch, n, steps, prepare=None, seed=5, hold_pose=False):
     from tests.common import make_pair, sync_oracle_to, step_errors
     kw = dict(has_object=True, controller_type="joint", reward_type="dense", seed=seed, frame_skip=1, max_episode_steps=10 ** 9)
     envs, ora = make_pair(n, **kw)
@@ -42,6 +42,8 @@ def _substep_run(torch, n, steps, prepare=None, seed=5):
     for t in range(steps):
         if t % 20 == 0:
             a = rng.uniform(-1, 1, (n, 7)).astype(np.float32)
+            if hold_pose:        # joint controller: ctrl := action; stay near the prepared pose (clipped to [-1, 1] by the env)
+                a = (ora.get_state()["ctrl"] + 0.05 * rng.normal(size=(n, 7))).astype(np.float32)
         sync_oracle_to(envs, ora)
         e, flags_equal, o = step_errors(envs, ora, a)
         assert flags_equal
@@ -62,6 +64,38 @@ def test_substeps_cube_resting_on_table(torch_cuda):
     assert worst["obs"] < 1e-13 and worst["qpos"] < 1e-12 and worst["qvel"] < 5e-10      # measured 5.6e-16, 1.0e-14, 5.2e-12
 
 
+def test_substeps_finger_pads_on_the_table_and_the_ground(torch_cuda):
+    """Arm poses that press a finger pad onto the table top or onto the ground plane next to the table (box-box / plane-box
+    contacts with rows in the robot's dofs only, mycobot280_main.xml:81,87-88,195-199,222-225), cube resting or being pushed."""
+    from tests.common import load_json
+    from oracle import pyoracle as po
+    tab = load_json("mycobot280")
+    m = po.OracleModel(tab, enable_contact=True, scope_geom=tab["geom_name"].index("object0"))
+    d = po.OracleData(m)
+    rng = np.random.default_rng(0)
+    gn = tab["geom_name"]; pads = (gn.index("right_finger_layer"), gn.index("left_finger_layer"))
+    poses = []
+    while len(poses) < 128:                       # rejection-sample poses with a SHALLOW pad contact (a deep one is a violent state)
+        q = np.array(tab["qpos0"], float)
+        q[:6] = rng.uniform(-2.5, 2.5, 6); q[6] = q[8] = rng.uniform(0, 0.7)
+        d.set_state(qpos=q, qvel=np.zeros(18)); d.forward()
+        n = int(d.get("ncon", (1,), np.int32)[0])
+        if n <= 4: continue
+        dist = d.get("efc_pos", (224,))[7:7 + 6 * n:6]
+        if dist.min() > -2e-3: poses.append(q)
+    poses = np.array(poses)
+
+    def prepare(ora):
+        s = ora.get_state()
+        s["qpos"][:, :12] = poses[:, :12]; s["qpos_lag"] = s["qpos"].copy()
+        s["ctrl"][:, :6] = poses[:, :6]; s["ctrl"][:, 6] = poses[:, 6] / 0.7
+        ora.set_state(**s)
+    worst, ncon = _substep_run(torch_cuda, 128, 200, prepare=prepare, hold_pose=True)
+    print(f"\npads on the table / ground, 200 sub-steps x 128 envs: {worst}, contact counts seen {sorted(ncon)}")
+    assert max(ncon) > 4
+    assert worst["obs"] < 1e-10 and worst["qpos"] < 1e-10 and worst["qvel"] < 1e-6
+
+
 def test_substeps_cube_tumbling_onto_table(torch_cuda):
     """Cubes dropped from 3 cm with random attitude and spin: vertex, edge and face contacts, make/break events."""
     def prepare(ora):
@@ -80,22 +114,27 @@ def test_substeps_cube_tumbling_onto_table(torch_cuda):
 
 
 def test_env_steps_with_object(torch_cuda):
-    from tests.common import make_pair, sync_oracle_to, step_errors
+    from tests.common import make_pair, make_oracle, sync_oracle_to, step_errors, twin_errors, assert_within_oracle_sensitivity
     n = 128
     for controller in ("joint", "IK"):
         envs, ora = make_pair(n, has_object=True, controller_type=controller, reward_type="sparse", seed=2)
-        envs.reset(seed=2); ora.reset(seed=2)
-        rng = np.random.default_rng(8)
-        errs = []
+        twin = make_oracle(n, has_object=True, controller_type=controller, reward_type="sparse", seed=2)
+        envs.reset(seed=2); ora.reset(seed=2); twin.reset(seed=2)
+        rng = np.random.default_rng(8); prng = np.random.default_rng(1)
+        errs, terrs = [], []
         for t in range(55):
             sync_oracle_to(envs, ora)
-            e, flags_equal, o = step_errors(envs, ora, rng.uniform(-1, 1, (n, 7)).astype(np.float32))
+            state = ora.get_state()
+            a = rng.uniform(-1, 1, (n, 7)).astype(np.float32)
+            e, flags_equal, o = step_errors(envs, ora, a)
             assert flags_equal
             errs.append(e)
+            if controller == "IK": terrs.append(twin_errors(twin, state, a, o, prng))
+        if controller == "IK": assert_within_oracle_sensitivity(errs, terrs, "[pnp IK env-step]")
         errs = np.concatenate(errs)
         print(f"\n[{controller}] PickAndPlace env-steps from identical state: median {np.median(errs):.2e} p99 {np.quantile(errs, 0.99):.2e}")
         if controller == "joint": assert np.median(errs) < 1e-13 and errs.max() < 1e-8      # measured: median 9e-16, p99 2e-13
-        else: assert np.median(errs) < 2e-10 and np.quantile(errs, 0.99) < 2e-3              # measured: median 1.4e-12, p99 1.3e-5
+        else: assert np.median(errs) < 2e-10      # measured: median 1.7e-12; the tails (finger pads meeting the table) are bounded above
         envs.close()
 
 
