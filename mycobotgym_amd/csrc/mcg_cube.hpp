@@ -722,7 +722,8 @@ struct CubeSys {
             else { gr[7] += sel(K.side, 0.0, gl); gr[9] += sel(K.side, gl, 0.0); }
             // robot block, lower triangle in the contact's local order (arm 0..5, gear, finger: increasing dof index), and
             // coupling block Cm[dof i][cube d].  All loads of a row first, then all stores: the addresses are per-lane, so
-            // a load behind a store could not be hoisted and every entry would pay the LDS latency alone.
+            // a load behind a store could not be hoisted and every entry would pay the LDS latency alone.  (One ds_add_f64
+            // per entry instead -- no load at all -- measured no faster: the loop is not bound by these round trips.)
             const int slot = (i < 6) ? i : (i == 6 ? gear : fing);
             int kg[i + 1]; real og[i + 1], oc[6];
             static_for<i + 1>([&](auto Jj) { constexpr int j = Jj;

@@ -83,13 +83,14 @@ MCG_DEV void sample_goal(const Cfg& C, int i, int32_t episode, uint32_t draw, re
 }
 
 // reset_model (mycobot.py:207-236), Reach: the object position stays the initial gripper xy.
-// Every lane of the wave computes a fresh episode; it is committed where `doit`.  The rejection loop is
-// wave-uniform (__any) with per-lane selects -- see the compiler hazard note in mcg_dynamics.hpp.
+// The rejection loop is wave-uniform (__any) with per-lane selects -- see the compiler hazard note in mcg_dynamics.hpp -- and
+// runs until the lanes that DO reset have their goal: with desynchronised episodes that is one or two lanes of a wave per step
+// (a quarter of the draws are accepted), not the slowest of 64.
 MCG_DEV void reset_env(const Cfg& C, int i, Env& E, bool doit) {
   const real ox = C.igx[0], oy = C.igx[1];
   real goal[3] = {0, 0, 0};
   uint32_t draw = 0;
-  bool need = true;
+  bool need = doit;
   int tries = 0;
   do {
     real g[3];
@@ -133,13 +134,18 @@ MCG_DEV void observe_reach(const Cfg& C, ModelPtr P, const Env& E, real* obs, re
   obs[8] = E.R.qd[6] * C.dt; obs[9] = E.R.qd[8] * C.dt;
 }
 
-MCG_DEV void load_env(const View& V, int i, Env& E) {
+// The episode bookkeeping (goal, return, counters) is only needed after the sub-steps: the step kernels load it THERE, so that it
+// is not carried -- spilled to scratch and reloaded -- across the whole sub-step loop (scratch lines end up as HBM traffic).
+MCG_DEV void load_robot(const View& V, int i, Env& E) {
   for (int k = 0; k < NB; k++) { E.R.q[k] = V.qpos(k, i); E.R.qd[k] = V.qvel(k, i); E.R.warm[k] = V.warm(k, i); }
   for (int k = 0; k < 7; k++) E.R.ctrl[k] = V.ctrl(k, i);
   for (int k = 0; k < 6; k++) E.qlag6[k] = V.qlag(k, i);
+}
+MCG_DEV void load_episode(const View& V, int i, Env& E) {
   for (int k = 0; k < 3; k++) E.goal[k] = V.goal(k, i);
   E.epret = V.epret(i); E.elapsed = V.elapsed(i); E.episode = V.episode(i); E.eplen = V.eplen(i);
 }
+MCG_DEV void load_env(const View& V, int i, Env& E) { load_robot(V, i, E); load_episode(V, i, E); }
 MCG_DEV void store_env(const View& V, int i, const Env& E) {
   for (int k = 0; k < NB; k++) { V.qpos(k, i) = E.R.q[k]; V.qvel(k, i) = E.R.qd[k]; V.warm(k, i) = E.R.warm[k]; }
   for (int k = 0; k < 7; k++) V.ctrl(k, i) = E.R.ctrl[k];
@@ -193,7 +199,7 @@ __global__ __launch_bounds__(SPLIT ? 192 : 64) void step_reach_kernel(Cfg C, Vie
   }
   MCG_TICK_INIT();
   Env E;
-  load_env(V, i, E);
+  load_robot(V, i, E);
   if constexpr (SPLIT) static_for<NB>([&](auto I) { constexpr int k = I; MS.st(LDS_QB + k, E.R.q[k]); MS.st(LDS_QDB + k, E.R.qd[k]); });   // q(0), qd(0) for the other waves
   MCG_TICK(ST_LOAD);
   float act[8];
@@ -236,6 +242,7 @@ __global__ __launch_bounds__(SPLIT ? 192 : 64) void step_reach_kernel(Cfg C, Vie
   }
 
   guard_robot(E.R, E.qlag6);
+  load_episode(V, i, E);
   if (C.block_gripper) {       // _step_callback (mycobot.py:300-306): finger joints := 0, then mj_forward removes the lag
     E.R.q[7] = 0; E.R.q[9] = 0;
     for (int k = 0; k < 6; k++) E.qlag6[k] = E.R.q[k];
@@ -306,8 +313,10 @@ MCG_DEV void load_envp(const View& V, int i, EnvP& E) {
   for (int k = 0; k < 4; k++) E.Cb.quat[k] = V.qpos(15 + k, i);
   for (int k = 0; k < 6; k++) { E.Cb.vel[k] = V.qvel(12 + k, i); E.Cb.warm[k] = V.warm(12 + k, i); E.qlag6[k] = V.qlag(k, i); }
   for (int k = 0; k < 7; k++) E.qlag7[k] = V.qlag(12 + k, i);
-  for (int k = 0; k < 3; k++) E.goal[k] = V.goal(k, i);
   E.dr[0] = V.dr(0, i); E.dr[1] = V.dr(1, i);
+}
+MCG_DEV void load_episodep(const View& V, int i, EnvP& E) {        // after the sub-steps, like load_episode
+  for (int k = 0; k < 3; k++) E.goal[k] = V.goal(k, i);
   E.epret = V.epret(i); E.elapsed = V.elapsed(i); E.episode = V.episode(i); E.eplen = V.eplen(i);
 }
 MCG_DEV void store_envp(const View& V, int i, const EnvP& E) {
@@ -333,7 +342,7 @@ MCG_DEV void reset_envp(const Cfg& C, int i, EnvP& E, bool doit) {
   }
   real oxy[2] = {C.igx[0], C.igx[1]}, goal[3] = {0, 0, 0};
   uint32_t draw = 0;
-  bool need = !C.hidden; int tries = 0;             // hidden cube (Reach): reset_model places nothing (mycobot.py:216: `if self.has_object`)
+  bool need = doit && !C.hidden; int tries = 0;     // hidden cube (Reach): reset_model places nothing (mycobot.py:216: `if self.has_object`)
   do {                                              // object position (mycobot.py:217-219)
     real g[3]; sample_goal(C, i, E.episode, draw, g);
     const bool rej = sqrt((g[0] - C.igx[0]) * (g[0] - C.igx[0]) + (g[1] - C.igx[1]) * (g[1] - C.igx[1])) < 0.1;
@@ -343,7 +352,7 @@ MCG_DEV void reset_envp(const Cfg& C, int i, EnvP& E, bool doit) {
     tries++;
   } while (__any(need));
   const real cxy[2] = {sel(C.hidden, C.init_qpos[12], oxy[0]), sel(C.hidden, C.init_qpos[13], oxy[1])};
-  need = true; tries = 0;
+  need = doit; tries = 0;
   do {                                              // goal (mycobot.py:231-233)
     real g[3]; sample_goal(C, i, E.episode, draw, g);
     const bool rej = sqrt((g[0] - oxy[0]) * (g[0] - oxy[0]) + (g[1] - oxy[1]) * (g[1] - oxy[1])) < 0.1;
@@ -629,6 +638,7 @@ __global__ __launch_bounds__(DUAL ? 256 : PNP_LANES) void step_pnp_kernel(Cfg C,
     E.touch = MS.ld(XCH_T0) != 0.0;
   }
   guard_robot(E.R, E.qlag6);
+  load_episodep(V, i, E);
   {   // same guard for the cube: back to its model pose at rest
     bool bad = false;
     for (int k = 0; k < 3; k++) bad = bad || bad_value(E.Cb.pos[k]);
@@ -702,7 +712,7 @@ __global__ __launch_bounds__(PNP_LANES) void reset_pnp_kernel(Cfg C, View V, con
   if (i >= C.n) return;
   const ModelPtr P = as_model_ptr(Pg);
   EnvP E;
-  load_envp(V, i, E);
+  load_envp(V, i, E); load_episodep(V, i, E);
   const bool doit = !mask || mask[i];
   E.episode = sel((doit && reseed), 0, E.episode);
   reset_envp(C, i, E, doit);

@@ -157,3 +157,34 @@ def test_domain_randomisation_changes_only_the_cube(built):
     # same goals and cube placement (DR draws use their own stream); arm identical, cube rest height differs with mass
     assert np.array_equal(o1["desired"], o2["desired"]) and np.allclose(o1["obs"][:, 0:3], o2["obs"][:, 0:3], atol=1e-12)
     assert np.abs(o1["obs"][:, 5] - o2["obs"][:, 5]).max() > 1e-7
+
+
+def test_finger_pads_never_reach_each_other(po):
+    """The last primitive pair the kernels leave out: right pad <-> left pad (mycobot280_main.xml:195-199,222-225).  With EVERY
+    primitive pair enabled in the oracle, closing the empty gripper fully stops at the gear joints' upper limit (0.7 rad) with the
+    two 2 mm thick pads still 2.6 mm apart: the pair cannot collide inside the joint range, so leaving it out changes nothing."""
+    tab = load_json("mycobot280")
+    om = po.OracleModel(tab, enable_contact=True, scope_geom=-1); d = po.OracleData(om)
+    q = np.asarray(tab["qpos0"], dtype=float).copy(); q[12] = 0.15                      # the cube out of the gripper's way
+    d.set_state(qpos=q, qvel=np.zeros(18), ctrl=[0, 0, 0, 0, 0, 0, 1.0])
+    gn = tab["geom_name"]; gr, gl = gn.index("right_finger_layer"), gn.index("left_finger_layer")
+    gaps = []
+    for _ in range(30):
+        d.step(20)
+        gx = d.get("geom_xpos", (48, 3))
+        gaps.append(np.linalg.norm(gx[gr] - gx[gl]) - 2 * tab["geom_size"][gr][2])
+        assert int(d.get("ncon", (1,), np.int32)[0]) == 4                               # the cube on the table, nothing else
+    assert d.qpos[6] > 0.699 and 0.0024 < gaps[-1] < 0.0028 and min(gaps) > 0.0024
+
+
+def test_finger_pad_on_the_table_is_a_contact(po):
+    """Scoped set (what the kernels implement): cube pairs + finger pad <-> table / ground plane."""
+    tab = load_json("mycobot280")
+    om = po.OracleModel(tab, enable_contact=True, scope_geom=tab["geom_name"].index("object0")); d = po.OracleData(om)
+    q = np.asarray(tab["qpos0"], dtype=float).copy()
+    q[:7] = [0.417, -2.299, 1.057, 0.345, 1.63, 0.161, 0.569]; q[8] = q[6]            # a pose that presses a pad on the table top
+    d.set_state(qpos=q, qvel=np.zeros(18)); d.forward()
+    n = int(d.get("ncon", (1,), np.int32)[0])
+    assert n > 4
+    J = d.get("efc_J", (224, 24))[7:7 + 6 * (n - 4), :18]         # pair order: (table, pads) before (table, cube): the cube's 4 contacts come last
+    assert np.abs(J[:, 12:18]).max() == 0.0 and np.abs(J[:, :10]).max() > 0           # rows of the pad contacts: robot dofs only
