@@ -438,10 +438,12 @@ MCG_DEV void tcp_forward(ModelPtr P, const real* q6, TcpPose& X, bool want_jac) 
 MCG_DEV void rne_bias(ModelPtr Pm, const real* cs, const real* sn, const real* qd, real* fs) {
   real F[NB][3], Nn[NB][3];                 // net force / moment about the body origin, body frame
   real w[NB][3], al[NB][3], ac[NB][3];      // angular velocity, angular acceleration, linear acceleration of the origin
+  BodyC nxt = load_body(launder(Pm), 0);      // each block starts the s_loads of the next body before it computes (see crb_to_lds)
   static_for<NB>([&](auto I) {
     constexpr int i = I; constexpr int p = PAR[i]; constexpr int K = AXK[i];
     constexpr int A = (K + 1) % 3, B = (K + 2) % 3;
-    const BodyC bc = load_body(launder(Pm), i); const BodyC* b = &bc;
+    const BodyC bc = nxt; const BodyC* b = &bc;
+    if constexpr (i + 1 < NB) nxt = load_body(launder(Pm), i + 1); else nxt = load_body(launder(Pm), NB - 1);
     const real g = AXS[i] * qd[i];
     if constexpr (p < 0) {
       // static base: w_p = al_p = 0, a_p = -gravity (base frame)
@@ -471,7 +473,8 @@ MCG_DEV void rne_bias(ModelPtr Pm, const real* cs, const real* sn, const real* q
   });
   static_for<NB>([&](auto I) {
     constexpr int i = NB - 1 - I; constexpr int p = PAR[i]; constexpr int K = AXK[i];
-    const BodyC bc = load_body(launder(Pm), i); const BodyC* b = &bc;
+    const BodyC bc = nxt; const BodyC* b = &bc;
+    if constexpr (i > 0) nxt = load_body(launder(Pm), i - 1);
     fs[i] = -b->damping * qd[i] - AXS[i] * Nn[i][K];
     if constexpr (p >= 0) {
       real fp[3], np[3];
@@ -490,11 +493,18 @@ MCG_DEV void rne_bias(ModelPtr Pm, const real* cs, const real* sn, const real* q
 template <class LS>
 MCG_DEV void crb_to_lds(ModelPtr Pm, const real* cs, const real* sn, const LS MS) {
     real cm[NB], cmc[NB][3], cI[NB][6];
+    // Scalar loads, batched: the offsets of the six arm bodies (51 of the 57 walk levels below pass through them) come in one batch
+    // up front, and each body block starts the loads of the NEXT body's constants before it computes -- a wave alone on its SIMD
+    // otherwise stalls ~100 clocks on every one of ~70 dependent s_load round trips, and this wave is on the critical path.
+    real rarm[6][3];
+    { ModelPtr Q = launder(Pm); static_for<6>([&](auto I) { constexpr int i = I; ldc<3>(Q->body[i].r, rarm[i]); }); }
+    BodyC nxt = load_body(launder(Pm), NB - 1);
     static_for<NB>([&](auto I) {
       constexpr int i = NB - 1 - I; constexpr int K = AXK[i]; constexpr int A = (K + 1) % 3, B = (K + 2) % 3;
       constexpr int p = PAR[i];
       constexpr bool leaf = (i == 7 || i == 9 || i == 10 || i == 11);
-      const BodyC bc = load_body(launder(Pm), i); const BodyC* b = &bc;
+      const BodyC bc = nxt; const BodyC* b = &bc;
+      if constexpr (i > 0) nxt = load_body(launder(Pm), i - 1);
       if constexpr (leaf) {
         cm[i] = b->mass;
         for (int k = 0; k < 3; k++) cmc[i][k] = b->mc[k];
@@ -517,7 +527,10 @@ MCG_DEV void crb_to_lds(ModelPtr Pm, const real* cs, const real* sn, const LS MS
         constexpr int cur = Cur; constexpr int pj = PAR[cur];
         if constexpr (pj >= 0) {
           constexpr int Kc = AXK[cur];
-          real rc[3]; ldc<3>(launder(Pm)->body[cur].r, rc);
+          real rc[3];
+          if constexpr (cur < 6) { rc[0] = rarm[cur][0]; rc[1] = rarm[cur][1]; rc[2] = rarm[cur][2]; }
+          else if constexpr (cur == i) { rc[0] = b->r[0]; rc[1] = b->r[1]; rc[2] = b->r[2]; }      // this block's own constants
+          else ldc<3>(launder(Pm)->body[cur].r, rc);
           real f2[3], n2[3];
           rot_up<Kc>(cs[cur], sn[cur], fj, f2);
           rot_up<Kc>(cs[cur], sn[cur], nj, n2);
@@ -691,14 +704,18 @@ MCG_DEV void robot_substep(ModelPtr Pm, Robot& S, real* qlag6, const LS MS, CPL*
   // "Compiler hazard"), so no lane-divergent branch is allowed around code that may spill.
   real Dl[10], arefl[10], sgl[10];
   bool any_limit = false;
+  // One laundered pointer and ONE batch of scalar loads for the ten ranges: a wave alone on its SIMD pays every s_load round trip
+  // (~100+ clocks) in full, and ten dependent ones in a row were a tenth of the sub-step.
+  real jr[10][2];
+  { ModelPtr Q = launder(Pm); static_for<10>([&](auto I) { constexpr int j = I; jr[j][0] = Q->jnt_range[j][0]; jr[j][1] = Q->jnt_range[j][1]; }); }
   static_for<10>([&](auto I) {
     constexpr int j = I;
-    ModelPtr Q = launder(Pm);
-    const real lo = S.q[j] - Q->jnt_range[j][0], hi = Q->jnt_range[j][1] - S.q[j];
+    const real lo = S.q[j] - jr[j][0], hi = jr[j][1] - S.q[j];
     real dist = (lo < 0) ? lo : 0.0, sg = (lo < 0) ? 1.0 : 0.0;
     dist = (hi < 0) ? hi : dist; sg = (hi < 0) ? -1.0 : sg;
     sgl[j] = sg; Dl[j] = 0; arefl[j] = 0;
     if (__any(sg != 0)) {
+      ModelPtr Q = launder(Pm);
       real par[10]; ldc<10>(Q->limit_par[j], par);
       const real imp = impedance(par, dist);
       const real D = imp * rcp_nr(fmax(MINVAL * imp, (1 - imp) * Q->limit_diag[j]));
@@ -986,7 +1003,7 @@ MCG_DEV void robot_substep(ModelPtr Pm, Robot& S, real* qlag6, const LS MS, CPL*
     real Lf[NB * (NB + 1) / 2], dinv[NB];
     static_for<NB>([&](auto I) { constexpr int i = I; dinv[i] = MS.ld(LDS_FDINV + i);
       static_for<i>([&](auto Jj) { constexpr int j = Jj; if constexpr (PAT_M.nz[i][j]) Lf[tri(i, j)] = MS.ld(LDS_FAC + tri(i, j)); }); });
-    static_for<NB>([&](auto I) { constexpr int i = I; rhs[i] = launder(Pm)->body[i].damping * a[i]; });
+    { ModelPtr Q = launder(Pm); static_for<NB>([&](auto I) { constexpr int i = I; rhs[i] = Q->body[i].damping * a[i]; }); }      // one batch of s_loads
     ldl_solve<PAT_M>(Lf, dinv, rhs);
     static_for<NB>([&](auto I) { constexpr int i = I; rhs[i] = fma(-h, rhs[i], a[i]); });
   } else {
@@ -1000,7 +1017,7 @@ MCG_DEV void robot_substep(ModelPtr Pm, Robot& S, real* qlag6, const LS MS, CPL*
     static_for<NB>([&](auto I) { constexpr int i = I; real sacc = 0;
       static_for<NB>([&](auto Jj) { constexpr int j = Jj;
         if constexpr (PAT_M.nz[i > j ? i : j][i > j ? j : i]) sacc = fma(Mh[tri(i, j)], a[j], sacc); }); rhs[i] = sacc; });
-    static_for<NB>([&](auto I) { constexpr int i = I; Mh[tri(i, i)] = fma(h, launder(Pm)->body[i].damping, Mh[tri(i, i)]); });
+    { ModelPtr Q = launder(Pm); static_for<NB>([&](auto I) { constexpr int i = I; Mh[tri(i, i)] = fma(h, Q->body[i].damping, Mh[tri(i, i)]); }); }
     ldl_factor<PAT_M>(Mh, dinv);
     ldl_solve<PAT_M>(Mh, dinv, rhs);
   }
@@ -1032,7 +1049,7 @@ MCG_DEV void helper_substep(ModelPtr Pm, const LS MS) {
     real Mh[NB * (NB + 1) / 2], dinv[NB];
     static_for<NB>([&](auto I) { constexpr int i = I;
       static_for<i + 1>([&](auto Jj) { constexpr int j = Jj; if constexpr (PAT_M.nz[i][j]) Mh[tri(i, j)] = MS.ld(LDS_M + tri(i, j)); }); });
-    static_for<NB>([&](auto I) { constexpr int i = I; Mh[tri(i, i)] = fma(h, launder(Pm)->body[i].damping, Mh[tri(i, i)]); });
+    { ModelPtr Q = launder(Pm); static_for<NB>([&](auto I) { constexpr int i = I; Mh[tri(i, i)] = fma(h, Q->body[i].damping, Mh[tri(i, i)]); }); }
     ldl_factor<PAT_M>(Mh, dinv);
     static_for<NB>([&](auto I) { constexpr int i = I; MS.st(LDS_FDINV + i, dinv[i]);
       static_for<i>([&](auto Jj) { constexpr int j = Jj; if constexpr (PAT_M.nz[i][j]) MS.st(LDS_FAC + tri(i, j), Mh[tri(i, j)]); }); });

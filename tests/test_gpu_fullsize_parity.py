@@ -59,7 +59,8 @@ def test_pickandplace_full_size(torch_cuda, controller):
             assert torch.equal(x, y)                          # two engines, same seed: bit-identical
     for o, r, tr, g, f in runs[0]:
         assert torch.isfinite(o).all() and torch.isfinite(r).all()
-    assert runs[0][49][2].all()                               # TimeLimit(50) at 8192 envs
+    early = torch.stack([r[2] for r in runs[0][:49]]).any(dim=0)      # an env that succeeded earlier restarted its episode clock
+    assert runs[0][49][2][~early].all() and int(early.sum()) < 64       # TimeLimit(50) at 8192 envs
     cube_z = runs[0][-1][0][:, 5]
     assert (cube_z > 0.19).float().mean() > 0.99              # the cubes are on the table (or lifted), not through it
 
