@@ -644,6 +644,11 @@ struct CubeSys {
     o[6] = sel(side, v[8], v[6]); o[7] = sel(side, v[9], v[7]);
   }
 
+  // Iteration structure (round 2).  A contact is walked ONCE per Newton iteration: the pass that checks the active set at the new
+  // point x also assembles the system of the set it finds there (the first FULL_STEPS iterations move to x with a full step, so the
+  // next set is known contact by contact), instead of a consistency pass followed by an assembly pass that both rebuild the
+  // contact's rows.  Pass P0 does the same for the warm start (initial masks + first assembly).  Only the fallback iterations (exact
+  // line search, from any point) keep the separate passes, because their next point is known after the search only.
   template <class BuildH>
   MCG_DEV void solve_coupled(BuildH& build_H, const real* g0, const real* Dl, const real* arefl, const real* sgl,
                              const real* qdr, real* ar) {
@@ -652,91 +657,108 @@ struct CubeSys {
     _Pragma("unroll") for (int k = 0; k < 6; k++) ac[k] = a_c[k];
     bool actl[10];
     _Pragma("unroll") for (int j = 0; j < 10; j++) actl[j] = (sgl[j] != 0) && (sgl[j] * ar[j] - arefl[j] < 0);
-    // initial contact masks
-    for (int c = 0; __any(c < ncon); c++) {
-      Coupled K; contact_of(c, K);
-      real a8[8], v8[8], da[4], dv[4];
-      gather8(ar, K.side, a8); gather8(qdr, K.side, v8);
-      bdots(K, ac, a8, da); bdots(K, Cb.vel, v8, dv);
-      int mask = 0;
-      static_for<3>([&](auto Kk) { constexpr int k = Kk; const real m = K.mu[k];
-        const real arp = -K.Bc * fma(m, dv[1 + k], dv[0]) - K.kterm, arm = -K.Bc * fma(-m, dv[1 + k], dv[0]) - K.kterm;
-        mask |= (fma(m, da[1 + k], da[0]) - arp < 0 ? (1 << (2 * k)) : 0) | (fma(-m, da[1 + k], da[0]) - arm < 0 ? (1 << (2 * k + 1)) : 0); });
-      if (c < ncon) S.st(LDS_ACT + c, (real)mask);
-    }
     bool conv = false;
     real xr[NB], xc[6];
-    MCG_TICK(ST_C_MASK);
+    real gr[NB], Hc[21], gc[6];
     MCG_COUNT(CN_COUPLED);
-    for (int it = 0; it < 50; it++) {
-      MCG_COUNT(CN_COUPLED_IT);
-      real gr[NB];
-      {   // G <- H_eq + active limit rows, parked in LDS; Cm <- 0
+
+    // G <- H_eq + active limit rows, parked in LDS; Cm <- 0; right-hand sides and the cube block start from their smooth parts
+    auto begin_assembly = [&](const bool* act_) {
+      {
         real L[NB * (NB + 1) / 2];
-        build_H(L, actl);
+        build_H(L, act_);
         static_for<NB>([&](auto I) { constexpr int i = I; static_for<i + 1>([&](auto Jj) { constexpr int j = Jj;
           if constexpr (PAT_H.nz[i][j]) S.st(GA + tri(i, j), L[tri(i, j)]); else if constexpr (PAT_G.nz[i][j]) S.st(GA + tri(i, j), 0.0); }); });
         _Pragma("unroll") for (int k = 0; k < 60; k++) S.st(CM + k, 0.0);
       }
       for (int i = 0; i < NB; i++) gr[i] = g0[i];
-      _Pragma("unroll") for (int j = 0; j < 10; j++) gr[j] += actl[j] ? sgl[j] * Dl[j] * arefl[j] : 0.0;
-      real Hc[21], gc[6];
+      _Pragma("unroll") for (int j = 0; j < 10; j++) gr[j] += act_[j] ? sgl[j] * Dl[j] * arefl[j] : 0.0;
       _Pragma("unroll") for (int k = 0; k < 21; k++) Hc[k] = 0;
       _Pragma("unroll") for (int k = 0; k < 6; k++) { Hc[tri(k, k)] = Md[k]; gc[k] = fs[k]; }
-      for (int c = 0; __any(c < ncon); c++) {
-        Coupled K; contact_of(c, K);
-        real W00 = 0, t0 = 0, W0[3], Wd[3], t[3];
-        {
+    };
+    // one contact's pyramid rows with the active set `mask` into Hc, gc, gr (registers) and G, Cm (LDS); dv = its basis . velocity
+    auto add_contact = [&](const Coupled& K, int mask, const real* dv, bool live) {
+      real W00 = 0, t0 = 0, W0[3], Wd[3], t[3];
+      static_for<3>([&](auto Kk) { constexpr int k = Kk; const real m = K.mu[k];
+        const real arp = -K.Bc * fma(m, dv[1 + k], dv[0]) - K.kterm, arm = -K.Bc * fma(-m, dv[1 + k], dv[0]) - K.kterm;
+        const real wp = sel(((mask >> (2 * k)) & 1) != 0, K.D, 0.0), wm = sel(((mask >> (2 * k + 1)) & 1) != 0, K.D, 0.0);
+        W00 += wp + wm; t0 = fma(wp, arp, fma(wm, arm, t0));
+        W0[k] = m * (wp - wm); Wd[k] = m * m * (wp + wm); t[k] = m * (wp * arp - wm * arm); });
+      // U_b = sum_b' W_bb' B_b' on the cube part (6) and the robot part (8)
+      real Uc[4][6];
+      _Pragma("unroll") for (int d = 0; d < 6; d++) {
+        Uc[0][d] = W00 * K.RC.Jn[d] + W0[0] * K.RC.J1[d] + W0[1] * K.RC.J2[d] + W0[2] * K.RC.Jt[d];
+        Uc[1][d] = W0[0] * K.RC.Jn[d] + Wd[0] * K.RC.J1[d];
+        Uc[2][d] = W0[1] * K.RC.Jn[d] + Wd[1] * K.RC.J2[d];
+        Uc[3][d] = W0[2] * K.RC.Jn[d] + Wd[2] * K.RC.Jt[d];
+        gc[d] += K.RC.Jn[d] * t0 + K.RC.J1[d] * t[0] + K.RC.J2[d] * t[1] + K.RC.Jt[d] * t[2];
+      }
+      static_for<6>([&](auto Dd) { constexpr int d = Dd; static_for<d + 1>([&](auto Ee) { constexpr int e = Ee;
+        Hc[tri(d, e)] += K.RC.Jn[d] * Uc[0][e] + K.RC.J1[d] * Uc[1][e] + K.RC.J2[d] * Uc[2][e] + K.RC.Jt[d] * Uc[3][e]; }); });
+      if (__any(K.pad && live)) {              // wave-uniform: a table-cube contact has no robot rows
+        real Ur[4][8];
+        _Pragma("unroll") for (int j = 0; j < 8; j++) {
+          Ur[0][j] = W00 * K.RP.Jn[j] + W0[0] * K.RP.J1[j] + W0[1] * K.RP.J2[j] + W0[2] * K.RP.Jt[j];
+          Ur[1][j] = W0[0] * K.RP.Jn[j] + Wd[0] * K.RP.J1[j];
+          Ur[2][j] = W0[1] * K.RP.Jn[j] + Wd[1] * K.RP.J2[j];
+          Ur[3][j] = W0[2] * K.RP.Jn[j] + Wd[2] * K.RP.Jt[j];
+        }
+        const int gear = 6 + 2 * K.side, fing = 7 + 2 * K.side;                 // dof of local 6 / 7
+        const int rowoff[2] = {gear * (gear + 1) / 2, fing * (fing + 1) / 2};
+        static_for<8>([&](auto Ii) { constexpr int i = Ii;
+          const real gl = K.RP.Jn[i] * t0 + K.RP.J1[i] * t[0] + K.RP.J2[i] * t[1] + K.RP.Jt[i] * t[2];
+          if constexpr (i < 6) gr[i] += gl;
+          else if constexpr (i == 6) { gr[6] += sel(K.side, 0.0, gl); gr[8] += sel(K.side, gl, 0.0); }
+          else { gr[7] += sel(K.side, 0.0, gl); gr[9] += sel(K.side, gl, 0.0); }
+          // robot block, lower triangle in the contact's local order (arm 0..5, gear, finger: increasing dof index), and
+          // coupling block Cm[dof i][cube d].  All loads of a row first, then all stores: the addresses are per-lane, so
+          // a load behind a store could not be hoisted and every entry would pay the LDS latency alone.  (One ds_add_f64
+          // per entry instead -- no load at all -- measured no faster: the loop is not bound by these round trips.)
+          const int slot = (i < 6) ? i : (i == 6 ? gear : fing);
+          int kg[i + 1]; real og[i + 1], oc[6];
+          static_for<i + 1>([&](auto Jj) { constexpr int j = Jj;
+            if constexpr (i < 6) kg[j] = GA + tri(i, j);
+            else kg[j] = GA + rowoff[i - 6] + (j < 6 ? j : (j == 6 ? gear : fing));
+            og[j] = S.ld(kg[j]); });
+          static_for<6>([&](auto Dd) { constexpr int d = Dd; oc[d] = S.ld(CM + slot * 6 + d); });
+          static_for<i + 1>([&](auto Jj) { constexpr int j = Jj;
+            const real v = K.RP.Jn[i] * Ur[0][j] + K.RP.J1[i] * Ur[1][j] + K.RP.J2[i] * Ur[2][j] + K.RP.Jt[i] * Ur[3][j];
+            S.st(kg[j], og[j] + v); });
+          static_for<6>([&](auto Dd) { constexpr int d = Dd;
+            const real v = K.RP.Jn[i] * Uc[0][d] + K.RP.J1[i] * Uc[1][d] + K.RP.J2[i] * Uc[2][d] + K.RP.Jt[i] * Uc[3][d];
+            S.st(CM + slot * 6 + d, oc[d] + v); }); });
+      }
+    };
+    // sign pattern of a contact's six pyramid rows at acceleration (basis dots da) given the velocity term (dv)
+    auto pattern = [&](const Coupled& K, const real* da, const real* dv) {
+      int mask = 0;
+      static_for<3>([&](auto Kk) { constexpr int k = Kk; const real m = K.mu[k];
+        const real arp = -K.Bc * fma(m, dv[1 + k], dv[0]) - K.kterm, arm = -K.Bc * fma(-m, dv[1 + k], dv[0]) - K.kterm;
+        mask |= (fma(m, da[1 + k], da[0]) - arp < 0 ? (1 << (2 * k)) : 0) | (fma(-m, da[1 + k], da[0]) - arm < 0 ? (1 << (2 * k + 1)) : 0); });
+      return mask;
+    };
+
+    // ---- P0: masks at the warm start + first assembly
+    begin_assembly(actl);
+    for (int c = 0; __any(c < ncon); c++) {
+      Coupled K; contact_of(c, K);
+      real a8[8], v8[8], da[4], dv[4];
+      gather8(ar, K.side, a8); gather8(qdr, K.side, v8);
+      bdots(K, ac, a8, da); bdots(K, Cb.vel, v8, dv);
+      const int mask = pattern(K, da, dv);
+      if (c < ncon) S.st(LDS_ACT + c, (real)mask);
+      add_contact(K, mask, dv, c < ncon);
+    }
+    bool assembled = true;
+    MCG_TICK(ST_C_MASK);
+    for (int it = 0; it < 50; it++) {
+      MCG_COUNT(CN_COUPLED_IT);
+      if (!assembled) {                          // after a line-search iteration: the set at the point the search reached
+        begin_assembly(actl);
+        for (int c = 0; __any(c < ncon); c++) {
+          Coupled K; contact_of(c, K);
           real v8[8], dv[4]; gather8(qdr, K.side, v8); bdots(K, Cb.vel, v8, dv);
-          static_for<3>([&](auto Kk) { constexpr int k = Kk; const real m = K.mu[k];
-            const real arp = -K.Bc * fma(m, dv[1 + k], dv[0]) - K.kterm, arm = -K.Bc * fma(-m, dv[1 + k], dv[0]) - K.kterm;
-            const real wp = sel(((K.mask >> (2 * k)) & 1) != 0, K.D, 0.0), wm = sel(((K.mask >> (2 * k + 1)) & 1) != 0, K.D, 0.0);
-            W00 += wp + wm; t0 = fma(wp, arp, fma(wm, arm, t0));
-            W0[k] = m * (wp - wm); Wd[k] = m * m * (wp + wm); t[k] = m * (wp * arp - wm * arm); });
-        }
-        // U_b = sum_b' W_bb' B_b' on the cube part (6) and the robot part (8)
-        real Uc[4][6];
-        _Pragma("unroll") for (int d = 0; d < 6; d++) {
-          Uc[0][d] = W00 * K.RC.Jn[d] + W0[0] * K.RC.J1[d] + W0[1] * K.RC.J2[d] + W0[2] * K.RC.Jt[d];
-          Uc[1][d] = W0[0] * K.RC.Jn[d] + Wd[0] * K.RC.J1[d];
-          Uc[2][d] = W0[1] * K.RC.Jn[d] + Wd[1] * K.RC.J2[d];
-          Uc[3][d] = W0[2] * K.RC.Jn[d] + Wd[2] * K.RC.Jt[d];
-          gc[d] += K.RC.Jn[d] * t0 + K.RC.J1[d] * t[0] + K.RC.J2[d] * t[1] + K.RC.Jt[d] * t[2];
-        }
-        static_for<6>([&](auto Dd) { constexpr int d = Dd; static_for<d + 1>([&](auto Ee) { constexpr int e = Ee;
-          Hc[tri(d, e)] += K.RC.Jn[d] * Uc[0][e] + K.RC.J1[d] * Uc[1][e] + K.RC.J2[d] * Uc[2][e] + K.RC.Jt[d] * Uc[3][e]; }); });
-        if (__any(K.pad && c < ncon)) {          // wave-uniform: a table contact has no robot rows
-          real Ur[4][8];
-          _Pragma("unroll") for (int j = 0; j < 8; j++) {
-            Ur[0][j] = W00 * K.RP.Jn[j] + W0[0] * K.RP.J1[j] + W0[1] * K.RP.J2[j] + W0[2] * K.RP.Jt[j];
-            Ur[1][j] = W0[0] * K.RP.Jn[j] + Wd[0] * K.RP.J1[j];
-            Ur[2][j] = W0[1] * K.RP.Jn[j] + Wd[1] * K.RP.J2[j];
-            Ur[3][j] = W0[2] * K.RP.Jn[j] + Wd[2] * K.RP.Jt[j];
-          }
-          const int gear = 6 + 2 * K.side, fing = 7 + 2 * K.side;                 // dof of local 6 / 7
-          const int rowoff[2] = {gear * (gear + 1) / 2, fing * (fing + 1) / 2};
-          static_for<8>([&](auto Ii) { constexpr int i = Ii;
-            const real gl = K.RP.Jn[i] * t0 + K.RP.J1[i] * t[0] + K.RP.J2[i] * t[1] + K.RP.Jt[i] * t[2];
-            if constexpr (i < 6) gr[i] += gl;
-            else if constexpr (i == 6) { gr[6] += sel(K.side, 0.0, gl); gr[8] += sel(K.side, gl, 0.0); }
-            else { gr[7] += sel(K.side, 0.0, gl); gr[9] += sel(K.side, gl, 0.0); }
-            // robot block, lower triangle in the contact's local order (arm 0..5, gear, finger: increasing dof index), and
-            // coupling block Cm[dof i][cube d].  All loads of a row first, then all stores: the addresses are per-lane, so
-            // a load behind a store could not be hoisted and every entry would pay the LDS latency alone.  (One ds_add_f64
-            // per entry instead -- no load at all -- measured no faster: the loop is not bound by these round trips.)
-            const int slot = (i < 6) ? i : (i == 6 ? gear : fing);
-            int kg[i + 1]; real og[i + 1], oc[6];
-            static_for<i + 1>([&](auto Jj) { constexpr int j = Jj;
-              if constexpr (i < 6) kg[j] = GA + tri(i, j);
-              else kg[j] = GA + rowoff[i - 6] + (j < 6 ? j : (j == 6 ? gear : fing));
-              og[j] = S.ld(kg[j]); });
-            static_for<6>([&](auto Dd) { constexpr int d = Dd; oc[d] = S.ld(CM + slot * 6 + d); });
-            static_for<i + 1>([&](auto Jj) { constexpr int j = Jj;
-              const real v = K.RP.Jn[i] * Ur[0][j] + K.RP.J1[i] * Ur[1][j] + K.RP.J2[i] * Ur[2][j] + K.RP.Jt[i] * Ur[3][j];
-              S.st(kg[j], og[j] + v); });
-            static_for<6>([&](auto Dd) { constexpr int d = Dd;
-              const real v = K.RP.Jn[i] * Uc[0][d] + K.RP.J1[i] * Uc[1][d] + K.RP.J2[i] * Uc[2][d] + K.RP.Jt[i] * Uc[3][d];
-              S.st(CM + slot * 6 + d, oc[d] + v); }); });
+          add_contact(K, K.mask, dv, c < ncon);
         }
       }
       MCG_TICK_PIN(gr, NB); MCG_TICK_PIN(gc, 6);
@@ -753,21 +775,23 @@ struct CubeSys {
         real sdot = 0;
         _Pragma("unroll") for (int d = 0; d < 6; d++) { S.st(CM + i * 6 + d, w[d]); sdot = fma(w[d] * dinvc[d], yl[d], sdot); }
         gr[i] -= sdot; });
-      real G[NB * (NB + 1) / 2], dinv[NB];
-      static_for<NB>([&](auto I) { constexpr int i = I; static_for<i + 1>([&](auto Jj) { constexpr int j = Jj;
-        if constexpr (PAT_G.nz[i][j]) G[tri(i, j)] = S.ld(GA + tri(i, j)); }); });
-      static_for<10>([&](auto Ii) { constexpr int i = Ii;
-        real wi[6];
-        _Pragma("unroll") for (int d = 0; d < 6; d++) wi[d] = S.ld(CM + i * 6 + d) * dinvc[d];
-        static_for<i + 1>([&](auto Jj) { constexpr int j = Jj;
-          real sdot = 0;
-          _Pragma("unroll") for (int d = 0; d < 6; d++) sdot = fma(wi[d], S.ld(CM + j * 6 + d), sdot);
-          G[tri(i, j)] -= sdot; }); });
-      for (int i = 0; i < NB; i++) xr[i] = gr[i];
-      MCG_TICK_PIN(xr, NB);
-      MCG_TICK(ST_C_SCHUR);
-      ldl_factor<PAT_G>(G, dinv);
-      ldl_solve<PAT_G>(G, dinv, xr);
+      {
+        real G[NB * (NB + 1) / 2], dinv[NB];
+        static_for<NB>([&](auto I) { constexpr int i = I; static_for<i + 1>([&](auto Jj) { constexpr int j = Jj;
+          if constexpr (PAT_G.nz[i][j]) G[tri(i, j)] = S.ld(GA + tri(i, j)); }); });
+        static_for<10>([&](auto Ii) { constexpr int i = Ii;
+          real wi[6];
+          _Pragma("unroll") for (int d = 0; d < 6; d++) wi[d] = S.ld(CM + i * 6 + d) * dinvc[d];
+          static_for<i + 1>([&](auto Jj) { constexpr int j = Jj;
+            real sdot = 0;
+            _Pragma("unroll") for (int d = 0; d < 6; d++) sdot = fma(wi[d], S.ld(CM + j * 6 + d), sdot);
+            G[tri(i, j)] -= sdot; }); });
+        for (int i = 0; i < NB; i++) xr[i] = gr[i];
+        MCG_TICK_PIN(xr, NB);
+        MCG_TICK(ST_C_SCHUR);
+        ldl_factor<PAT_G>(G, dinv);
+        ldl_solve<PAT_G>(G, dinv, xr);
+      }
       {   // x_c = L^-T D^-1 (L^-1 g_c - sum_i W_i x_r[i])
         real z[6];
         _Pragma("unroll") for (int d = 0; d < 6; d++) z[d] = yl[d];
@@ -779,13 +803,40 @@ struct CubeSys {
       }
       MCG_TICK_PIN(xr, NB); MCG_TICK_PIN(xc, 6);
       MCG_TICK(ST_C_SOLVE);
-      // consistency of the assumed active set at (xr, xc); r0 / dr of every contact row for the line search
+      bool same = true;
+      bool actx[10];
+      _Pragma("unroll") for (int j = 0; j < 10; j++) { actx[j] = (sgl[j] != 0) && (sgl[j] * xr[j] - arefl[j] < 0); same = same && (actx[j] == actl[j]); }
+
+      if (it < FULL_STEPS) {
+        // ---- fused pass: active set at x against the assumed one, and the system of the set found at x (G, W of this iteration
+        // are dead: the solve above has consumed them)
+        begin_assembly(actx);
+        for (int c = 0; __any(c < ncon); c++) {
+          Coupled K; contact_of(c, K);
+          real x8[8], v8[8], dx[4], dv[4];
+          gather8(xr, K.side, x8); gather8(qdr, K.side, v8);
+          bdots(K, xc, x8, dx); bdots(K, Cb.vel, v8, dv);
+          const int mask = pattern(K, dx, dv);
+          same = same && (c >= ncon || mask == K.mask);
+          if (c < ncon && !conv) S.st(LDS_ACT + c, (real)mask);
+          add_contact(K, mask, dv, c < ncon);
+        }
+        const bool finish = !conv && same;
+        conv = conv || finish;                 // a lane that finishes takes x; the others move to x with a full step: both take x
+        for (int i = 0; i < NB; i++) ar[i] = sel((finish || !conv), xr[i], ar[i]);
+        _Pragma("unroll") for (int d = 0; d < 6; d++) ac[d] = sel((finish || !conv), xc[d], ac[d]);
+        _Pragma("unroll") for (int j = 0; j < 10; j++) actl[j] = sel(conv && !finish, actl[j], actx[j]);
+        MCG_TICK(ST_C_CHECK);
+        if (!__any(!conv)) break;
+        assembled = true;
+        continue;
+      }
+
+      // ---- fallback iteration with the exact line search: consistency at (xr, xc); r0 / dr of every contact row
       // (from here on the row area of LDS holds line-search rows again: G and W are dead)
       real pr[NB], pc[6];
       for (int i = 0; i < NB; i++) pr[i] = xr[i] - ar[i];
       _Pragma("unroll") for (int d = 0; d < 6; d++) pc[d] = xc[d] - ac[d];
-      bool same = true;
-      _Pragma("unroll") for (int j = 0; j < 10; j++) { const bool now = (sgl[j] != 0) && (sgl[j] * xr[j] - arefl[j] < 0); same = same && (now == actl[j]); }
       for (int c = 0; __any(c < ncon); c++) {
         Coupled K; contact_of(c, K);
         real a8[8], v8[8], p8[8], da[4], dv[4], dp[4];
@@ -804,19 +855,8 @@ struct CubeSys {
       conv = conv || finish;
       MCG_TICK(ST_C_CHECK);
       if (!__any(!conv)) break;
-      // The first FULL_STEPS iterations take the full Newton step and re-mask there (semismooth Newton): when the active set
-      // settles this way the line search is never run, and a step that lands on a consistent set is the exact minimiser whatever
-      // path led to it.  Unit steps may cycle between two sets, so later iterations use the exact line search, which converges
-      // from any point.
-      if (it < FULL_STEPS) {
-        for (int i = 0; i < NB; i++) ar[i] = sel(conv, ar[i], xr[i]);
-        _Pragma("unroll") for (int d = 0; d < 6; d++) ac[d] = sel(conv, ac[d], xc[d]);
-        _Pragma("unroll") for (int j = 0; j < 10; j++) { const bool now = (sgl[j] != 0) && (sgl[j] * ar[j] - arefl[j] < 0); actl[j] = sel(conv, actl[j], now); }
-        remask(1.0, conv);
-        MCG_TICK(ST_C_LS);
-        continue;
-      }
-      // line search (bisection): smooth part = robot quadratic with H0 = M + equality rows (no limits), cube diag M
+      assembled = false;
+      // line search: smooth part = robot quadratic with H0 = M + equality rows (no limits), cube diag M
       MCG_COUNT(CN_COUPLED_LS);
       real lin0 = 0, quad = 0;
       {
