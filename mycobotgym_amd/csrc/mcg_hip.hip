@@ -465,15 +465,17 @@ MCG_DEV void pnp_substep(ModelPtr P, EnvP& E, const PnpScratch MS, const WLD& W)
 constexpr int XCH_FLAG = LDS_POLY, XCH_T0 = LDS_POLY + 1, XCH_T1 = LDS_POLY + 2, XCH_NCON = LDS_POLY + 3;
 constexpr int XCH_CB = LDS_POLY + 4, XCH_QL7 = LDS_POLY + 23;
 static_assert(XCH_QL7 + 7 <= LDS_POLY + 64, "exchange area exceeds the clip-polygon slots");
-// q(t), qd(t) for the other waves sit in the H_eq area: they are read right after S1, H_eq is only assembled after S2 (the
-// clip-polygon slots will not do: the cube wave's collision pass overwrites them while the helper and RNE waves still read)
-constexpr int XCH_Q = LDS_HEQ, XCH_QD = LDS_HEQ + NB;
+// q(t), qd(t) for the other waves sit at the start of the line-search row area: they are written at the end of a sub-step (every
+// solve that uses that area is over by then), read right after S1, and dead before the cube wave's solve touches the area after
+// S2.  (The clip-polygon slots will not do: the collision pass overwrites them while the helper and RNE waves still read; the
+// H_eq area would, but then the robot wave could not assemble the constraint part of H_eq BEFORE S2, while it waits for M.)
+constexpr int XCH_Q = LDS_ROW, XCH_QD = LDS_ROW + NB;
 constexpr int XCH_FS = PNP_SLOTS;                 // 12 more slots: 640 x 32 lanes x 8 B = the CU's 160 KB exactly
 constexpr int PNP_SLOTS_DUAL = PNP_SLOTS + NB;
 static_assert(PNP_SLOTS_DUAL * PNP_LANES * 8 <= 160 * 1024, "LDS of a CU");
-// robot-side split of the four-wave PickAndPlace kernel: M from the helper wave, passive - bias from the RNE wave; the Euler
-// step stays with M a (no room for the factor in LDS)
-struct SplitPnp { static constexpr bool enabled = true, rne_remote = true, factor_remote = false, early_heq = false;
+// robot-side split of the four-wave PickAndPlace kernel: M from the helper wave, passive - bias from the RNE wave, the constraint
+// part of H_eq assembled before barrier S2; the Euler step stays with M a (no room for the factor in LDS)
+struct SplitPnp { static constexpr bool enabled = true, rne_remote = true, factor_remote = false, early_heq = true;
                   static constexpr int QB = XCH_Q, QDB = XCH_QD, FS = XCH_FS; };
 
 MCG_DEV void cube_to_lds(const PnpScratch MS, const Cube& Cb) {
