@@ -69,7 +69,11 @@ typedef struct mcg_model {
   /* mocap variant only (mycobot280_mocap.xml): weld between the mocap body and gripper_tcp */
   double base_quat[4];              /* orientation of the arm's base body: start of the xquat chain */
   double weld_on;                   /* 1 = the model carries the weld (and no arm actuators) */
-  double weld_par[10], weld_diag;   /* solver numbers as in limit_par; the six rows share one weight */
+  double weld_par[10];              /* solver numbers as in limit_par */
+  double weld_diag[2];              /* diagApprox of the translational rows 0-2 and of the rotational rows 3-5.  Built-in models: the
+                                       same (translational) weight on all six, which is what the reference's mocap keyframe supports
+                                       (oracle/RULE_STUDY.md, K2); mj_diagApprox as recalled puts the rotational inverse weight on
+                                       rows 3-5: specialize(..., weld_rule="mujoco") / MyCobotVecEnv(weld_rule="mujoco") */
   double weld_anchor[3];            /* weld point on the robot, link6 frame */
   double weld_relpos[3], weld_relquat[4], weld_torquescale;
   double target0[3];                /* MJCF position of site `target0`: what stage_rewards reads unless rendering (mycobot.py:422, 309-311) */

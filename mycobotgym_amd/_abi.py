@@ -44,7 +44,7 @@ class McgModel(C.Structure):
         ("contact_par", (d * 15) * 5),
         ("contact_diag", (d * 2) * 5),
         ("geom_friction0", d * 3),
-        ("base_quat", d * 4), ("weld_on", d), ("weld_par", d * 10), ("weld_diag", d), ("weld_anchor", d * 3),
+        ("base_quat", d * 4), ("weld_on", d), ("weld_par", d * 10), ("weld_diag", d * 2), ("weld_anchor", d * 3),
         ("weld_relpos", d * 3), ("weld_relquat", d * 4), ("weld_torquescale", d),
         ("target0", d * 3),
     ]

@@ -731,7 +731,7 @@ MCG_DEV void robot_substep(ModelPtr Pm, Robot& S, real* qlag6, const LS MS, CPL*
   // mocap weld: rows 0-2 position (mocap point - weld point), rows 3-5 orientation torquescale * imag(neg(q_tcp) q_m relquat);
   // Jacobian = -(jac of the weld point), its rotational part mapped through 0.5 neg(q_tcp) (.) q_m relquat; arm dofs only.
   // [RECALL mj_instantiateEquality mjEQ_WELD; the common row weight is pinned by the reference keyframe, see the oracle]
-  real Jw[6][6], Dw = 0, arefw[6];
+  real Jw[6][6], Dw[2] = {0, 0}, arefw[6];       // Dw: translational rows 0-2, rotational rows 3-5
   if constexpr (WLD::enabled) {
     ModelPtr Q = launder(Pm);
     TcpPose X; tcp_forward(Q, S.q, X, true);
@@ -754,14 +754,15 @@ MCG_DEV void robot_substep(ModelPtr Pm, Robot& S, real* qlag6, const LS MS, CPL*
     });
     real ss = 0; for (int k = 0; k < 6; k++) ss = fma(cpos[k], cpos[k], ss);
     const real imp = impedance(par, sqrt(ss));
-    Dw = imp * rcp_nr(fmax(MINVAL * imp, (1 - imp) * Q->weld_diag));
+    Dw[0] = imp * rcp_nr(fmax(MINVAL * imp, (1 - imp) * Q->weld_diag[0]));
+    Dw[1] = imp * rcp_nr(fmax(MINVAL * imp, (1 - imp) * Q->weld_diag[1]));
     static_for<6>([&](auto Rr) {
       constexpr int r = Rr;
       real vel = 0;
       static_for<6>([&](auto I) { constexpr int j = I; vel = fma(Jw[r][j], S.qd[j], vel); });
       arefw[r] = -par[1] * vel - par[0] * imp * cpos[r];
     });
-    pin(Dw); pin6(arefw);
+    pin(Dw[0]); pin(Dw[1]); pin6(arefw);
     for (int r = 0; r < 6; r++) pin6(Jw[r]);
     MCG_FENCE();
   }
@@ -783,7 +784,7 @@ MCG_DEV void robot_substep(ModelPtr Pm, Robot& S, real* qlag6, const LS MS, CPL*
           static_for<a + 1>([&](auto B_) { constexpr int b = B_; acc[tri(a, b)] = fma(ja, Jc[sd][k][b], acc[tri(a, b)]); }); }); }); });
     if constexpr (WLD::enabled)
       static_for<6>([&](auto Rr) { constexpr int r = Rr;
-        static_for<6>([&](auto A_) { constexpr int a = A_; const real ja = Dw * Jw[r][a];
+        static_for<6>([&](auto A_) { constexpr int a = A_; const real ja = Dw[r / 3] * Jw[r][a];
           static_for<a + 1>([&](auto B_) { constexpr int b = B_; acc[tri(a, b)] = fma(ja, Jw[r][b], acc[tri(a, b)]); }); }); });
     static_for<6>([&](auto A_) { constexpr int a = A_;
       static_for<a + 1>([&](auto B_) { constexpr int b = B_; MS.st(LDS_HEQ + tri(a, b), acc[tri(a, b)]); }); });
@@ -819,7 +820,7 @@ MCG_DEV void robot_substep(ModelPtr Pm, Robot& S, real* qlag6, const LS MS, CPL*
   });
   g0[6] += Dj * arefj; g0[8] -= Dj * arefj;
   if constexpr (WLD::enabled)
-    static_for<6>([&](auto Rr) { constexpr int r = Rr; const real da = Dw * arefw[r];
+    static_for<6>([&](auto Rr) { constexpr int r = Rr; const real da = Dw[r / 3] * arefw[r];
       static_for<6>([&](auto I) { constexpr int j = I; g0[j] = fma(Jw[r][j], da, g0[j]); }); });
   if constexpr (SPL::early_heq) assemble_heq(std::false_type{});      // J^T D J only: M is not there yet
   if constexpr (SPL::enabled) {

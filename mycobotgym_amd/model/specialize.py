@@ -65,7 +65,7 @@ def mix_contact(m, g1, g2):
     return condim, [f[0], f[0], f[1], f[2], f[2]], solref, solimp
 
 
-def specialize(m: dict) -> dict:
+def specialize(m: dict, weld_rule: str = "common") -> dict:
     """m: table from ``load_model`` (full scene; the cube may have been dropped)."""
     name2id = {n: i for i, n in enumerate(m["body_name"])}
     has_cube = "object0" in name2id
@@ -193,7 +193,7 @@ def specialize(m: dict) -> dict:
 
     # --- mocap weld (mocap.xml:15-20): body1 = the mocap body (static), body2 = gripper_tcp, welded into link6
     out["weld_on"] = 0.0
-    out["weld_par"] = np.zeros(10); out["weld_diag"] = 0.0; out["weld_anchor"] = np.zeros(3)
+    out["weld_par"] = np.zeros(10); out["weld_diag"] = np.zeros(2); out["weld_anchor"] = np.zeros(3)
     out["weld_relpos"] = np.zeros(3); out["weld_relquat"] = np.array([1.0, 0, 0, 0]); out["weld_torquescale"] = 1.0
     if weld:
         w = weld[0]
@@ -206,7 +206,11 @@ def specialize(m: dict) -> dict:
         out["weld_on"] = 1.0
         out["weld_par"] = np.array(_solparams(w["solref"], w["solimp"], h))
         # all six rows carry the translational inverse weights (oracle/mco_physics.c, pinned by the keyframe equilibrium)
-        out["weld_diag"] = float(biw[b1, 0] + biw[b2, 0])
+        # weld_rule "common": one (translational) weight for the six rows -- the variant the reference's mocap keyframe supports;
+        # "mujoco": mj_diagApprox as recalled, the rotational inverse weight on rows 3-5 (oracle/RULE_STUDY.md, K2)
+        assert weld_rule in ("common", "mujoco")
+        part = 1 if weld_rule == "mujoco" else 0
+        out["weld_diag"] = np.array([biw[b1, 0] + biw[b2, 0], biw[b1, part] + biw[b2, part]])
         out["weld_anchor"] = p + data[0:3]               # anchor (body2 frame) in the link6 frame
         out["weld_relpos"] = data[3:6]; out["weld_relquat"] = data[6:10]; out["weld_torquescale"] = float(data[10])
         out["mocap_pose0"] = np.concatenate([np.asarray(m["body_pos"][b1], float), np.asarray(m["body_quat"][b1], float)])

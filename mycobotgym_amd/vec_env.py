@@ -69,7 +69,7 @@ class MyCobotVecEnv:
                  frame_skip: int = 20, max_episode_steps: int = MAX_EPISODE_STEPS, device="cuda:0", seed: int = 0,
                  env_id_offset: int = 0, auto_reset: bool = True, mesh_inertia: str = "legacy",
                  domain_randomization: Optional[dict] = None, model_path: Optional[str] = None,
-                 image_obs: bool = False, model: Optional["_abi.McgModel"] = None, **unused):
+                 image_obs: bool = False, model: Optional["_abi.McgModel"] = None, weld_rule: str = "common", **unused):
         if image_obs:
             raise NotImplementedError("image observations (-v1 ids, MyCobotImgEnv) need a rasteriser: out of scope")
         if controller_type == "delta_joint":
@@ -122,6 +122,9 @@ class MyCobotVecEnv:
             cfg.dr_friction_range[0], cfg.dr_friction_range[1] = domain_randomization.get("friction", (1.0, 1.0))
         cfg.seed = int(seed) & (2 ** 64 - 1); cfg.env_id_offset = int(env_id_offset)
         self._cfg = cfg
+        if model is None and weld_rule != "common":     # mocap weld with MuJoCo's recalled row weights (rotational rows softer)
+            from .model.specialize import specialize
+            model = _abi.McgModel.from_spec(specialize(load_table(True, mesh_inertia, mocap), weld_rule=weld_rule))
         if model is None:     # built-in block; a caller-supplied mcg_model (tests, custom robots) overrides it
             model = _abi.McgModel()
             variant = (1 if mesh_inertia == "exact" else 0) + (2 if mocap else 0)     # 2, 3: mocap body + weld (mycobot280_mocap.xml)

@@ -127,3 +127,31 @@ def test_mocap_needs_its_model_variant(torch_cuda):
     h = C.c_void_p()
     assert L.mcg_create(C.byref(cfg), C.byref(model), 0, C.byref(h)) != 0
     assert b"mocap" in L.mcg_last_error()
+
+
+def test_mocap_weld_with_mujoco_row_weights(torch_cuda):
+    """`weld_rule="mujoco"`: the rotational inverse weight on the weld's rows 3-5 (mj_diagApprox as recalled) instead of one common
+    weight (the variant the reference's keyframe supports, oracle/RULE_STUDY.md): same parity bar, and a visibly softer orientation."""
+    from tests.common import make_pair, sync_oracle_to, step_errors
+    n = 128
+    envs, ora = make_pair(n, controller_type="mocap", reward_type="dense", seed=3, frame_skip=1, max_episode_steps=10 ** 9,
+                          weld_rule="mujoco")
+    ref, _ = make_pair(n, controller_type="mocap", reward_type="dense", seed=3, frame_skip=1, max_episode_steps=10 ** 9)
+    envs.reset(seed=3); ora.reset(seed=3); ref.reset(seed=3)
+    rng = np.random.default_rng(7)
+    worst = 0.0; differs = 0.0
+    for t in range(10):
+        a = _actions(rng, n, 8)
+        for s in range(20):
+            sync_oracle_to(envs, ora)
+            ref.set_state(**{k: v for k, v in envs.get_state().items()})
+            e, flags_equal, o = step_errors(envs, ora, a)
+            assert flags_equal
+            worst = max(worst, e.max())
+            import torch
+            ob, *_ = ref.step(torch.as_tensor(a))
+            differs = max(differs, float(np.abs(ob["observation"].cpu().numpy() - o["obs"]).max()))
+    print(f"\nmocap, weld_rule=mujoco: 200 sub-steps x {n} envs from identical state: max obs err {worst:.2e}; "
+          f"against the common-weight weld the same sub-steps differ by up to {differs:.2e}")
+    assert worst < 3e-13 and differs > 1e-9
+    envs.close(); ref.close()
