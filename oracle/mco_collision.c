@@ -214,8 +214,63 @@ static int filtered(const mco_model* m, int g1, int g2) {
   return 0;
 }
 
+/* ------------------------------------------------------------------- static box / plane - support polytope of a mesh */
+static void world_vertex(const mco_model* m, const mco_data* d, int g, int k, double* w) {
+  const double* R = d->geom_xmat[g]; const double* p = d->geom_xpos[g]; const double* v = m->hull_vert[g][k];
+  for (int r = 0; r < 3; r++) w[r] = p[r] + R[3*r]*v[0] + R[3*r+1]*v[1] + R[3*r+2]*v[2];
+}
+static void plane_polytope(const mco_model* m, mco_data* d, int gp, int gm) {
+  double n[3]; col(d->geom_xmat[gp], 2, n);
+  const double* pp = d->geom_xpos[gp];
+  double best = 0, bw[3] = {0, 0, 0}; int found = 0;
+  for (int k = 0; k < m->hull_nvert[gm]; k++) {
+    double w[3]; world_vertex(m, d, gm, k, w);
+    double rel[3] = { w[0] - pp[0], w[1] - pp[1], w[2] - pp[2] };
+    double dist = dot3(rel, n);
+    if (dist < 0 && (!found || dist < best)) { best = dist; memcpy(bw, w, sizeof(bw)); found = 1; }
+  }
+  if (!found) return;
+  double pos[3] = { bw[0] - 0.5*best*n[0], bw[1] - 0.5*best*n[1], bw[2] - 0.5*best*n[2] };
+  add_contact(m, d, gp, gm, pos, n, best);
+}
+static void box_polytope(const mco_model* m, mco_data* d, int gb, int gm) {
+  const double* pb = d->geom_xpos[gb]; const double* Rb = d->geom_xmat[gb]; const double* h = m->geom_size[gb];
+  double lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
+  double wlo[3][3], whi[3][3];                      /* the vertices that realise the extremes (first occurrence) */
+  for (int k = 0; k < m->hull_nvert[gm]; k++) {
+    double w[3]; world_vertex(m, d, gm, k, w);
+    double rel[3] = { w[0] - pb[0], w[1] - pb[1], w[2] - pb[2] };
+    for (int a = 0; a < 3; a++) {
+      double ax[3]; col(Rb, a, ax);
+      double c = dot3(rel, ax);
+      if (c < lo[a]) { lo[a] = c; memcpy(wlo[a], w, sizeof(w)); }
+      if (c > hi[a]) { hi[a] = c; memcpy(whi[a], w, sizeof(w)); }
+    }
+  }
+  for (int a = 0; a < 3; a++) if (lo[a] > h[a] || hi[a] < -h[a]) return;      /* a face axis separates */
+  double depth = INFINITY; int axis = 0, sign = 1;
+  for (int a = 0; a < 3; a++) {
+    double dp = h[a] - lo[a], dn = hi[a] + h[a];    /* push the polytope out through face +a / -a */
+    if (dp < depth) { depth = dp; axis = a; sign = 1; }
+    if (dn < depth) { depth = dn; axis = a; sign = -1; }
+  }
+  double n[3]; col(Rb, axis, n); for (int k = 0; k < 3; k++) n[k] *= sign;    /* from the box (geom1) to the mesh (geom2) */
+  const double* w = sign > 0 ? wlo[axis] : whi[axis];                          /* the vertex deepest inside */
+  double pos[3] = { w[0] + 0.5*depth*n[0], w[1] + 0.5*depth*n[1], w[2] + 0.5*depth*n[2] };
+  add_contact(m, d, gb, gm, pos, n, -depth);
+}
+
 void mco_collision(const mco_model* m, mco_data* d) {
   d->ncon = 0;
+  /* static primitive <-> arm-side mesh (support polytope): these pairs first, mesh by mesh (the order the kernels emit them in) */
+  for (int g2 = 0; g2 < m->ngeom; g2++) {
+    if (m->geom_type[g2] != MCO_GEOM_MESH || m->hull_nvert[g2] <= 0 || m->collide_extra[g2] != 3) continue;
+    for (int g1 = 0; g1 < m->ngeom; g1++) {
+      if (m->collide_extra[g1] != 1 || filtered(m, g1, g2)) continue;
+      if (m->geom_type[g1] == MCO_GEOM_PLANE) plane_polytope(m, d, g1, g2);
+      else if (m->geom_type[g1] == MCO_GEOM_BOX) box_polytope(m, d, g1, g2);
+    }
+  }
   for (int g1 = 0; g1 < m->ngeom; g1++) for (int g2 = g1 + 1; g2 < m->ngeom; g2++) {
     int t1 = m->geom_type[g1], t2 = m->geom_type[g2];
     if (t1 == MCO_GEOM_MESH || t2 == MCO_GEOM_MESH) continue;           /* convex-mesh collision: out of scope */

@@ -852,7 +852,7 @@ typedef struct { const char* name; size_t off; int count; int is_int; } field_t;
 #define MF_D(f) { #f, offsetof(mco_model, f), (int)(sizeof(((mco_model*)0)->f) / sizeof(double)), 0 }
 static const field_t model_fields[] = {
   MF_I(nbody), MF_I(njnt), MF_I(nq), MF_I(nv), MF_I(ngeom), MF_I(nsite), MF_I(nu), MF_I(neq), MF_I(ntendon),
-  MF_I(nexclude), MF_I(enable_contact), MF_I(collide_scope_geom), MF_I(collide_extra), MF_I(rule), MF_D(timestep), MF_D(gravity), MF_D(meaninertia),
+  MF_I(nexclude), MF_I(enable_contact), MF_I(collide_scope_geom), MF_I(collide_extra), MF_I(hull_nvert), MF_D(hull_vert), MF_I(rule), MF_D(timestep), MF_D(gravity), MF_D(meaninertia),
   MF_I(body_parent), MF_I(body_rootid), MF_I(body_weldid), MF_I(body_dofadr), MF_I(body_dofnum), MF_I(body_mocapid),
   MF_D(body_pos), MF_D(body_quat), MF_D(body_ipos), MF_D(body_iquat), MF_D(body_mass), MF_D(body_inertia),
   MF_I(jnt_type), MF_I(jnt_body), MF_I(jnt_qposadr), MF_I(jnt_dofadr), MF_I(jnt_limited),

@@ -52,7 +52,14 @@ typedef struct mco_model {
   double timestep, gravity[3], meaninertia;
   int enable_contact;            /* 0: collision stage skipped (Reach / free-space configs) */
   int collide_scope_geom;        /* >= 0: only pairs that involve this geom collide (the build's scoped set: the cube) ... */
-  int collide_extra[48];         /* ... plus pairs of one geom flagged 1 (static: ground plane, table) and one flagged 2 (finger pad) */
+  int collide_extra[48];         /* ... plus pairs of one geom flagged 1 (static: ground plane, table) and one flagged 2 (finger pad)
+                                    or 3 (arm-side mesh geom with a support polytope, below) */
+  /* Convex-mesh collision, first stage: MuJoCo collides a mesh geom's convex hull (libccd MPR, one contact per pair);
+   * restated here for mesh <-> static box / plane only, on the SUPPORT POLYTOPE of the hull (its support points in 26 directions,
+   * mycobotgym_amd/model/mjcf.py): separating-axis test over the box's face axes, one contact at the deepest vertex along the face of
+   * least penetration.  hull_nvert[g] = 0: geom g's mesh does not collide. */
+  int hull_nvert[48];
+  double hull_vert[48][26][3];   /* geom frame */
   /* Study switches (oracle/rule_study.py): alternatives to [RECALL] rules the reference's keyframes can discriminate.
    * All zero = the adopted rule set, which is what the HIP kernels implement and every parity test runs.
    *   rule[0] weld diagApprox   0 one common (translational) weight for the six rows | 1 translational rows 0-2, rotational rows 3-5

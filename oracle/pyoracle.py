@@ -17,6 +17,7 @@ _LIB_PATH = os.path.join(_HERE, "_build", "libmco_oracle.so")
 _lib = None
 
 MAXNQ, MAXNV, MAXU = 24, 24, 8
+ARM_MESHES = ("link1", "link2", "link3", "link4", "link5", "link6", "flange", "gripper_base")     # SURVEY 8f-4, first stage
 
 
 def build(force: bool = False) -> str:
@@ -80,7 +81,7 @@ def _ptr(a):
 class OracleModel:
     """An ``mco_model`` filled from one of ``mycobotgym_amd/assets/*.json``."""
 
-    def __init__(self, table: dict, enable_contact: bool = False, scope_geom: int = -1):
+    def __init__(self, table: dict, enable_contact: bool = False, scope_geom: int = -1, mesh_collision: bool = True):
         L = lib()
         self.table = table
         self.buf = C.create_string_buffer(L.mco_model_sizeof())
@@ -97,7 +98,14 @@ class OracleModel:
                 if table["geom_type"][g] == 7: continue
                 if table["body_weldid"][table["geom_body"][g]] == 0: extra[g] = 1
                 elif table["geom_name"][g] in ("right_finger_layer", "left_finger_layer"): extra[g] = 2
-            si("collide_extra", extra)
+            # ... and the arm-side mesh geoms (links 1-6, flange, gripper_base; both copies of each) through their support polytopes
+            hn = [0] * 48; hv = np.zeros((48, 26, 3))
+            for g in range(table["ngeom"]):
+                name = table["geom_mesh"][g] if table["geom_type"][g] == 7 else ""
+                sup = np.asarray(table.get("meshes", {}).get(name, {}).get("support", []), dtype=np.float64)
+                if mesh_collision and name in ARM_MESHES and len(sup):
+                    extra[g] = 3; hn[g] = len(sup); hv[g, :len(sup)] = sup
+            si("collide_extra", extra); si("hull_nvert", hn); sd("hull_vert", hv)
         sd("timestep", [table["opt"]["timestep"]]); sd("gravity", table["opt"]["gravity"])
         for k in ("body_parent", "body_rootid", "body_weldid", "body_dofadr", "body_dofnum", "jnt_type", "jnt_body",
                   "jnt_qposadr", "jnt_dofadr", "dof_body", "dof_jnt", "dof_parent", "geom_type", "geom_body",
