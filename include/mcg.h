@@ -45,7 +45,7 @@ typedef struct mcg_body {          /* 16 doubles = 128 B: one body's constants, 
   double mass, mc[3];               /* mass, mass * centre of mass (body frame, about the origin) */
   double inertia[6];                /* xx yy zz xy xz yz about the body origin */
   double armature, damping;         /* of the body's hinge (cube: unused, see cube_damping) */
-  double pad;
+  double hull_rad;                  /* arm bodies: largest distance from the body origin to a vertex of the mesh polytopes riding on it */
 } mcg_body;
 
 typedef struct mcg_model {
@@ -62,9 +62,16 @@ typedef struct mcg_model {
   double site_eef[3];               /* EEF site in the link6 frame */
   /* PickAndPlace only */
   double cube_half[3], table_pos[3], table_half[3], pad_box[2][6];
-  double contact_par[5][15];        /* table-cube, right pad-cube, left pad-cube, table-right pad, table-left pad: the 10 solver
-                                       numbers | friction[5].  The ground plane carries the table's (default) parameters. */
-  double contact_diag[5][2];        /* summed body_invweight0 (translational, rotational) of the pair */
+  double contact_par[6][15];        /* table-cube, right pad-cube, left pad-cube, table-right pad, table-left pad, table-arm mesh: the
+                                       10 solver numbers | friction[5].  The ground plane carries the table's (default) parameters. */
+  double contact_diag[5][2];        /* summed body_invweight0 (translational, rotational) of the first five pairs */
+  /* Convex-mesh collision, first stage (mycobot280_main.xml:105-175): the arm-side mesh geoms -- link1..link6, flange,
+     gripper_base -- against the table and the ground plane, on the support polytope of each mesh's convex hull (its support points in
+     26 directions, mycobotgym_amd/model/mjcf.py:support_polytope), one contact per pair at the deepest vertex. */
+  double link_hull[8][26][3];       /* vertices in the frame of the engine body the geom rides on: polytope p on body min(p, 5) */
+  double link_hull_box[8][6];       /* centre and half extents of the vertices' bounding box in that frame (broad phase) */
+  double link_diag[8][2];           /* body_invweight0 of the geom's MJCF body (translational, rotational) */
+  double link_mult;                 /* identical colliding geoms per mesh (the reference attaches every mesh twice: 2) */
   double geom_friction0[3];         /* sliding friction of the table, pad and cube geoms (re-mixed under domain randomisation) */
   /* mocap variant only (mycobot280_mocap.xml): weld between the mocap body and gripper_tcp */
   double base_quat[4];              /* orientation of the arm's base body: start of the xquat chain */

@@ -23,7 +23,7 @@ d = C.c_double
 
 
 class McgBody(C.Structure):
-    _fields_ = [("r", d * 3), ("mass", d), ("mc", d * 3), ("inertia", d * 6), ("armature", d), ("damping", d), ("pad", d)]
+    _fields_ = [("r", d * 3), ("mass", d), ("mc", d * 3), ("inertia", d * 6), ("armature", d), ("damping", d), ("hull_rad", d)]
 
 
 class McgModel(C.Structure):
@@ -41,8 +41,9 @@ class McgModel(C.Structure):
         ("act_forcerange", (d * 2) * 7), ("tendon_coef", d * 2),
         ("site_eef", d * 3),
         ("cube_half", d * 3), ("table_pos", d * 3), ("table_half", d * 3), ("pad_box", (d * 6) * 2),
-        ("contact_par", (d * 15) * 5),
+        ("contact_par", (d * 15) * 6),
         ("contact_diag", (d * 2) * 5),
+        ("link_hull", ((d * 3) * 26) * 8), ("link_hull_box", (d * 6) * 8), ("link_diag", (d * 2) * 8), ("link_mult", d),
         ("geom_friction0", d * 3),
         ("base_quat", d * 4), ("weld_on", d), ("weld_par", d * 10), ("weld_diag", d * 2), ("weld_anchor", d * 3),
         ("weld_relpos", d * 3), ("weld_relquat", d * 4), ("weld_torquescale", d),

@@ -29,7 +29,9 @@ typedef LaneScratchT<PNP_LANES> PnpScratch;
 // rows of mcg_model.contact_par / contact_diag.  The ground plane carries the table's parameters (both are default geoms).
 // TABLE_PAD*: a finger pad on the table top or on the ground (mycobot280_main.xml:81,87-88,195-199,222-225): rows in the robot's
 // dofs only; they route the sub-step through the coupled solver like the pad-cube contacts do.
-enum { PAIR_TABLE_CUBE = 0, PAIR_PADR_CUBE = 1, PAIR_PADL_CUBE = 2, PAIR_TABLE_PADR = 3, PAIR_TABLE_PADL = 4 };
+// TABLE_LINK0 + p: the support polytope of arm-side mesh p (link1..6, flange, gripper_base; it rides on arm body min(p, 5)) on the
+// table or the ground: condim 3 (four pyramid rows), rows in the arm dofs up to that body only (first stage).
+enum { PAIR_TABLE_CUBE = 0, PAIR_PADR_CUBE = 1, PAIR_PADL_CUBE = 2, PAIR_TABLE_PADR = 3, PAIR_TABLE_PADL = 4, PAIR_TABLE_LINK0 = 5 };
 
 struct Cube {
   real pos[3], quat[4], vel[6], warm[6];     // vel = world linear velocity, body-frame angular velocity (MuJoCo free joint)
@@ -50,17 +52,21 @@ MCG_DEV void make_frame(const real* n, real* t1, real* t2) {
 template <class LS>
 struct ContactList {
   const LS S;
-  int n;
-  MCG_DEV void add(const real* pos, const real* normal, real dist, int type) {
-    const bool ok = (dist < 0) && (n < MAXCON);
+  int n;              // entries stored
+  int ncap = 0;       // contacts as the oracle (and MuJoCo) counts them: `mult` identical colliding geoms give `mult` identical contacts,
+                      // stored here as ONE entry whose rows carry `mult` times the weight (the same cost function); the cap of MAXCON
+                      // contacts cuts the list where the oracle's cuts it
+  MCG_DEV void add(const real* pos, const real* normal, real dist, int type, int mult = 1) {
+    const int take = sel(mult < MAXCON - ncap, mult, MAXCON - ncap);
+    const bool ok = (dist < 0) && (take > 0);
     if (ok) {                           // plain LDS stores of live registers (no value is merged across this branch)
       const int b = LDS_CON + n * CON_STRIDE;
       real t1[3], t2[3];
       make_frame(normal, t1, t2);
       _Pragma("unroll") for (int k = 0; k < 3; k++) { S.st(b + k, pos[k]); S.st(b + 3 + k, normal[k]); S.st(b + 6 + k, t1[k]); S.st(b + 9 + k, t2[k]); }
-      S.st(b + 12, dist); S.st(b + 15, (real)type);
+      S.st(b + 12, dist); S.st(b + 13, (real)take); S.st(b + 15, (real)type);       // slot 13: multiplicity until prepare() turns it into D
     }
-    n += sel(ok, 1, 0);
+    n += sel(ok, 1, 0); ncap += sel(ok, take, 0);
   }
 };
 
@@ -81,6 +87,7 @@ MCG_DEV void ground_box(ContactList<LS>& CL, const real* pb, const real* Rb, con
 // mjc_BoxBox restated by behaviour: separating-axis test over 15 axes, then face clipping (<= 8 points) or one
 // edge-edge point; position = midpoint between the surfaces, normal from box A to box B, dist < 0.
 // A, B: rotation matrices row-major (world <- box).  Lanes with `live == false` do nothing.
+static constexpr real EDGE_MIN_SIN = 1e-6;      // edges closer to parallel than this make no edge-edge axis: the face axes cover them
 template <class LS>
 MCG_DEV void box_box(ContactList<LS>& CL, bool live, const real* pa, const real* Ra, const real* ha,
                      const real* pb, const real* Rb, const real* hb, int type) {
@@ -109,13 +116,15 @@ MCG_DEV void box_box(ContactList<LS>& CL, bool live, const real* pa, const real*
   _Pragma("unroll") for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
     const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
     const real expr = pA[i2]*Cm[i1][j] - pA[i1]*Cm[i2][j];
-    const real len = sqrt(fmax(0.0, 1 - Cm[i][j]*Cm[i][j]));
-    const bool valid = len >= 1e-9;
+    // |A_i x B_j| from the cross product itself: 1 - C^2 cancels to rounding noise of 1e-8 for parallel edges, and an axis made of
+    // that noise then beat the face axes (a cube at rest lost its four table contacts for a sub-step)
+    real L[3]; cross(A[i], B[j], L);
+    const real len = sqrt(dot3(L, L));
+    const bool valid = len >= EDGE_MIN_SIN;
     const real il = 1.0 / (valid ? len : 1.0);
     const real s = (fabs(expr) - (ha[i1]*Q[i2][j] + ha[i2]*Q[i1][j] + hb[j1]*Q[i][j2] + hb[j2]*Q[i][j1])) * il;
     sep = sep || (valid && s > 0);
     const bool tk = valid && (s * 1.05 > best);
-    real L[3]; cross(A[i], B[j], L);
     best = sel(tk, s, best); code = sel(tk, 6 + 3*i + j, code); invert = sel(tk, (expr < 0), invert);
     _Pragma("unroll") for (int k = 0; k < 3; k++) nrm[k] = sel(tk, L[k] * il, nrm[k]);
   }
@@ -250,7 +259,7 @@ struct CubeSys {
   unsigned long long pm_bits;                  // the model pointer's bits, for stages reached through the robot's hook
   MCG_DEV CubeSys(const LS s_, const Cube& c, const real* d) : S(s_), Cb(c), pm_bits(0) { dr[0] = d[0]; dr[1] = d[1]; }
   real h, Rc[9], Md[6], damp[6], fs[6];
-  real B_tc, B_pc, B_tp, mu_tc[3], mu_pc[3], mu_tp[3];
+  real B_tc, B_pc, B_tp, B_tl, mu_tc[3], mu_pc[3], mu_tp[3], mu_tl[3];
   int ncon; bool any_pad, solved, touch[2];    // touch: this forward pass has a right / left pad-cube contact; any_pad: any pad contact
   real a_c[6];
 
@@ -277,6 +286,7 @@ struct CubeSys {
     mu_pc[0] = mu_pc[1] = fmax(fp, fcb); mu_pc[2] = Q->contact_par[PAIR_PADR_CUBE][12];
     mu_tp[0] = mu_tp[1] = fmax(ft, fp); mu_tp[2] = Q->contact_par[PAIR_TABLE_PADR][12];
     B_tc = Q->contact_par[PAIR_TABLE_CUBE][1]; B_pc = Q->contact_par[PAIR_PADR_CUBE][1]; B_tp = Q->contact_par[PAIR_TABLE_PADR][1];
+    mu_tl[0] = mu_tl[1] = Q->contact_par[PAIR_TABLE_LINK0][10]; mu_tl[2] = 0; B_tl = Q->contact_par[PAIR_TABLE_LINK0][1];      // condim 3: no torsional rows
   }
 
   MCG_DEV ModelPtr model() const {                // wave-uniform pointer rebuilt as a scalar
@@ -303,8 +313,8 @@ struct CubeSys {
     solved = false;
     _Pragma("unroll") for (int k = 0; k < 6; k++) a_c[k] = Cb.warm[k];
 
-    // ---- P4 collision over the primitive geoms, in the oracle's pair order (the cap of MAXCON contacts then cuts the same tail):
-    // ground-pads, ground-cube, table-pads, table-cube, right pad-cube, left pad-cube
+    // ---- P4 collision, in the oracle's pair order (the cap of MAXCON contacts then cuts the same tail): arm-side meshes on the
+    // ground / the table (mesh by mesh), then the primitive geoms: ground-pads, ground-cube, table-pads, table-cube, pads-cube
     ContactList<LS> CL{S, 0};
     real hc[3]; ldc<3>(Q->cube_half, hc);
     real tp[3], th[3]; ldc<3>(Q->table_pos, tp); ldc<3>(Q->table_half, th);
@@ -331,7 +341,71 @@ struct CubeSys {
           Rio[3*k + A] = cs_ * ca + sn_ * cb; Rio[3*k + B] = -sn_ * ca + cs_ * cb;
         }
       };
-      static_for<6>([&](auto I) { constexpr int i = I; real r[3]; ldc<3>(Q->body[i].r, r); joint(i, AXK[i], AXS[i], r, qr[i], R, p); });
+      // Arm-side mesh geoms (support polytopes) against the ground plane and the table, body by body as the chain is walked: the oracle's
+      // rule (mco_collision.c: plane_polytope / box_polytope) -- separating-axis test over the table's face axes, ONE contact at the
+      // deepest vertex along the face of least penetration; the deepest vertex below z = 0 for the ground.  Broad phase: the lowest
+      // point of the vertices' bounding box in the body frame.
+      auto hull = [&](int pi, const real* Rio, const real* pio) {
+        ModelPtr H = launder(Pm);
+        real bx[6]; ldc<6>(H->link_hull_box[pi], bx);
+        const real cz = pio[2] + Rio[6] * bx[0] + Rio[7] * bx[1] + Rio[8] * bx[2];
+        const real ez = fabs(Rio[6]) * bx[3] + fabs(Rio[7]) * bx[4] + fabs(Rio[8]) * bx[5];
+        if (!__any(cz - ez < tp[2] + th[2])) return;                      // wave-uniform: nothing of it reaches the table top's height
+        real lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY}, wz[3] = {0, 0, 0};
+        for (int k = 0; k < 26; k++) {
+          real v[3]; ldc<3>(H->link_hull[pi][k], v);
+          real w[3];
+          _Pragma("unroll") for (int r = 0; r < 3; r++) w[r] = pio[r] + Rio[3*r]*v[0] + Rio[3*r+1]*v[1] + Rio[3*r+2]*v[2];
+          const bool lower = w[2] < lo[2];                                 // first occurrence of the minimum, as the oracle keeps it
+          _Pragma("unroll") for (int r = 0; r < 3; r++) { wz[r] = sel(lower, w[r], wz[r]); lo[r] = fmin(lo[r], w[r]); hi[r] = fmax(hi[r], w[r]); }
+        }
+        const int mult = (int)H->link_mult;
+        const int before = CL.n;
+        {   // ground plane z = 0
+          const real n[3] = {0, 0, 1};
+          const real pos[3] = {wz[0], wz[1], wz[2] - 0.5 * lo[2]};
+          CL.add(pos, n, lo[2] < 0 ? lo[2] : 1.0, PAIR_TABLE_LINK0 + pi, mult);
+        }
+        {   // table (static, axis-aligned): faces +-x, +-y, +-z
+          bool sep = false; real depth = INFINITY; int axis = 0; bool plus = true;
+          _Pragma("unroll") for (int a = 0; a < 3; a++) {
+            const real l = lo[a] - tp[a], hgh = hi[a] - tp[a];
+            sep = sep || (l > th[a]) || (hgh < -th[a]);
+            const real dp = th[a] - l, dn = hgh + th[a];
+            const bool tp_ = dp < depth;                                   // selects, no lane-divergent branch (compiler hazard, mcg_dynamics.hpp)
+            depth = sel(tp_, dp, depth); axis = sel(tp_, a, axis); plus = sel(tp_, true, plus);
+            const bool tn_ = dn < depth;
+            depth = sel(tn_, dn, depth); axis = sel(tn_, a, axis); plus = sel(tn_, false, plus);
+          }
+          const bool topface = (axis == 2) && plus;
+          real wd[3] = {wz[0], wz[1], wz[2]};
+          if (__any(!sep && !topface)) {                                   // rare: a side or bottom face wins: find that face's deepest vertex
+            real best = INFINITY;
+            for (int k = 0; k < 26; k++) {
+              real v[3]; ldc<3>(H->link_hull[pi][k], v);
+              real w[3];
+              _Pragma("unroll") for (int r = 0; r < 3; r++) w[r] = pio[r] + Rio[3*r]*v[0] + Rio[3*r+1]*v[1] + Rio[3*r+2]*v[2];
+              const real c = sel3(axis, w[0], w[1], w[2]);
+              const real key = plus ? c : -c;                              // face +a: the smallest coordinate; face -a: the largest
+              const bool better = !topface && key < best;
+              best = sel(better, key, best);
+              _Pragma("unroll") for (int r = 0; r < 3; r++) wd[r] = sel(better, w[r], wd[r]);
+            }
+          }
+          real n[3] = {0, 0, 0};
+          _Pragma("unroll") for (int r = 0; r < 3; r++) n[r] = (r == axis) ? (plus ? 1.0 : -1.0) : 0.0;
+          const real pos[3] = {wd[0] + 0.5 * depth * n[0], wd[1] + 0.5 * depth * n[1], wd[2] + 0.5 * depth * n[2]};
+          CL.add(pos, n, sep ? 1.0 : -depth, PAIR_TABLE_LINK0 + pi, mult);
+        }
+        any_pad = any_pad || (CL.n > before);
+      };
+      static_for<6>([&](auto I) { constexpr int i = I; real r[3]; ldc<3>(Q->body[i].r, r);
+        const real rad = Q->body[i].hull_rad;                             // comes with the same batch of scalar loads as r
+        joint(i, AXK[i], AXS[i], r, qr[i], R, p);
+        if (__any(p[2] - rad < tp[2] + th[2])) {                          // wave-uniform: the body's bounding sphere reaches the table top's height
+          hull(i, R, p);
+          if constexpr (i == 5) { hull(6, R, p); hull(7, R, p); }
+        } });
       const real dxe = p[0] - Cb.pos[0], dye = p[1] - Cb.pos[1], dze = p[2] - Cb.pos[2];
       reach = dxe*dxe + dye*dye + dze*dze < 0.2 * 0.2;                  // link6 origin within 20 cm of the cube
       // a pad's far corner is at most 0.16 m from the link6 origin: pads can only touch the table / the ground from within 0.17 m
@@ -423,15 +497,32 @@ struct CubeSys {
       real m0 = sel(padcube, mu_pc[0], mu_tc[0]);
       real tran = sel(type == PAIR_PADR_CUBE, Q->contact_diag[PAIR_PADR_CUBE][0],
                       sel(type == PAIR_PADL_CUBE, Q->contact_diag[PAIR_PADL_CUBE][0], Q->contact_diag[PAIR_TABLE_CUBE][0]));
+      const real mult = S.ld(b + 13);                                     // identical contacts this entry stands for (ContactList::add)
       if (any_tp) {
+        const bool tablink = type >= PAIR_TABLE_LINK0, tabp = tabpad && !tablink;
         real par_tp[10]; ldc<10>(Q->contact_par[PAIR_TABLE_PADR], par_tp);
-        imp = sel(tabpad, impedance(par_tp, dist), imp); kk = sel(tabpad, par_tp[0], kk); m0 = sel(tabpad, mu_tp[0], m0);
+        imp = sel(tabp, impedance(par_tp, dist), imp); kk = sel(tabp, par_tp[0], kk); m0 = sel(tabp, mu_tp[0], m0);
         tran = sel(type == PAIR_TABLE_PADR, Q->contact_diag[PAIR_TABLE_PADR][0], sel(type == PAIR_TABLE_PADL, Q->contact_diag[PAIR_TABLE_PADL][0], tran));
+        if (__any(tablink)) {
+          real par_tl[10]; ldc<10>(Q->contact_par[PAIR_TABLE_LINK0], par_tl);
+          imp = sel(tablink, impedance(par_tl, dist), imp); kk = sel(tablink, par_tl[0], kk); m0 = sel(tablink, mu_tl[0], m0);
+          real tl = tran;
+          static_for<8>([&](auto Pp) { constexpr int pp = Pp; tl = sel(type == PAIR_TABLE_LINK0 + pp, Q->link_diag[pp][0], tl); });
+          tran = tl;
+        }
       }
       const real Rn = fmax(MINVAL, (1 - imp) * tran * (1 + m0*m0) / imp);
       const real Rpy = fmax(MINVAL, 2 * m0*m0 * Rn);
-      if (c < ncon) { S.st(b + 13, 1.0 / Rpy); S.st(b + 14, kk * imp * dist); }
+      if (c < ncon) { S.st(b + 13, mult / Rpy); S.st(b + 14, kk * imp * dist); }
     }
+#ifdef MCG_DBG_PRINT
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      printf("[prepare] ncon %d any_pad %d touch %d %d cube pos %.9g %.9g %.9g\n", ncon, (int)any_pad, (int)touch[0], (int)touch[1], Cb.pos[0], Cb.pos[1], Cb.pos[2]);
+      for (int c = 0; c < ncon; c++) { const int b = LDS_CON + c * CON_STRIDE;
+        printf("   contact %d type %d dist %.6e D %.6e kterm %.6e pos %.6f %.6f %.6f n %.3f %.3f %.3f\n", c, (int)S.ld(b + 15), S.ld(b + 12), S.ld(b + 13), S.ld(b + 14),
+               S.ld(b), S.ld(b + 1), S.ld(b + 2), S.ld(b + 3), S.ld(b + 4), S.ld(b + 5)); }
+    }
+#endif
   }
 
   // rows of contact c in the cube's dofs / in the robot's dofs of the pad's side
@@ -608,7 +699,7 @@ struct CubeSys {
   struct Coupled {                 // one contact, as the coupled solve sees it
     CubeRows RC; PadRows RP;
     real D, kterm, Bc, mu[3];
-    int type, side, mask; bool pad;
+    int type, side, mask; bool pad, dim3;      // dim3: condim 3 (arm mesh contacts): the torsional pair of rows does not exist
   };
   MCG_DEV void contact_of(int c, Coupled& K) const {
     const int b = LDS_CON + c * CON_STRIDE;
@@ -616,10 +707,19 @@ struct CubeSys {
     K.D = sel((c < ncon), S.ld(b + 13), 0.0); K.kterm = S.ld(b + 14);
     K.mask = sel((c < ncon), (int)S.ld(LDS_ACT + c), 0);
     K.pad = K.type != PAIR_TABLE_CUBE;                                   // the contact has rows in the robot's dofs
-    const bool tabpad = K.type >= PAIR_TABLE_PADR;                       // ... and none in the cube's (table / ground - pad)
+    const bool tabpad = K.type >= PAIR_TABLE_PADR;                       // ... and none in the cube's (table / ground - pad or arm mesh)
+    const bool link = K.type >= PAIR_TABLE_LINK0;
+    const int lbody = sel(link, sel(K.type - PAIR_TABLE_LINK0 < 5, K.type - PAIR_TABLE_LINK0, 5), 7);      // last arm joint that moves the mesh
+    K.dim3 = link;
+    K.mask = sel(link, K.mask & 15, K.mask);
     K.side = sel((K.type == PAIR_PADL_CUBE || K.type == PAIR_TABLE_PADL), 1, 0);
     rows_cube(c, K.RC);
     rows_pad(c, K.side, K.RP);
+    _Pragma("unroll") for (int j = 0; j < 8; j++) {                      // an arm mesh on body b: joints 0..b only (no gripper dofs)
+      const bool moves = j <= lbody;
+      K.RP.Jn[j] = sel(moves, K.RP.Jn[j], 0.0); K.RP.J1[j] = sel(moves, K.RP.J1[j], 0.0);
+      K.RP.J2[j] = sel(moves, K.RP.J2[j], 0.0); K.RP.Jt[j] = sel(moves, K.RP.Jt[j], 0.0);
+    }
     // pad-cube: the pad is geom1 (rows_pad carries that minus sign); table-pad: the pad is geom2, its rows enter with +
     // (selects, not products with 0: the joint-frame slots of a side whose pads were not posed hold stale LDS contents)
     _Pragma("unroll") for (int j = 0; j < 8; j++) {
@@ -630,8 +730,8 @@ struct CubeSys {
       K.RC.Jn[d] = sel(tabpad, 0.0, K.RC.Jn[d]); K.RC.J1[d] = sel(tabpad, 0.0, K.RC.J1[d]);
       K.RC.J2[d] = sel(tabpad, 0.0, K.RC.J2[d]); K.RC.Jt[d] = sel(tabpad, 0.0, K.RC.Jt[d]);
     }
-    _Pragma("unroll") for (int k = 0; k < 3; k++) K.mu[k] = sel(tabpad, mu_tp[k], sel(K.pad, mu_pc[k], mu_tc[k]));
-    K.Bc = sel(tabpad, B_tp, sel(K.pad, B_pc, B_tc));
+    _Pragma("unroll") for (int k = 0; k < 3; k++) K.mu[k] = sel(link, mu_tl[k], sel(tabpad, mu_tp[k], sel(K.pad, mu_pc[k], mu_tc[k])));
+    K.Bc = sel(link, B_tl, sel(tabpad, B_tp, sel(K.pad, B_pc, B_tc)));
   }
   // the four basis dot products of a contact with a (cube 6-vector, robot 8-vector of the contact's side)
   MCG_DEV static void bdots(const Coupled& K, const real* vc, const real* v8, real* o) {
@@ -735,7 +835,7 @@ struct CubeSys {
       static_for<3>([&](auto Kk) { constexpr int k = Kk; const real m = K.mu[k];
         const real arp = -K.Bc * fma(m, dv[1 + k], dv[0]) - K.kterm, arm = -K.Bc * fma(-m, dv[1 + k], dv[0]) - K.kterm;
         mask |= (fma(m, da[1 + k], da[0]) - arp < 0 ? (1 << (2 * k)) : 0) | (fma(-m, da[1 + k], da[0]) - arm < 0 ? (1 << (2 * k + 1)) : 0); });
-      return mask;
+      return sel(K.dim3, mask & 15, mask);
     };
 
     // ---- P0: masks at the warm start + first assembly
@@ -747,6 +847,9 @@ struct CubeSys {
       bdots(K, ac, a8, da); bdots(K, Cb.vel, v8, dv);
       const int mask = pattern(K, da, dv);
       if (c < ncon) S.st(LDS_ACT + c, (real)mask);
+#ifdef MCG_DBG_PRINT
+      if (blockIdx.x == 0 && threadIdx.x == 0 && c < ncon) printf("[P0] c %d type %d pad %d mask %d da %.4e %.4e %.4e %.4e dv %.4e %.4e %.4e %.4e D %.4e kterm %.4e Bc %.4e mu %.3e %.3e %.3e\n", c, K.type, (int)K.pad, mask, da[0], da[1], da[2], da[3], dv[0], dv[1], dv[2], dv[3], K.D, K.kterm, K.Bc, K.mu[0], K.mu[1], K.mu[2]);
+#endif
       add_contact(K, mask, dv, c < ncon);
     }
     bool assembled = true;
@@ -818,6 +921,9 @@ struct CubeSys {
           bdots(K, xc, x8, dx); bdots(K, Cb.vel, v8, dv);
           const int mask = pattern(K, dx, dv);
           same = same && (c >= ncon || mask == K.mask);
+#ifdef MCG_DBG_PRINT
+          if (blockIdx.x == 0 && threadIdx.x == 0 && c < ncon) printf("[it %d] c %d mask %d (was %d) dx %.4e %.4e %.4e %.4e xc2 %.6e conv %d\n", it, c, mask, K.mask, dx[0], dx[1], dx[2], dx[3], xc[2], (int)conv);
+#endif
           if (c < ncon && !conv) S.st(LDS_ACT + c, (real)mask);
           add_contact(K, mask, dv, c < ncon);
         }
@@ -845,8 +951,9 @@ struct CubeSys {
         static_for<3>([&](auto Kk) { constexpr int k = Kk;
           static_for<2>([&](auto Od) { constexpr int odd = Od; constexpr int r = 2 * k + odd;
             const real m = odd ? -K.mu[k] : K.mu[k];
-            const real r0 = fma(m, da[1 + k], da[0]) - (-K.Bc * fma(m, dv[1 + k], dv[0]) - K.kterm), jp = fma(m, dp[1 + k], dp[0]);
-            if (c < ncon) { S.st(LDS_ROW + (c * 6 + r) * 2, r0); S.st(LDS_ROW + (c * 6 + r) * 2 + 1, jp); }
+            const bool absent = K.dim3 && k == 2;
+            const real r0 = sel(absent, 1.0, fma(m, da[1 + k], da[0]) - (-K.Bc * fma(m, dv[1 + k], dv[0]) - K.kterm)), jp = sel(absent, 0.0, fma(m, dp[1 + k], dp[0]));
+            if (c < ncon) { S.st(LDS_ROW + (c * 6 + r) * 2, r0); S.st(LDS_ROW + (c * 6 + r) * 2 + 1, jp); }      // absent: a row that never activates
             same = same && (c >= ncon || ((r0 + jp) < 0) == (((K.mask >> r) & 1) != 0)); }); });
       }
       const bool finish = !conv && same;
@@ -901,6 +1008,9 @@ struct CubeSys {
       remask(alpha, conv);
       MCG_TICK(ST_C_LS);
     }
+#ifdef MCG_DBG_PRINT
+    if (blockIdx.x == 0 && threadIdx.x == 0) printf("[coupled done] ac %.6e %.6e %.6e %.6e %.6e %.6e conv %d\n", ac[0], ac[1], ac[2], ac[3], ac[4], ac[5], (int)conv);
+#endif
     _Pragma("unroll") for (int k = 0; k < 6; k++) a_c[k] = ac[k];
     solved = true;
   }

@@ -244,6 +244,31 @@ def specialize(m: dict, weld_rule: str = "common") -> dict:
         # structural facts the cube kernels rely on: CoM at the body origin, principal axes = body axes
         assert np.allclose(mc[12], 0) and np.allclose(inertia[12][3:], 0), "cube: centred, axis-aligned inertia expected"
         out["geom_ids"] = {"table": gt, "cube": gc, "pad_r": gr, "pad_l": gl}
+        # --- convex-mesh collision, first stage: support polytopes of the arm-side mesh geoms, in engine body frames
+        names = ("link1", "link2", "link3", "link4", "link5", "link6", "flange", "gripper_base")
+        hull = np.zeros((8, 26, 3)); box = np.zeros((8, 6)); ldiag = np.zeros((8, 2)); mult = set()
+        for p, nm in enumerate(names):
+            gs = [g for g in range(m["ngeom"]) if m["geom_type"][g] == 7 and m["geom_mesh"][g] == nm
+                  and m["geom_contype"][g] and m["geom_conaffinity"][g]]
+            sup = np.asarray(m["meshes"][nm]["support"], dtype=float)
+            assert gs and 4 <= len(sup) <= 26, nm
+            g = gs[0]
+            root, R, pw = weld_frames[m["geom_body"][g]]
+            assert root == min(p, 5), "arm-side meshes ride on links 1-6 (flange and gripper_base welded into link6)"
+            assert np.allclose(m["geom_pos"][g], 0) and np.allclose(m["geom_quat"][g], [1, 0, 0, 0])
+            v = pw + sup @ R.T
+            hull[p, :len(v)] = v; hull[p, len(v):] = v[0]                      # padded with a repeat: extremes and first occurrences unchanged
+            box[p] = np.concatenate([0.5 * (v.max(0) + v.min(0)), 0.5 * (v.max(0) - v.min(0))])
+            ldiag[p] = biw[m["geom_body"][g]]
+            mult.add(len(gs))
+            condim, fri, solref, solimp = mix_contact(m, gt, g)
+            assert condim == 3
+        assert len(mult) == 1
+        cp.append(np.concatenate([_solparams(solref, solimp, h), fri]))
+        out["contact_par"] = np.array(cp)    # + row 5: table - arm mesh (condim 3)
+        out["link_hull"] = hull; out["link_hull_box"] = box; out["link_diag"] = ldiag; out["link_mult"] = float(mult.pop())
+        for p in range(8):                # mcg_body.hull_rad: the free broad-phase number that travels with the body's other constants
+            out["body"][min(p, 5), 15] = max(out["body"][min(p, 5), 15], float(np.linalg.norm(hull[p], axis=1).max()))
     return out
 
 

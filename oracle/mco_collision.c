@@ -85,6 +85,7 @@ static void plane_box(const mco_model* m, mco_data* d, int gp, int gb) {
 }
 
 /* --------------------------------------------------------------------------------------- box - box */
+#define EDGE_MIN_SIN 1e-6    /* an edge axis needs edges at least this far from parallel (sine of their angle) */
 #define EDGE_FUDGE 1.05      /* an edge axis must beat the best face axis by 5 % (avoids flicker on parallel faces) */
 
 static void box_box(const mco_model* m, mco_data* d, int ga, int gb) {
@@ -113,13 +114,13 @@ static void box_box(const mco_model* m, mco_data* d, int ga, int gb) {
   for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
     int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
     double expr = pA[i2]*C[i1][j] - pA[i1]*C[i2][j];                  /* p . (A_i x B_j) */
-    double len = sqrt(fmax(0.0, 1 - C[i][j]*C[i][j]));
-    if (len < 1e-9) continue;                                          /* parallel edges: covered by the face axes */
+    double L[3]; cross3(L, A[i], B[j]);
+    double len = sqrt(dot3(L, L));       /* from the cross product itself: 1 - C^2 is rounding noise of 1e-8 for parallel edges */
+    if (len < EDGE_MIN_SIN) continue;                                  /* (nearly) parallel edges: covered by the face axes */
     double s = (fabs(expr) - (ha[i1]*Q[i2][j] + ha[i2]*Q[i1][j] + hb[j1]*Q[i][j2] + hb[j2]*Q[i][j1])) / len;
     if (s > 0) return;
     if (s * EDGE_FUDGE > best) {
       best = s; code = 6 + 3*i + j;
-      double L[3]; cross3(L, A[i], B[j]);
       for (int k = 0; k < 3; k++) nrm[k] = L[k] / len;
       invert = expr < 0;
     }

@@ -64,36 +64,82 @@ def test_substeps_cube_resting_on_table(torch_cuda):
     assert worst["obs"] < 1e-13 and worst["qpos"] < 1e-12 and worst["qvel"] < 5e-10      # measured 5.6e-16, 1.0e-14, 5.2e-12
 
 
-def test_substeps_finger_pads_on_the_table_and_the_ground(torch_cuda):
-    """Arm poses that press a finger pad onto the table top or onto the ground plane next to the table (box-box / plane-box
-    contacts with rows in the robot's dofs only, mycobot280_main.xml:81,87-88,195-199,222-225), cube resting or being pushed."""
+def _contact_poses(kind, count=128, seed=0):
+    """Rejection-sampled arm poses (cube at rest on the table) with a SHALLOW contact of the wanted kind (a deep one is a violent
+    state).  kind "pad": a finger pad on the table / the ground; kind "mesh": an arm-side mesh (support polytope, condim 3: 4 rows)."""
     from tests.common import load_json
     from oracle import pyoracle as po
     tab = load_json("mycobot280")
     m = po.OracleModel(tab, enable_contact=True, scope_geom=tab["geom_name"].index("object0"))
     d = po.OracleData(m)
-    rng = np.random.default_rng(0)
-    gn = tab["geom_name"]; pads = (gn.index("right_finger_layer"), gn.index("left_finger_layer"))
+    rng = np.random.default_rng(seed)
     poses = []
-    while len(poses) < 128:                       # rejection-sample poses with a SHALLOW pad contact (a deep one is a violent state)
+    while len(poses) < count:
         q = np.array(tab["qpos0"], float)
         q[:6] = rng.uniform(-2.5, 2.5, 6); q[6] = q[8] = rng.uniform(0, 0.7)
         d.set_state(qpos=q, qvel=np.zeros(18)); d.forward()
-        n = int(d.get("ncon", (1,), np.int32)[0])
+        n = int(d.get("ncon", (1,), np.int32)[0]); nefc = int(d.get("nefc", (1,), np.int32)[0])
         if n <= 4: continue
-        dist = d.get("efc_pos", (224,))[7:7 + 6 * n:6]
-        if dist.min() > -2e-3: poses.append(q)
-    poses = np.array(poses)
+        rows = d.get("efc_type", (224,), np.int32)[:nefc] == 2                      # contact rows (pyramid)
+        ids = d.get("efc_id", (224,), np.int32)[:nefc][rows]
+        per_contact = np.bincount(ids)
+        has_mesh = bool((per_contact == 4).any())                                  # condim 3
+        has_pad = int((per_contact == 6).sum()) > 4                                # condim 4 beyond the cube's four
+        if d.get("efc_pos", (224,))[:nefc][rows].min() <= -2e-3: continue
+        if (kind == "mesh" and has_mesh) or (kind == "pad" and has_pad and not has_mesh): poses.append(q)
+    return np.array(poses)
 
+
+def _pose_prepare(poses):
     def prepare(ora):
         s = ora.get_state()
         s["qpos"][:, :12] = poses[:, :12]; s["qpos_lag"] = s["qpos"].copy()
         s["ctrl"][:, :6] = poses[:, :6]; s["ctrl"][:, 6] = poses[:, 6] / 0.7
         ora.set_state(**s)
-    worst, ncon = _substep_run(torch_cuda, 128, 200, prepare=prepare, hold_pose=True)
+    return prepare
+
+
+def test_substeps_finger_pads_on_the_table_and_the_ground(torch_cuda):
+    """Arm poses that press a finger pad onto the table top or onto the ground plane next to the table (box-box / plane-box
+    contacts with rows in the robot's dofs only, mycobot280_main.xml:81,87-88,195-199,222-225), cube resting or being pushed."""
+    worst, ncon = _substep_run(torch_cuda, 128, 200, prepare=_pose_prepare(_contact_poses("pad")), hold_pose=True)
     print(f"\npads on the table / ground, 200 sub-steps x 128 envs: {worst}, contact counts seen {sorted(ncon)}")
     assert max(ncon) > 4
     assert worst["obs"] < 1e-10 and worst["qpos"] < 1e-10 and worst["qvel"] < 1e-6
+
+
+def test_substeps_arm_meshes_on_the_table_and_the_ground(torch_cuda):
+    """SURVEY 8f-4, first stage: the arm-side mesh geoms (their 26-direction support polytopes) against the table and the ground:
+    one condim-3 contact per mesh at the deepest vertex, duplicated visual/collision meshes as one entry of double weight."""
+    worst, ncon = _substep_run(torch_cuda, 128, 200, prepare=_pose_prepare(_contact_poses("mesh", seed=1)), hold_pose=True)
+    print(f"\narm meshes on the table / ground, 200 sub-steps x 128 envs: {worst}, contact counts seen {sorted(ncon)}")
+    assert max(ncon) > 4
+    assert worst["obs"] < 1e-10 and worst["qpos"] < 1e-10 and worst["qvel"] < 1e-6
+
+
+def test_cube_edges_parallel_to_the_table_edges(torch_cuda):
+    """Regression (round 2): a cube rocking on the table by 3e-4 rad about y has its y edges parallel to the table's.  With
+    |A_i x B_j| taken as sqrt(1 - C^2), rounding (C = 1 - 1e-16) made a 1e-8 `length`, and the axis built from that noise beat the
+    face axes: the four table contacts were replaced by one contact without a normal and the cube fell freely for a sub-step.
+    The state is the one the fault was found in (tests/golden/cube_parallel_edge_state.npz: inputs + the oracle's output)."""
+    import os
+    from tests.common import make_pair, sync_oracle_to, step_errors
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "cube_parallel_edge_state.npz"))
+    n = 64
+    envs, ora = make_pair(n, has_object=True, controller_type="joint", reward_type="dense", seed=5, frame_skip=1, max_episode_steps=10 ** 9)
+    envs.reset(seed=5); ora.reset(seed=5)
+    s = ora.get_state()
+    for k in s: s[k][:] = z["pre_" + k]
+    ora.set_state(**s)
+    sync_oracle_to(envs, ora)
+    a = np.tile(z["action"], (n, 1)).astype(np.float32)
+    step_errors(envs, ora, a)
+    st, so = envs.get_state(), ora.get_state()
+    assert int(ora.data(0).get("ncon", (1,), np.int32)[0]) == 8                   # 4 pad-table + 4 cube-table
+    assert np.abs(so["qpos"][0] - z["post_qpos"]).max() < 1e-12                   # the oracle still gives the recorded answer
+    assert np.abs(st["qpos"].cpu().numpy().T - so["qpos"]).max() < 1e-12
+    assert np.abs(st["qvel"].cpu().numpy().T - so["qvel"]).max() < 1e-9
+    envs.close()
 
 
 def test_substeps_cube_tumbling_onto_table(torch_cuda):

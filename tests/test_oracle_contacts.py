@@ -58,6 +58,29 @@ def test_edge_contact_and_tilted_cube(po):
     assert _contacts(d)[0] == 2
 
 
+def test_nearly_parallel_edges_never_beat_the_faces(po):
+    """A cube rocking on the table by 1e-9 .. 1e-3 rad, with rounding-level noise in its quaternion: always the four face contacts
+    (normal +z), never an edge-edge axis made of the rounding noise of two parallel edges (the fault
+    tests/golden/cube_parallel_edge_state.npz records; EDGE_MIN_SIN in mco_collision.c)."""
+    rng = np.random.default_rng(0)
+    tab, om, d = _scene(po, [-0.05, 0.0, 0.21])
+    q = np.asarray(tab["qpos0"], dtype=float).copy()
+    for trial in range(400):
+        ang = 10.0 ** rng.uniform(-9, -3.3)
+        axis = rng.normal(size=3); axis[2] = 0; axis /= np.linalg.norm(axis)
+        if trial % 3 == 0: axis = np.array([0.0, 1.0, 0.0])
+        quat = np.concatenate([[np.cos(ang / 2)], np.sin(ang / 2) * axis]) * (1 + rng.uniform(-1, 1) * 1e-8)
+        quat = quat + rng.uniform(-1, 1, 4) * 2e-16
+        q[12:15] = [rng.uniform(-0.15, 0.15), rng.uniform(-0.2, 0.2), 0.21 - 2e-5]
+        q[15:19] = quat
+        d.set_state(qpos=q, qvel=np.zeros(18)); d.forward()
+        n, nefc = _contacts(d)
+        assert n == 4 and nefc == 7 + 24, (trial, ang, n)
+        J = d.get("efc_J", (224, 24))[7:31, 12:15]
+        assert np.abs(J[0::6, 2] - 1.0).max() < 1e-6, (trial, ang)       # first pyramid row: n + mu t1, z-component = n_z = 1
+        assert d.get("efc_pos", (224,))[7:31].max() < -1e-6
+
+
 def _rest_penetration(po, rules=None):
     tab, om, d = _scene(po, [-0.05, 0.0, 0.21])
     if rules:
@@ -188,3 +211,34 @@ def test_finger_pad_on_the_table_is_a_contact(po):
     assert n > 4
     J = d.get("efc_J", (224, 24))[7:7 + 6 * (n - 4), :18]         # pair order: (table, pads) before (table, cube): the cube's 4 contacts come last
     assert np.abs(J[:, 12:18]).max() == 0.0 and np.abs(J[:, :10]).max() > 0           # rows of the pad contacts: robot dofs only
+
+
+def test_arm_mesh_on_the_table_is_a_contact(po):
+    """SURVEY 8f-4, first stage: the arm-side mesh geoms collide with the table / ground through the support polytope of their convex
+    hull (26 directions), one contact per geom pair at the deepest vertex; every mesh is attached twice in the reference
+    (mycobot280_main.xml:105-175: a visual copy with density 0 and a default one, both colliding), so contacts come in identical pairs;
+    default geoms are condim 3: four pyramid rows, in the arm's dofs up to the link."""
+    tab = load_json("mycobot280")
+    om = po.OracleModel(tab, enable_contact=True, scope_geom=tab["geom_name"].index("object0")); d = po.OracleData(om)
+    q = np.asarray(tab["qpos0"], dtype=float).copy()
+    d.set_state(qpos=q, qvel=np.zeros(18)); d.forward()
+    assert int(d.get("ncon", (1,), np.int32)[0]) == 4                    # upright arm: only the cube on the table
+    # fold the arm forward until link4 / link5 press on the table top
+    rng = np.random.default_rng(3)
+    found = None
+    for _ in range(20000):
+        q[:6] = rng.uniform(-2.5, 2.5, 6)
+        d.set_state(qpos=q, qvel=np.zeros(18)); d.forward()
+        n = int(d.get("ncon", (1,), np.int32)[0])
+        nefc = int(d.get("nefc", (1,), np.int32)[0])
+        if n == 6 and nefc == 7 + 2 * 4 + 4 * 6:                         # exactly one mesh pair (2 x condim 3) + the cube's four (condim 4)
+            found = q.copy(); break
+    assert found is not None
+    J = d.get("efc_J", (224, 24))[7:7 + 8, :18]
+    pos = d.get("efc_pos", (224,))[7:7 + 8]
+    assert np.allclose(J[:4], J[4:8]) and np.allclose(pos[:4], pos[4:8]) and pos[0] < 0        # the two copies: identical contacts
+    assert np.abs(J[:, 6:]).max() == 0.0 and np.abs(J[:, :6]).max() > 0                         # arm dofs only
+    # the mesh proxies: 26 support points, 78-89 % of the hull's volume
+    for name in ("link1", "link2", "link3", "link4", "link5", "link6", "flange", "gripper_base"):
+        mm = tab["meshes"][name]
+        assert len(mm["support"]) == 26 and 0.75 < mm["support_volume"] / mm["hull_volume"] < 0.92 and mm["hull_nvert"] > 500
