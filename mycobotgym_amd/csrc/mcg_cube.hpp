@@ -744,39 +744,157 @@ struct CubeSys {
     o[6] = sel(side, v[8], v[6]); o[7] = sel(side, v[9], v[7]);
   }
 
-  // Iteration structure (round 2).  A contact is walked ONCE per Newton iteration: the pass that checks the active set at the new
-  // point x also assembles the system of the set it finds there (the first FULL_STEPS iterations move to x with a full step, so the
-  // next set is known contact by contact), instead of a consistency pass followed by an assembly pass that both rebuild the
-  // contact's rows.  Pass P0 does the same for the warm start (initial masks + first assembly).  Only the fallback iterations (exact
-  // line search, from any point) keep the separate passes, because their next point is known after the search only.
-  template <class BuildH>
-  MCG_DEV void solve_coupled(BuildH& build_H, const real* g0, const real* Dl, const real* arefl, const real* sgl,
-                             const real* qdr, real* ar) {
-    derive(model());
-    real ac[6];
-    _Pragma("unroll") for (int k = 0; k < 6; k++) ac[k] = a_c[k];
-    bool actl[10];
-    _Pragma("unroll") for (int j = 0; j < 10; j++) actl[j] = (sgl[j] != 0) && (sgl[j] * ar[j] - arefl[j] < 0);
-    bool conv = false;
-    real xr[NB], xc[6];
-    real gr[NB], Hc[21], gc[6];
-    MCG_COUNT(CN_COUPLED);
+  // ---- twist space (round 2).  Every contact that involves the cube -- table-cube, pad-cube -- acts on a RELATIVE TWIST of two rigid
+  // bodies: r = twist(cube) - twist(pad of the side) (or - 0 for the table), a 6-vector [v at the cube centre ; omega] in the world
+  // frame.  Its four basis rows are e = [dir ; lever x dir] (normal, two tangents) and [0 ; n] (torsion), lever = pos - cube centre:
+  // 3 cross products instead of 8 joint-by-joint rows + the cube's.  sum_rows D j j^T of all contacts of a class is accumulated as ONE
+  // 6x6 matrix A_class = sum E^T W E (and b_class = sum E^T t) in registers, and mapped to the dofs once per Newton iteration through
+  // the twist columns c_j = [(anchor_j - centre) x axis_j ; axis_j] of the pad's chain and T_c = diag(I, Rc) of the cube:
+  //    Hc += T_c^T (A_0 + A_1 + A_2) T_c,  Cm[j] -= T_c^T A_s c_j,  G[j][k] += c_k^T A_s c_j,  gr[j] -= c_j^T b_s,  gc += T_c^T b.
+  // A contact costs ~400 instructions per pass (was ~2 000 with per-entry LDS read-modify-writes of G and Cm), the mapping ~1 500 per
+  // iteration.  Contacts between a static geom and the robot alone (table / ground - pad, - arm mesh) keep the dof-space path
+  // (contact_of / add_contact below), executed only when a lane of the wave holds one at that list position.
+  struct TwistCols { real c[10][6]; };          // arm 0..5, gear / finger right (6, 7), gear / finger left (8, 9)
+  MCG_DEV void twist_cols(TwistCols& T) const {
+    _Pragma("unroll") for (int j = 0; j < 10; j++) {
+      real ax[3], d[3], v[3];
+      _Pragma("unroll") for (int k = 0; k < 3; k++) { ax[k] = S.ld(LDS_WJ + j*6 + k); d[k] = S.ld(LDS_WJ + j*6 + 3 + k) - Cb.pos[k]; }
+      cross(d, ax, v);
+      // a side without a pad-cube contact in this lane: its gear / finger frames may be stale LDS contents (pads not posed)
+      const bool ok = (j < 6) || touch[(j - 6) >> 1];
+      _Pragma("unroll") for (int k = 0; k < 3; k++) { T.c[j][k] = sel(ok, v[k], 0.0); T.c[j][3 + k] = sel(ok, ax[k], 0.0); }
+    }
+  }
+  // relative twists of the three classes for cube vector vc (v ; omega body frame) and robot vector vr (12)
+  struct Twists { real r[3][6]; };
+  MCG_DEV void rel_twists(const TwistCols& T, const real* vc, const real* vr, Twists& W) const {
+    real tc[6], ua[6], us[2][6];
+    _Pragma("unroll") for (int k = 0; k < 3; k++) { tc[k] = vc[k]; tc[3 + k] = Rc[3*k]*vc[3] + Rc[3*k+1]*vc[4] + Rc[3*k+2]*vc[5]; }
+    _Pragma("unroll") for (int k = 0; k < 6; k++) {
+      ua[k] = 0;
+      _Pragma("unroll") for (int j = 0; j < 6; j++) ua[k] = fma(T.c[j][k], vr[j], ua[k]);
+      us[0][k] = fma(T.c[7][k], vr[7], fma(T.c[6][k], vr[6], ua[k]));
+      us[1][k] = fma(T.c[9][k], vr[9], fma(T.c[8][k], vr[8], ua[k]));
+      W.r[0][k] = tc[k]; W.r[1][k] = tc[k] - us[0][k]; W.r[2][k] = tc[k] - us[1][k];
+    }
+  }
+  struct TwistRows { real e[3][6], n[3]; real D, kterm; int type, mask; bool tw; };     // e[3] = [0 ; n]
+  MCG_DEV void twist_rows(int c, TwistRows& E) const {
+    const int b = LDS_CON + c * CON_STRIDE;
+    real lev[3], dir[3][3];
+    _Pragma("unroll") for (int k = 0; k < 3; k++) { lev[k] = S.ld(b + k) - Cb.pos[k]; dir[0][k] = S.ld(b + 3 + k); dir[1][k] = S.ld(b + 6 + k); dir[2][k] = S.ld(b + 9 + k); }
+    _Pragma("unroll") for (int r = 0; r < 3; r++) { real x[3]; cross(lev, dir[r], x); _Pragma("unroll") for (int k = 0; k < 3; k++) { E.e[r][k] = dir[r][k]; E.e[r][3 + k] = x[k]; } }
+    _Pragma("unroll") for (int k = 0; k < 3; k++) E.n[k] = dir[0][k];
+    E.type = sel((c < ncon), (int)S.ld(b + 15), 0);
+    E.tw = (c < ncon) && E.type < PAIR_TABLE_PADR;
+    E.D = sel(E.tw, S.ld(b + 13), 0.0); E.kterm = S.ld(b + 14);
+    E.mask = sel(E.tw, (int)S.ld(LDS_ACT + c), 0);
+  }
+  MCG_DEV static void tdots(const TwistRows& E, const real* r, real* o) {
+    _Pragma("unroll") for (int b = 0; b < 3; b++) { o[b] = 0; _Pragma("unroll") for (int k = 0; k < 6; k++) o[b] = fma(E.e[b][k], r[k], o[b]); }
+    o[3] = E.n[0]*r[3] + E.n[1]*r[4] + E.n[2]*r[5];
+  }
+  MCG_DEV static void pick_twist(const Twists& W, int type, real* r) {
+    _Pragma("unroll") for (int k = 0; k < 6; k++) r[k] = sel(type == PAIR_PADR_CUBE, W.r[1][k], sel(type == PAIR_PADL_CUBE, W.r[2][k], W.r[0][k]));
+  }
+  static constexpr int LDS_DV = LDS_POLY + 16;     // basis . velocity of every twist-space contact, 4 per contact (the clip polygons are dead;
+                                                   // slots 0..3 of that area are the split kernels' flags, read by other waves after S2)
+  static_assert(16 + 4 * MAXCON <= 64, "velocity terms exceed the clip-polygon slots");
 
-    // G <- H_eq + active limit rows, parked in LDS; Cm <- 0; right-hand sides and the cube block start from their smooth parts
-    auto begin_assembly = [&](const bool* act_) {
-      {
-        real L[NB * (NB + 1) / 2];
-        build_H(L, act_);
-        static_for<NB>([&](auto I) { constexpr int i = I; static_for<i + 1>([&](auto Jj) { constexpr int j = Jj;
-          if constexpr (PAT_H.nz[i][j]) S.st(GA + tri(i, j), L[tri(i, j)]); else if constexpr (PAT_G.nz[i][j]) S.st(GA + tri(i, j), 0.0); }); });
-        _Pragma("unroll") for (int k = 0; k < 60; k++) S.st(CM + k, 0.0);
+  // Iteration structure.  A contact is walked ONCE per Newton iteration: the pass that checks the active set at the new point x also
+  // assembles the system of the set it finds there (the first FULL_STEPS iterations move to x with a full step, so the next set is
+  // known contact by contact), instead of a consistency pass followed by an assembly pass.  Pass P0 does the same for the warm start
+  // (initial masks + first assembly).  Only the fallback iterations (exact line search, from any point) keep the separate passes,
+  // because their next point is known after the search only.
+  //
+  // Register files, not instructions, set the pace here (one wave per SIMD: a dependent scratch reload is 174 clocks).  As one
+  // function the solve needs ~770 VGPRs' worth of live values and the compiler reloads ~10 % of all operands from scratch, one at a
+  // time.  So it is cut into PHASES, each a function of its own (__noinline__) with its own register allocation, that exchange
+  // state through one struct in memory (CoupledMem, in the driver's frame): assemble (contact pass + mapping), Schur + LDL + solve,
+  // line search.  Each phase loads what it needs in a batch, works in registers, and stores its results in a batch.
+  struct CoupledMem {
+    real g0[NB], Dl[10], arefl[10], sgl[10], qd[NB];      // inputs, constant during the solve
+    real ar[NB], ac[6], xr[NB], xc[6];                    // iterate and Newton candidate
+    real gr[NB], Hc[21], gc[6];                           // the register part of the Newton system (G, Cm are in LDS)
+    int actl, conv;                                       // active limit rows (bit j), lane has converged
+  };
+  enum { PASS_WARM = 0, PASS_FUSED = 1, PASS_REBUILD = 2 };
+
+  // Phase A.  System of the active set found at the pass's point: PASS_WARM the warm start (also stores every contact's velocity
+  // term), PASS_FUSED the candidate x (checks it against the assumed set, commits the step; returns true when every lane is done),
+  // PASS_REBUILD the iterate with the masks the line search left in LDS.
+  // (Measured: a phase that first copies the object into registers -- through `this` every field is a flat load, repeated after LDS
+  // stores because a generic pointer may alias LDS -- is 10 % SLOWER: the extra live registers cost more reloads than the flat loads.)
+  template <bool ADD_M>
+  __device__ __noinline__ bool coupled_assemble(CoupledMem* Mm, int mode) { return coupled_assemble_impl<ADD_M>(Mm, mode); }
+  template <bool ADD_M>
+  MCG_DEV bool coupled_assemble_impl(CoupledMem* Mm, int mode) {
+    real pr_[NB], pc_[6];                        // the pass's point
+    const bool at_x = mode == PASS_FUSED;
+    for (int i = 0; i < NB; i++) pr_[i] = at_x ? Mm->xr[i] : Mm->ar[i];
+    _Pragma("unroll") for (int d = 0; d < 6; d++) pc_[d] = at_x ? Mm->xc[d] : Mm->ac[d];
+    const bool conv = Mm->conv != 0;
+    const int actl = Mm->actl;
+    int act = 0;
+    bool same = true;
+    {
+      real sgl[10], arefl[10];
+      _Pragma("unroll") for (int j = 0; j < 10; j++) { sgl[j] = Mm->sgl[j]; arefl[j] = Mm->arefl[j]; }
+      _Pragma("unroll") for (int j = 0; j < 10; j++) act |= ((sgl[j] != 0) && (sgl[j] * pr_[j] - arefl[j] < 0)) ? (1 << j) : 0;
+      if (mode == PASS_REBUILD) act = actl;
+      same = act == actl;
+    }
+    MCG_TICK(ST_A_ENTRY);
+    // G <- H_eq + active limit rows, parked in LDS; Cm <- 0
+    {
+      real L[NB * (NB + 1) / 2];
+      static_for<NB>([&](auto I) { constexpr int i = I;
+        static_for<i + 1>([&](auto Jj) { constexpr int j = Jj;
+          if constexpr (PAT_E.nz[i][j]) {
+            L[tri(i, j)] = S.ld(LDS_HEQ + tri(i, j));
+            if constexpr (ADD_M && PAT_M.nz[i][j]) L[tri(i, j)] += S.ld(LDS_M + tri(i, j));
+          } else if constexpr (PAT_H.nz[i][j]) L[tri(i, j)] = 0.0; }); });
+      static_for<10>([&](auto I) { constexpr int j = I; L[tri(j, j)] += ((act >> j) & 1) ? Mm->Dl[j] : 0.0; });
+      static_for<NB>([&](auto I) { constexpr int i = I; static_for<i + 1>([&](auto Jj) { constexpr int j = Jj;
+        if constexpr (PAT_H.nz[i][j]) S.st(GA + tri(i, j), L[tri(i, j)]); else if constexpr (PAT_G.nz[i][j]) S.st(GA + tri(i, j), 0.0); }); });
+      _Pragma("unroll") for (int k = 0; k < 60; k++) S.st(CM + k, 0.0);
+    }
+    MCG_TICK(ST_A_G);
+    real At[3][21], bt[3][6];                    // twist-space accumulators: table-cube, right pad-cube, left pad-cube
+    _Pragma("unroll") for (int q = 0; q < 3; q++) { _Pragma("unroll") for (int k = 0; k < 21; k++) At[q][k] = 0; _Pragma("unroll") for (int k = 0; k < 6; k++) bt[q][k] = 0; }
+    real grs[10];                                // static contacts' part of the robot right-hand side
+    _Pragma("unroll") for (int j = 0; j < 10; j++) grs[j] = 0;
+
+    // a twist-space contact's pyramid rows with the active set `mask` into its class accumulators; dv = its basis . velocity
+    auto add_twist = [&](const TwistRows& E, int mask, const real* dv) {
+      const bool padc = E.type != PAIR_TABLE_CUBE;
+      const real Bc = sel(padc, B_pc, B_tc);
+      real W00 = 0, t0 = 0, W0[3], Wd[3], t[3];
+      static_for<3>([&](auto Kk) { constexpr int k = Kk; const real m = sel(padc, mu_pc[k], mu_tc[k]);
+        const real arp = -Bc * fma(m, dv[1 + k], dv[0]) - E.kterm, arm = -Bc * fma(-m, dv[1 + k], dv[0]) - E.kterm;
+        const real wp = sel(((mask >> (2 * k)) & 1) != 0, E.D, 0.0), wm = sel(((mask >> (2 * k + 1)) & 1) != 0, E.D, 0.0);
+        W00 += wp + wm; t0 = fma(wp, arp, fma(wm, arm, t0));
+        W0[k] = m * (wp - wm); Wd[k] = m * m * (wp + wm); t[k] = m * (wp * arp - wm * arm); });
+      // U_b = sum_b' W_bb' e_b' (arrow matrix), then dA = sum_b e_b U_b^T (symmetric), db = sum_b e_b t_b
+      real U[4][6], dA[21], db[6];
+      _Pragma("unroll") for (int d = 0; d < 6; d++) {
+        const real e3 = d < 3 ? 0.0 : E.n[d < 3 ? 0 : d - 3];
+        U[0][d] = W00 * E.e[0][d] + W0[0] * E.e[1][d] + W0[1] * E.e[2][d] + W0[2] * e3;
+        U[1][d] = W0[0] * E.e[0][d] + Wd[0] * E.e[1][d];
+        U[2][d] = W0[1] * E.e[0][d] + Wd[1] * E.e[2][d];
+        U[3][d] = W0[2] * E.e[0][d] + Wd[2] * e3;
+        db[d] = E.e[0][d] * t0 + E.e[1][d] * t[0] + E.e[2][d] * t[1] + e3 * t[2];
       }
-      for (int i = 0; i < NB; i++) gr[i] = g0[i];
-      _Pragma("unroll") for (int j = 0; j < 10; j++) gr[j] += act_[j] ? sgl[j] * Dl[j] * arefl[j] : 0.0;
-      _Pragma("unroll") for (int k = 0; k < 21; k++) Hc[k] = 0;
-      _Pragma("unroll") for (int k = 0; k < 6; k++) { Hc[tri(k, k)] = Md[k]; gc[k] = fs[k]; }
+      static_for<6>([&](auto Dd) { constexpr int d = Dd; static_for<d + 1>([&](auto Ee) { constexpr int e = Ee;
+        const real e3 = d < 3 ? 0.0 : E.n[d < 3 ? 0 : d - 3];
+        dA[tri(d, e)] = E.e[0][d] * U[0][e] + E.e[1][d] * U[1][e] + E.e[2][d] * U[2][e] + e3 * U[3][e]; }); });
+      // the lane's class takes the update (weights are zero for lanes without a live twist-space contact here)
+      static_for<3>([&](auto Qq) { constexpr int q = Qq; const real on = (E.type == q) ? 1.0 : 0.0;
+        _Pragma("unroll") for (int k = 0; k < 21; k++) At[q][k] = fma(on, dA[k], At[q][k]);
+        _Pragma("unroll") for (int k = 0; k < 6; k++) bt[q][k] = fma(on, db[k], bt[q][k]); });
     };
-    // one contact's pyramid rows with the active set `mask` into Hc, gc, gr (registers) and G, Cm (LDS); dv = its basis . velocity
+    static_assert(PAIR_TABLE_CUBE == 0 && PAIR_PADR_CUBE == 1 && PAIR_PADL_CUBE == 2, "twist classes are the pair codes");
+    // one dof-space (static geom - robot) contact's pyramid rows with the active set `mask` into grs (registers) and G (LDS)
     auto add_contact = [&](const Coupled& K, int mask, const real* dv, bool live) {
       real W00 = 0, t0 = 0, W0[3], Wd[3], t[3];
       static_for<3>([&](auto Kk) { constexpr int k = Kk; const real m = K.mu[k];
@@ -784,234 +902,379 @@ struct CubeSys {
         const real wp = sel(((mask >> (2 * k)) & 1) != 0, K.D, 0.0), wm = sel(((mask >> (2 * k + 1)) & 1) != 0, K.D, 0.0);
         W00 += wp + wm; t0 = fma(wp, arp, fma(wm, arm, t0));
         W0[k] = m * (wp - wm); Wd[k] = m * m * (wp + wm); t[k] = m * (wp * arp - wm * arm); });
-      // U_b = sum_b' W_bb' B_b' on the cube part (6) and the robot part (8)
-      real Uc[4][6];
-      _Pragma("unroll") for (int d = 0; d < 6; d++) {
-        Uc[0][d] = W00 * K.RC.Jn[d] + W0[0] * K.RC.J1[d] + W0[1] * K.RC.J2[d] + W0[2] * K.RC.Jt[d];
-        Uc[1][d] = W0[0] * K.RC.Jn[d] + Wd[0] * K.RC.J1[d];
-        Uc[2][d] = W0[1] * K.RC.Jn[d] + Wd[1] * K.RC.J2[d];
-        Uc[3][d] = W0[2] * K.RC.Jn[d] + Wd[2] * K.RC.Jt[d];
-        gc[d] += K.RC.Jn[d] * t0 + K.RC.J1[d] * t[0] + K.RC.J2[d] * t[1] + K.RC.Jt[d] * t[2];
+      real Ur[4][8];
+      _Pragma("unroll") for (int j = 0; j < 8; j++) {
+        Ur[0][j] = W00 * K.RP.Jn[j] + W0[0] * K.RP.J1[j] + W0[1] * K.RP.J2[j] + W0[2] * K.RP.Jt[j];
+        Ur[1][j] = W0[0] * K.RP.Jn[j] + Wd[0] * K.RP.J1[j];
+        Ur[2][j] = W0[1] * K.RP.Jn[j] + Wd[1] * K.RP.J2[j];
+        Ur[3][j] = W0[2] * K.RP.Jn[j] + Wd[2] * K.RP.Jt[j];
       }
-      static_for<6>([&](auto Dd) { constexpr int d = Dd; static_for<d + 1>([&](auto Ee) { constexpr int e = Ee;
-        Hc[tri(d, e)] += K.RC.Jn[d] * Uc[0][e] + K.RC.J1[d] * Uc[1][e] + K.RC.J2[d] * Uc[2][e] + K.RC.Jt[d] * Uc[3][e]; }); });
-      if (__any(K.pad && live)) {              // wave-uniform: a table-cube contact has no robot rows
-        real Ur[4][8];
-        _Pragma("unroll") for (int j = 0; j < 8; j++) {
-          Ur[0][j] = W00 * K.RP.Jn[j] + W0[0] * K.RP.J1[j] + W0[1] * K.RP.J2[j] + W0[2] * K.RP.Jt[j];
-          Ur[1][j] = W0[0] * K.RP.Jn[j] + Wd[0] * K.RP.J1[j];
-          Ur[2][j] = W0[1] * K.RP.Jn[j] + Wd[1] * K.RP.J2[j];
-          Ur[3][j] = W0[2] * K.RP.Jn[j] + Wd[2] * K.RP.Jt[j];
-        }
-        const int gear = 6 + 2 * K.side, fing = 7 + 2 * K.side;                 // dof of local 6 / 7
-        const int rowoff[2] = {gear * (gear + 1) / 2, fing * (fing + 1) / 2};
-        static_for<8>([&](auto Ii) { constexpr int i = Ii;
-          const real gl = K.RP.Jn[i] * t0 + K.RP.J1[i] * t[0] + K.RP.J2[i] * t[1] + K.RP.Jt[i] * t[2];
-          if constexpr (i < 6) gr[i] += gl;
-          else if constexpr (i == 6) { gr[6] += sel(K.side, 0.0, gl); gr[8] += sel(K.side, gl, 0.0); }
-          else { gr[7] += sel(K.side, 0.0, gl); gr[9] += sel(K.side, gl, 0.0); }
-          // robot block, lower triangle in the contact's local order (arm 0..5, gear, finger: increasing dof index), and
-          // coupling block Cm[dof i][cube d].  All loads of a row first, then all stores: the addresses are per-lane, so
-          // a load behind a store could not be hoisted and every entry would pay the LDS latency alone.  (One ds_add_f64
-          // per entry instead -- no load at all -- measured no faster: the loop is not bound by these round trips.)
-          const int slot = (i < 6) ? i : (i == 6 ? gear : fing);
-          int kg[i + 1]; real og[i + 1], oc[6];
-          static_for<i + 1>([&](auto Jj) { constexpr int j = Jj;
-            if constexpr (i < 6) kg[j] = GA + tri(i, j);
-            else kg[j] = GA + rowoff[i - 6] + (j < 6 ? j : (j == 6 ? gear : fing));
-            og[j] = S.ld(kg[j]); });
-          static_for<6>([&](auto Dd) { constexpr int d = Dd; oc[d] = S.ld(CM + slot * 6 + d); });
-          static_for<i + 1>([&](auto Jj) { constexpr int j = Jj;
-            const real v = K.RP.Jn[i] * Ur[0][j] + K.RP.J1[i] * Ur[1][j] + K.RP.J2[i] * Ur[2][j] + K.RP.Jt[i] * Ur[3][j];
-            S.st(kg[j], og[j] + v); });
-          static_for<6>([&](auto Dd) { constexpr int d = Dd;
-            const real v = K.RP.Jn[i] * Uc[0][d] + K.RP.J1[i] * Uc[1][d] + K.RP.J2[i] * Uc[2][d] + K.RP.Jt[i] * Uc[3][d];
-            S.st(CM + slot * 6 + d, oc[d] + v); }); });
-      }
+      const int gear = 6 + 2 * K.side, fing = 7 + 2 * K.side;                 // dof of local 6 / 7
+      const int rowoff[2] = {gear * (gear + 1) / 2, fing * (fing + 1) / 2};
+      static_for<8>([&](auto Ii) { constexpr int i = Ii;
+        const real gl = K.RP.Jn[i] * t0 + K.RP.J1[i] * t[0] + K.RP.J2[i] * t[1] + K.RP.Jt[i] * t[2];
+        if constexpr (i < 6) grs[i] += gl;
+        else if constexpr (i == 6) { grs[6] += sel(K.side, 0.0, gl); grs[8] += sel(K.side, gl, 0.0); }
+        else { grs[7] += sel(K.side, 0.0, gl); grs[9] += sel(K.side, gl, 0.0); }
+        // robot block, lower triangle in the contact's local order (arm 0..5, gear, finger: increasing dof index).  All loads of a
+        // row first, then all stores: the addresses are per-lane, so a load behind a store could not be hoisted.
+        int kg[i + 1]; real og[i + 1];
+        static_for<i + 1>([&](auto Jj) { constexpr int j = Jj;
+          if constexpr (i < 6) kg[j] = GA + tri(i, j);
+          else kg[j] = GA + rowoff[i - 6] + (j < 6 ? j : (j == 6 ? gear : fing));
+          og[j] = S.ld(kg[j]); });
+        static_for<i + 1>([&](auto Jj) { constexpr int j = Jj;
+          const real v = K.RP.Jn[i] * Ur[0][j] + K.RP.J1[i] * Ur[1][j] + K.RP.J2[i] * Ur[2][j] + K.RP.Jt[i] * Ur[3][j];
+          S.st(kg[j], og[j] + v); }); });
     };
     // sign pattern of a contact's six pyramid rows at acceleration (basis dots da) given the velocity term (dv)
-    auto pattern = [&](const Coupled& K, const real* da, const real* dv) {
+    auto pattern_of = [&](const real* mu, real Bc, real kterm, bool dim3, const real* da, const real* dv) {
       int mask = 0;
-      static_for<3>([&](auto Kk) { constexpr int k = Kk; const real m = K.mu[k];
-        const real arp = -K.Bc * fma(m, dv[1 + k], dv[0]) - K.kterm, arm = -K.Bc * fma(-m, dv[1 + k], dv[0]) - K.kterm;
+      static_for<3>([&](auto Kk) { constexpr int k = Kk; const real m = mu[k];
+        const real arp = -Bc * fma(m, dv[1 + k], dv[0]) - kterm, arm = -Bc * fma(-m, dv[1 + k], dv[0]) - kterm;
         mask |= (fma(m, da[1 + k], da[0]) - arp < 0 ? (1 << (2 * k)) : 0) | (fma(-m, da[1 + k], da[0]) - arm < 0 ? (1 << (2 * k + 1)) : 0); });
-      return sel(K.dim3, mask & 15, mask);
+      return sel(dim3, mask & 15, mask);
     };
 
-    // ---- P0: masks at the warm start + first assembly
-    begin_assembly(actl);
-    for (int c = 0; __any(c < ncon); c++) {
-      Coupled K; contact_of(c, K);
-      real a8[8], v8[8], da[4], dv[4];
-      gather8(ar, K.side, a8); gather8(qdr, K.side, v8);
-      bdots(K, ac, a8, da); bdots(K, Cb.vel, v8, dv);
-      const int mask = pattern(K, da, dv);
-      if (c < ncon) S.st(LDS_ACT + c, (real)mask);
+    {
+      Twists RV, RP_;
+      {   // (the twist columns are rebuilt for the mapping below rather than kept live across the contact loop; likewise the point)
+        TwistCols T; twist_cols(T);
+        if (mode == PASS_WARM) { real qd[NB]; for (int i = 0; i < NB; i++) qd[i] = Mm->qd[i]; rel_twists(T, Cb.vel, qd, RV); }
+        if (mode != PASS_REBUILD) rel_twists(T, pc_, pr_, RP_);
+      }
+      MCG_TICK(ST_A_TWIST);
+      for (int c = 0; __any(c < ncon); c++) {
+        const int type = sel((c < ncon), (int)S.ld(LDS_CON + c * CON_STRIDE + 15), 0);
+        const bool tw = (c < ncon) && type < PAIR_TABLE_PADR, st = (c < ncon) && type >= PAIR_TABLE_PADR;
+        if (__any(tw)) {
+          TwistRows E; twist_rows(c, E);
+          real dv[4];
+          if (mode == PASS_WARM) {
+            real rv[6]; pick_twist(RV, E.type, rv); tdots(E, rv, dv);
+            if (tw) { _Pragma("unroll") for (int b = 0; b < 4; b++) S.st(LDS_DV + c * 4 + b, dv[b]); }
+          } else {
+            _Pragma("unroll") for (int b = 0; b < 4; b++) dv[b] = sel(tw, S.ld(LDS_DV + c * 4 + b), 0.0);      // (other lanes: stale slots)
+          }
+          int mask = E.mask;
+          if (mode != PASS_REBUILD) {
+            real rp[6], dp[4];
+            pick_twist(RP_, E.type, rp); tdots(E, rp, dp);
+            const bool padc = E.type != PAIR_TABLE_CUBE;
+            const real mu[3] = {sel(padc, mu_pc[0], mu_tc[0]), sel(padc, mu_pc[1], mu_tc[1]), sel(padc, mu_pc[2], mu_tc[2])};
+            mask = pattern_of(mu, sel(padc, B_pc, B_tc), E.kterm, false, dp, dv);
+            same = same && (!tw || mask == E.mask);
 #ifdef MCG_DBG_PRINT
-      if (blockIdx.x == 0 && threadIdx.x == 0 && c < ncon) printf("[P0] c %d type %d pad %d mask %d da %.4e %.4e %.4e %.4e dv %.4e %.4e %.4e %.4e D %.4e kterm %.4e Bc %.4e mu %.3e %.3e %.3e\n", c, K.type, (int)K.pad, mask, da[0], da[1], da[2], da[3], dv[0], dv[1], dv[2], dv[3], K.D, K.kterm, K.Bc, K.mu[0], K.mu[1], K.mu[2]);
+            if (blockIdx.x == 0 && threadIdx.x == 0 && tw) printf("[pass %d] c %d type %d mask %d (was %d) dp %.4e %.4e %.4e %.4e dv %.4e %.4e %.4e %.4e\n", mode, c, E.type, mask, E.mask, dp[0], dp[1], dp[2], dp[3], dv[0], dv[1], dv[2], dv[3]);
 #endif
-      add_contact(K, mask, dv, c < ncon);
+            if (tw && !conv) S.st(LDS_ACT + c, (real)mask);
+          }
+          add_twist(E, mask, dv);
+        }
+        if (__any(st)) {
+          Coupled K; contact_of(c, K);
+          K.D = sel(st, K.D, 0.0); K.mask = sel(st, K.mask, 0);
+          real v8[8], dv[4], qd[NB];
+          const real zero6[6] = {0, 0, 0, 0, 0, 0};
+          for (int i = 0; i < NB; i++) qd[i] = Mm->qd[i];
+          gather8(qd, K.side, v8); bdots(K, zero6, v8, dv);
+          int mask = K.mask;
+          if (mode != PASS_REBUILD) {
+            real p8[8], dp[4], ps[NB];
+            for (int i = 0; i < NB; i++) ps[i] = at_x ? Mm->xr[i] : Mm->ar[i];
+            gather8(ps, K.side, p8); bdots(K, zero6, p8, dp);
+            mask = pattern_of(K.mu, K.Bc, K.kterm, K.dim3, dp, dv);
+            same = same && (!st || mask == K.mask);
+            if (st && !conv) S.st(LDS_ACT + c, (real)mask);
+          }
+          add_contact(K, mask, dv, st);
+        }
+      }
+      MCG_TICK(ST_A_LOOP);
+      // ---- the accumulators into the dof-space system: cube block and right-hand sides (registers -> memory), G and Cm in LDS
+      real gr[NB], Hc[21], gc[6];
+      for (int i = 0; i < NB; i++) gr[i] = Mm->g0[i];
+      _Pragma("unroll") for (int j = 0; j < 10; j++) gr[j] += (((act >> j) & 1) ? Mm->sgl[j] * Mm->Dl[j] * Mm->arefl[j] : 0.0) + grs[j];
+      _Pragma("unroll") for (int k = 0; k < 21; k++) Hc[k] = 0;
+      _Pragma("unroll") for (int k = 0; k < 6; k++) { Hc[tri(k, k)] = Md[k]; gc[k] = fs[k]; }
+      {
+        real As[21], bs[6];
+        _Pragma("unroll") for (int k = 0; k < 21; k++) As[k] = At[0][k] + At[1][k] + At[2][k];
+        _Pragma("unroll") for (int k = 0; k < 6; k++) bs[k] = bt[0][k] + bt[1][k] + bt[2][k];
+        // T_c^T As T_c, T_c = diag(I, Rc): [vv, vw Rc ; . , Rc^T ww Rc]
+        static_for<3>([&](auto Dd) { constexpr int d = Dd; static_for<d + 1>([&](auto Ee) { constexpr int e = Ee; Hc[tri(d, e)] += As[tri(d, e)]; }); });
+        real X[3][3];
+        static_for<3>([&](auto Dd) { constexpr int d = Dd; static_for<3>([&](auto Ee) { constexpr int e = Ee;       // Hc[3+d][e] = sum_k Rc[k][d] As[3+k][e]
+          Hc[tri(3 + d, e)] += Rc[d] * As[tri(3, e)] + Rc[3 + d] * As[tri(4, e)] + Rc[6 + d] * As[tri(5, e)]; }); });
+        static_for<3>([&](auto Kk) { constexpr int k = Kk; static_for<3>([&](auto Ee) { constexpr int e = Ee;       // X = ww Rc
+          X[k][e] = As[tri(3 + k, 3)] * Rc[e] + As[tri(3 + k, 4)] * Rc[3 + e] + As[tri(3 + k, 5)] * Rc[6 + e]; }); });
+        static_for<3>([&](auto Dd) { constexpr int d = Dd; static_for<d + 1>([&](auto Ee) { constexpr int e = Ee;
+          Hc[tri(3 + d, 3 + e)] += Rc[d] * X[0][e] + Rc[3 + d] * X[1][e] + Rc[6 + d] * X[2][e]; }); });
+        _Pragma("unroll") for (int k = 0; k < 3; k++) { gc[k] += bs[k]; gc[3 + k] += Rc[k] * bs[3] + Rc[3 + k] * bs[4] + Rc[6 + k] * bs[5]; }
+      }
+      if (__any(touch[0] || touch[1])) {          // wave-uniform: a pad-cube contact reaches the robot's dofs
+        TwistCols T; twist_cols(T);
+        real A12[21], b12[6];
+        _Pragma("unroll") for (int k = 0; k < 21; k++) A12[k] = At[1][k] + At[2][k];
+        _Pragma("unroll") for (int k = 0; k < 6; k++) b12[k] = bt[1][k] + bt[2][k];
+        static_for<10>([&](auto Ii) { constexpr int i = Ii;
+          constexpr int cls = i < 6 ? 0 : (i < 8 ? 1 : 2);            // 0: both sides (arm), 1: right chain, 2: left chain
+          const real* A = cls == 0 ? A12 : At[cls];
+          const real* bb = cls == 0 ? b12 : bt[cls];
+          real pv[6];
+          _Pragma("unroll") for (int d = 0; d < 6; d++) { pv[d] = 0; _Pragma("unroll") for (int e = 0; e < 6; e++) pv[d] = fma(A[tri(d, e)], T.c[i][e], pv[d]); }
+          real gl = 0;
+          _Pragma("unroll") for (int d = 0; d < 6; d++) gl = fma(T.c[i][d], bb[d], gl);
+          gr[i] -= gl;
+          // G row i: the dofs k <= i of the same chain (arm dofs belong to both)
+          constexpr int nk = i < 8 ? i + 1 : 6 + (i - 8) + 1;
+          int kg[nk]; real og[nk], oc[6];
+          static_for<nk>([&](auto Kk) { constexpr int kk = Kk; constexpr int k = (i >= 8 && kk >= 6) ? kk + 2 : kk;
+            kg[kk] = GA + tri(i, k); og[kk] = S.ld(kg[kk]); });
+          _Pragma("unroll") for (int d = 0; d < 6; d++) oc[d] = S.ld(CM + i * 6 + d);
+          static_for<nk>([&](auto Kk) { constexpr int kk = Kk; constexpr int k = (i >= 8 && kk >= 6) ? kk + 2 : kk;
+            real v = 0;
+            _Pragma("unroll") for (int d = 0; d < 6; d++) v = fma(T.c[k][d], pv[d], v);
+            S.st(kg[kk], og[kk] + v); });
+          _Pragma("unroll") for (int d = 0; d < 3; d++) {
+            S.st(CM + i * 6 + d, oc[d] - pv[d]);
+            S.st(CM + i * 6 + 3 + d, oc[3 + d] - (Rc[d] * pv[3] + Rc[3 + d] * pv[4] + Rc[6 + d] * pv[5]));
+          } });
+      }
+      MCG_TICK(ST_A_MAP);
+      for (int i = 0; i < NB; i++) Mm->gr[i] = gr[i];
+      _Pragma("unroll") for (int k = 0; k < 21; k++) Mm->Hc[k] = Hc[k];
+      _Pragma("unroll") for (int k = 0; k < 6; k++) Mm->gc[k] = gc[k];
     }
-    bool assembled = true;
+    MCG_TICK(ST_A_STORE);
+    if (mode == PASS_WARM) { Mm->actl = act; return false; }
+    if (mode == PASS_REBUILD) return false;
+    // commit the full step: a lane that finishes takes x; the others move to x: both take x; converged lanes keep theirs
+    const bool finish = !conv && same;
+    const bool nconv = conv || finish;
+    const bool take = finish || !nconv;
+    for (int i = 0; i < NB; i++) Mm->ar[i] = sel(take, Mm->xr[i], Mm->ar[i]);
+    _Pragma("unroll") for (int d = 0; d < 6; d++) Mm->ac[d] = sel(take, Mm->xc[d], Mm->ac[d]);
+    Mm->actl = sel(nconv && !finish, actl, act);
+    Mm->conv = nconv ? 1 : 0;
+    return !__any(!nconv);
+  }
+
+  // Phase B.  Schur complement on the cube block (Hc = L D L^T, W_i = L^-1 Cm_i kept in place of Cm_i), sparse L^T D L of the robot
+  // block, both solves: (xr, xc) <- the Newton candidate of the assembled system.
+  __device__ __noinline__ void coupled_schur_solve(CoupledMem* Mm) { coupled_schur_solve_impl(Mm); }
+  MCG_DEV void coupled_schur_solve_impl(CoupledMem* Mm) {
+    real gr[NB], Hc[21], gc[6], xr[NB], xc[6];
+    for (int i = 0; i < NB; i++) gr[i] = Mm->gr[i];
+    _Pragma("unroll") for (int k = 0; k < 21; k++) Hc[k] = Mm->Hc[k];
+    _Pragma("unroll") for (int k = 0; k < 6; k++) gc[k] = Mm->gc[k];
+    real dinvc[6], yl[6];
+    spd_factor<6>(Hc, dinvc);
+    _Pragma("unroll") for (int d = 0; d < 6; d++) yl[d] = gc[d];
+    spd_forward<6>(Hc, yl);
+    real Wm[10][6];                              // W_i = L^-1 Cm_i, kept in registers for the Schur update and the back-substitution
+    static_for<10>([&](auto Ii) { constexpr int i = Ii;
+      _Pragma("unroll") for (int d = 0; d < 6; d++) Wm[i][d] = S.ld(CM + i * 6 + d); });
+    static_for<10>([&](auto Ii) { constexpr int i = Ii;
+      spd_forward<6>(Hc, Wm[i]);
+      real sdot = 0;
+      _Pragma("unroll") for (int d = 0; d < 6; d++) sdot = fma(Wm[i][d] * dinvc[d], yl[d], sdot);
+      gr[i] -= sdot; });
+    {
+      real G[NB * (NB + 1) / 2], dinv[NB];
+      static_for<NB>([&](auto I) { constexpr int i = I; static_for<i + 1>([&](auto Jj) { constexpr int j = Jj;
+        if constexpr (PAT_G.nz[i][j]) G[tri(i, j)] = S.ld(GA + tri(i, j)); }); });
+      static_for<10>([&](auto Ii) { constexpr int i = Ii;
+        real wi[6];
+        _Pragma("unroll") for (int d = 0; d < 6; d++) wi[d] = Wm[i][d] * dinvc[d];
+        static_for<i + 1>([&](auto Jj) { constexpr int j = Jj;
+          real sdot = 0;
+          _Pragma("unroll") for (int d = 0; d < 6; d++) sdot = fma(wi[d], Wm[j][d], sdot);
+          G[tri(i, j)] -= sdot; }); });
+      for (int i = 0; i < NB; i++) xr[i] = gr[i];
+      ldl_factor<PAT_G>(G, dinv);
+      ldl_solve<PAT_G>(G, dinv, xr);
+    }
+    {   // x_c = L^-T D^-1 (L^-1 g_c - sum_i W_i x_r[i])
+      real z[6];
+      _Pragma("unroll") for (int d = 0; d < 6; d++) z[d] = yl[d];
+      static_for<10>([&](auto Ii) { constexpr int i = Ii;
+        _Pragma("unroll") for (int d = 0; d < 6; d++) z[d] = fma(-Wm[i][d], xr[i], z[d]); });
+      _Pragma("unroll") for (int d = 0; d < 6; d++) z[d] *= dinvc[d];
+      spd_backward<6>(Hc, z);
+      _Pragma("unroll") for (int d = 0; d < 6; d++) xc[d] = z[d];
+    }
+    for (int i = 0; i < NB; i++) Mm->xr[i] = xr[i];
+    _Pragma("unroll") for (int d = 0; d < 6; d++) Mm->xc[d] = xc[d];
+  }
+
+  // Phase C.  Fallback iteration: consistency of the assumed set at the candidate x; lanes where it fails search the line from the
+  // iterate towards x exactly and re-mask there.  Returns true when every lane is done.
+  template <bool ADD_M>
+  __device__ __noinline__ bool coupled_linesearch(CoupledMem* Mm) { return coupled_linesearch_impl<ADD_M>(Mm); }
+  template <bool ADD_M>
+  MCG_DEV bool coupled_linesearch_impl(CoupledMem* Mm) {
+    real ar[NB], ac[6], pr[NB], pc[6], qd[NB], sgl[10], arefl[10];
+    for (int i = 0; i < NB; i++) { ar[i] = Mm->ar[i]; pr[i] = Mm->xr[i] - ar[i]; qd[i] = Mm->qd[i]; }
+    _Pragma("unroll") for (int d = 0; d < 6; d++) { ac[d] = Mm->ac[d]; pc[d] = Mm->xc[d] - ac[d]; }
+    _Pragma("unroll") for (int j = 0; j < 10; j++) { sgl[j] = Mm->sgl[j]; arefl[j] = Mm->arefl[j]; }
+    bool conv = Mm->conv != 0;
+    const int actl = Mm->actl;
+    bool same = true;
+    _Pragma("unroll") for (int j = 0; j < 10; j++) same = same && (((sgl[j] != 0) && (sgl[j] * Mm->xr[j] - arefl[j] < 0)) == (((actl >> j) & 1) != 0));
+    // r0 / dr of every contact row (from here on the row area of LDS holds line-search rows again: G and W are dead)
+    {
+      TwistCols T; twist_cols(T);
+      Twists RA, RP; rel_twists(T, ac, ar, RA); rel_twists(T, pc, pr, RP);
+      for (int c = 0; __any(c < ncon); c++) {
+        const int type = sel((c < ncon), (int)S.ld(LDS_CON + c * CON_STRIDE + 15), 0);
+        const bool tw = (c < ncon) && type < PAIR_TABLE_PADR, st = (c < ncon) && type >= PAIR_TABLE_PADR;
+        real da[4] = {0, 0, 0, 0}, dv[4] = {0, 0, 0, 0}, dp[4] = {0, 0, 0, 0}, mu[3] = {0, 0, 0}, Bc = 0, kterm = 0; int mask = 0; bool dim3 = false;
+        if (__any(tw)) {
+          TwistRows E; twist_rows(c, E);
+          real ra[6], rp[6], ta[4], tp_[4];
+          pick_twist(RA, E.type, ra); pick_twist(RP, E.type, rp);
+          tdots(E, ra, ta); tdots(E, rp, tp_);
+          const bool padc = E.type != PAIR_TABLE_CUBE;
+          _Pragma("unroll") for (int b = 0; b < 4; b++) { da[b] = ta[b]; dp[b] = tp_[b]; dv[b] = sel(tw, S.ld(LDS_DV + c * 4 + b), 0.0); }
+          _Pragma("unroll") for (int k = 0; k < 3; k++) mu[k] = sel(padc, mu_pc[k], mu_tc[k]);
+          Bc = sel(padc, B_pc, B_tc); kterm = E.kterm; mask = E.mask;
+        }
+        if (__any(st)) {
+          Coupled K; contact_of(c, K);
+          K.D = sel(st, K.D, 0.0); K.mask = sel(st, K.mask, 0);
+          real a8[8], v8[8], p8[8], sa[4], sv[4], sp[4];
+          gather8(ar, K.side, a8); gather8(qd, K.side, v8); gather8(pr, K.side, p8);
+          bdots(K, ac, a8, sa); bdots(K, Cb.vel, v8, sv); bdots(K, pc, p8, sp);
+          _Pragma("unroll") for (int b = 0; b < 4; b++) { da[b] = sel(st, sa[b], da[b]); dv[b] = sel(st, sv[b], dv[b]); dp[b] = sel(st, sp[b], dp[b]); }
+          _Pragma("unroll") for (int k = 0; k < 3; k++) mu[k] = sel(st, K.mu[k], mu[k]);
+          Bc = sel(st, K.Bc, Bc); kterm = sel(st, K.kterm, kterm); mask = sel(st, K.mask, mask); dim3 = st && K.dim3;
+        }
+        static_for<3>([&](auto Kk) { constexpr int k = Kk;
+          static_for<2>([&](auto Od) { constexpr int odd = Od; constexpr int r = 2 * k + odd;
+            const real m = odd ? -mu[k] : mu[k];
+            const bool absent = dim3 && k == 2;
+            const real r0 = sel(absent, 1.0, fma(m, da[1 + k], da[0]) - (-Bc * fma(m, dv[1 + k], dv[0]) - kterm)), jp = sel(absent, 0.0, fma(m, dp[1 + k], dp[0]));
+            if (c < ncon) { S.st(LDS_ROW + (c * 6 + r) * 2, r0); S.st(LDS_ROW + (c * 6 + r) * 2 + 1, jp); }      // absent: a row that never activates
+            same = same && (c >= ncon || ((r0 + jp) < 0) == (((mask >> r) & 1) != 0)); }); });
+      }
+    }
+    const bool finish = !conv && same;
+    for (int i = 0; i < NB; i++) ar[i] = sel(finish, ar[i] + pr[i], ar[i]);
+    _Pragma("unroll") for (int d = 0; d < 6; d++) ac[d] = sel(finish, ac[d] + pc[d], ac[d]);
+    conv = conv || finish;
+    if (__any(finish)) {
+      for (int i = 0; i < NB; i++) if (finish) Mm->ar[i] = Mm->xr[i];           // the candidate itself, not iterate + step (rounding)
+      _Pragma("unroll") for (int d = 0; d < 6; d++) if (finish) Mm->ac[d] = Mm->xc[d];
+    }
+    Mm->conv = conv ? 1 : 0;
+    if (!__any(!conv)) return true;
+    // line search: smooth part = robot quadratic with H0 = M + equality rows (no limits), cube diag M
+    MCG_COUNT(CN_COUPLED_LS);
+    real lin0 = 0, quad = 0;
+    real g0[NB], Dl[10];
+    for (int i = 0; i < NB; i++) g0[i] = Mm->g0[i];
+    _Pragma("unroll") for (int j = 0; j < 10; j++) Dl[j] = Mm->Dl[j];
+    {
+      real L[NB * (NB + 1) / 2];
+      static_for<NB>([&](auto I) { constexpr int i = I;
+        static_for<i + 1>([&](auto Jj) { constexpr int j = Jj;
+          if constexpr (PAT_E.nz[i][j]) {
+            L[tri(i, j)] = S.ld(LDS_HEQ + tri(i, j));
+            if constexpr (ADD_M && PAT_M.nz[i][j]) L[tri(i, j)] += S.ld(LDS_M + tri(i, j));
+          } else if constexpr (PAT_H.nz[i][j]) L[tri(i, j)] = 0.0; }); });
+      static_for<NB>([&](auto I) { constexpr int i = I; real ha = 0, hp = 0;
+        static_for<NB>([&](auto Jj) { constexpr int j = Jj;
+          if constexpr (PAT_H.nz[i > j ? i : j][i > j ? j : i]) { ha = fma(L[tri(i, j)], ar[j], ha); hp = fma(L[tri(i, j)], pr[j], hp); } });
+        lin0 += (ha - g0[i]) * pr[i]; quad += hp * pr[i]; });
+    }
+    _Pragma("unroll") for (int k = 0; k < 6; k++) { lin0 += (Md[k] * ac[k] - fs[k]) * pc[k]; quad += Md[k] * pc[k] * pc[k]; }
+    // limit rows join the piecewise part
+    real l_r0[10], l_dr[10];
+    _Pragma("unroll") for (int j = 0; j < 10; j++) { l_r0[j] = sgl[j] * ar[j] - arefl[j]; l_dr[j] = sgl[j] * pr[j]; }
+    // phi'(alpha) is piecewise linear and increasing: Newton on it (slope = quad + sum over active rows of D dr^2) lands
+    // exactly on the root once it is on the right piece; a bracket [lo, hi] with bisection as the fallback keeps it safe.
+    auto dphi = [&](real al, real& slope) {
+      real sacc = lin0 + al * quad; slope = quad;
+      dphi_rows(al, sacc, slope);
+      _Pragma("unroll") for (int j = 0; j < 10; j++) { const real rr = l_r0[j] + al * l_dr[j]; const bool on = sgl[j] != 0 && rr < 0;
+        sacc += sel(on, Dl[j] * rr * l_dr[j], 0.0); slope += sel(on, Dl[j] * l_dr[j] * l_dr[j], 0.0); }
+      return sacc;
+    };
+    real lo = 0, hi = 2, sl;
+    const bool beyond = dphi(hi, sl) < 0;
+    real al = 1.0;
+    for (int b = 0; b < 8; b++) {
+      const real f = dphi(al, sl);
+      const bool neg = f < 0;
+      lo = sel(neg, al, lo); hi = sel(neg, hi, al);
+      const real nw = al - f / sl;
+      const real nx = sel(nw > lo && nw < hi, nw, 0.5 * (lo + hi));
+      const bool moved = fabs(nx - al) > 1e-15 * fmax(1.0, fabs(al));     // on the root's own linear piece Newton stays put
+      al = nx;
+      if (!__any(moved && !conv && !beyond)) break;                         // wave-uniform exit
+    }
+    const real alpha = sel(beyond, 2.0, al);
+    int act = 0;
+    for (int i = 0; i < NB; i++) { ar[i] = ar[i] + alpha * pr[i]; if (!conv) Mm->ar[i] = ar[i]; }
+    _Pragma("unroll") for (int d = 0; d < 6; d++) { ac[d] = ac[d] + alpha * pc[d]; if (!conv) Mm->ac[d] = ac[d]; }
+    _Pragma("unroll") for (int j = 0; j < 10; j++) act |= ((sgl[j] != 0) && (sgl[j] * ar[j] - arefl[j] < 0)) ? (1 << j) : 0;
+    if (!conv) Mm->actl = act;
+    remask(alpha, conv);
+    return false;
+  }
+
+  // The driver: out of line itself, on copies of its inputs, so that the robot pipeline it is called from keeps its own registers.
+  // ADD_M: H_eq in LDS holds J^T D J only, M is added when it is read (split kernels that assemble the constraint part before M is
+  // published).
+  struct SolveIO {
+    Cube Cb; real dr[2]; unsigned long long pm_bits; int ncon; bool touch[2], any_pad;
+    real g0[NB], Dl[10], arefl[10], sgl[10], qd[NB], a[NB], a_c[6];
+  };
+  template <bool ADD_M>
+  static __device__ __noinline__ void solve_coupled_outlined(unsigned lds_column, SolveIO* io) {
+    const LS MS((LdsPtr)(uintptr_t)lds_column);
+    CubeSys CS(MS, io->Cb, io->dr);
+    CS.pm_bits = io->pm_bits;
+    CS.adopt(CS.model(), io->ncon, io->touch[0], io->touch[1], io->any_pad);
+    CoupledMem Mm;
+    for (int i = 0; i < NB; i++) { Mm.g0[i] = io->g0[i]; Mm.qd[i] = io->qd[i]; Mm.ar[i] = io->a[i]; }
+    _Pragma("unroll") for (int j = 0; j < 10; j++) { Mm.Dl[j] = io->Dl[j]; Mm.arefl[j] = io->arefl[j]; Mm.sgl[j] = io->sgl[j]; }
+    _Pragma("unroll") for (int k = 0; k < 6; k++) Mm.ac[k] = CS.a_c[k];
+    Mm.conv = 0; Mm.actl = 0;
+    MCG_COUNT(CN_COUPLED);
+    CS.template coupled_assemble<ADD_M>(&Mm, PASS_WARM);
     MCG_TICK(ST_C_MASK);
+    bool assembled = true;
     for (int it = 0; it < 50; it++) {
       MCG_COUNT(CN_COUPLED_IT);
-      if (!assembled) {                          // after a line-search iteration: the set at the point the search reached
-        begin_assembly(actl);
-        for (int c = 0; __any(c < ncon); c++) {
-          Coupled K; contact_of(c, K);
-          real v8[8], dv[4]; gather8(qdr, K.side, v8); bdots(K, Cb.vel, v8, dv);
-          add_contact(K, K.mask, dv, c < ncon);
-        }
-      }
-      MCG_TICK_PIN(gr, NB); MCG_TICK_PIN(gc, 6);
-      MCG_TICK(ST_C_ASSEMBLE);
-      // Schur complement on the cube block: Hc = L D L^T, W_i = L^-1 Cm_i (kept in place of Cm_i)
-      real dinvc[6], yl[6];
-      spd_factor<6>(Hc, dinvc);
-      _Pragma("unroll") for (int d = 0; d < 6; d++) yl[d] = gc[d];
-      spd_forward<6>(Hc, yl);
-      static_for<10>([&](auto Ii) { constexpr int i = Ii;
-        real w[6];
-        _Pragma("unroll") for (int d = 0; d < 6; d++) w[d] = S.ld(CM + i * 6 + d);
-        spd_forward<6>(Hc, w);
-        real sdot = 0;
-        _Pragma("unroll") for (int d = 0; d < 6; d++) { S.st(CM + i * 6 + d, w[d]); sdot = fma(w[d] * dinvc[d], yl[d], sdot); }
-        gr[i] -= sdot; });
-      {
-        real G[NB * (NB + 1) / 2], dinv[NB];
-        static_for<NB>([&](auto I) { constexpr int i = I; static_for<i + 1>([&](auto Jj) { constexpr int j = Jj;
-          if constexpr (PAT_G.nz[i][j]) G[tri(i, j)] = S.ld(GA + tri(i, j)); }); });
-        static_for<10>([&](auto Ii) { constexpr int i = Ii;
-          real wi[6];
-          _Pragma("unroll") for (int d = 0; d < 6; d++) wi[d] = S.ld(CM + i * 6 + d) * dinvc[d];
-          static_for<i + 1>([&](auto Jj) { constexpr int j = Jj;
-            real sdot = 0;
-            _Pragma("unroll") for (int d = 0; d < 6; d++) sdot = fma(wi[d], S.ld(CM + j * 6 + d), sdot);
-            G[tri(i, j)] -= sdot; }); });
-        for (int i = 0; i < NB; i++) xr[i] = gr[i];
-        MCG_TICK_PIN(xr, NB);
-        MCG_TICK(ST_C_SCHUR);
-        ldl_factor<PAT_G>(G, dinv);
-        ldl_solve<PAT_G>(G, dinv, xr);
-      }
-      {   // x_c = L^-T D^-1 (L^-1 g_c - sum_i W_i x_r[i])
-        real z[6];
-        _Pragma("unroll") for (int d = 0; d < 6; d++) z[d] = yl[d];
-        static_for<10>([&](auto Ii) { constexpr int i = Ii;
-          _Pragma("unroll") for (int d = 0; d < 6; d++) z[d] = fma(-S.ld(CM + i * 6 + d), xr[i], z[d]); });
-        _Pragma("unroll") for (int d = 0; d < 6; d++) z[d] *= dinvc[d];
-        spd_backward<6>(Hc, z);
-        _Pragma("unroll") for (int d = 0; d < 6; d++) xc[d] = z[d];
-      }
-      MCG_TICK_PIN(xr, NB); MCG_TICK_PIN(xc, 6);
+      if (!assembled) { CS.template coupled_assemble<ADD_M>(&Mm, PASS_REBUILD); MCG_TICK(ST_C_ASSEMBLE); }
+      CS.coupled_schur_solve(&Mm);
       MCG_TICK(ST_C_SOLVE);
-      bool same = true;
-      bool actx[10];
-      _Pragma("unroll") for (int j = 0; j < 10; j++) { actx[j] = (sgl[j] != 0) && (sgl[j] * xr[j] - arefl[j] < 0); same = same && (actx[j] == actl[j]); }
-
       if (it < FULL_STEPS) {
-        // ---- fused pass: active set at x against the assumed one, and the system of the set found at x (G, W of this iteration
-        // are dead: the solve above has consumed them)
-        begin_assembly(actx);
-        for (int c = 0; __any(c < ncon); c++) {
-          Coupled K; contact_of(c, K);
-          real x8[8], v8[8], dx[4], dv[4];
-          gather8(xr, K.side, x8); gather8(qdr, K.side, v8);
-          bdots(K, xc, x8, dx); bdots(K, Cb.vel, v8, dv);
-          const int mask = pattern(K, dx, dv);
-          same = same && (c >= ncon || mask == K.mask);
-#ifdef MCG_DBG_PRINT
-          if (blockIdx.x == 0 && threadIdx.x == 0 && c < ncon) printf("[it %d] c %d mask %d (was %d) dx %.4e %.4e %.4e %.4e xc2 %.6e conv %d\n", it, c, mask, K.mask, dx[0], dx[1], dx[2], dx[3], xc[2], (int)conv);
-#endif
-          if (c < ncon && !conv) S.st(LDS_ACT + c, (real)mask);
-          add_contact(K, mask, dv, c < ncon);
-        }
-        const bool finish = !conv && same;
-        conv = conv || finish;                 // a lane that finishes takes x; the others move to x with a full step: both take x
-        for (int i = 0; i < NB; i++) ar[i] = sel((finish || !conv), xr[i], ar[i]);
-        _Pragma("unroll") for (int d = 0; d < 6; d++) ac[d] = sel((finish || !conv), xc[d], ac[d]);
-        _Pragma("unroll") for (int j = 0; j < 10; j++) actl[j] = sel(conv && !finish, actl[j], actx[j]);
+        const bool done = CS.template coupled_assemble<ADD_M>(&Mm, PASS_FUSED);
         MCG_TICK(ST_C_CHECK);
-        if (!__any(!conv)) break;
+        if (done) break;
         assembled = true;
         continue;
       }
-
-      // ---- fallback iteration with the exact line search: consistency at (xr, xc); r0 / dr of every contact row
-      // (from here on the row area of LDS holds line-search rows again: G and W are dead)
-      real pr[NB], pc[6];
-      for (int i = 0; i < NB; i++) pr[i] = xr[i] - ar[i];
-      _Pragma("unroll") for (int d = 0; d < 6; d++) pc[d] = xc[d] - ac[d];
-      for (int c = 0; __any(c < ncon); c++) {
-        Coupled K; contact_of(c, K);
-        real a8[8], v8[8], p8[8], da[4], dv[4], dp[4];
-        gather8(ar, K.side, a8); gather8(qdr, K.side, v8); gather8(pr, K.side, p8);
-        bdots(K, ac, a8, da); bdots(K, Cb.vel, v8, dv); bdots(K, pc, p8, dp);
-        static_for<3>([&](auto Kk) { constexpr int k = Kk;
-          static_for<2>([&](auto Od) { constexpr int odd = Od; constexpr int r = 2 * k + odd;
-            const real m = odd ? -K.mu[k] : K.mu[k];
-            const bool absent = K.dim3 && k == 2;
-            const real r0 = sel(absent, 1.0, fma(m, da[1 + k], da[0]) - (-K.Bc * fma(m, dv[1 + k], dv[0]) - K.kterm)), jp = sel(absent, 0.0, fma(m, dp[1 + k], dp[0]));
-            if (c < ncon) { S.st(LDS_ROW + (c * 6 + r) * 2, r0); S.st(LDS_ROW + (c * 6 + r) * 2 + 1, jp); }      // absent: a row that never activates
-            same = same && (c >= ncon || ((r0 + jp) < 0) == (((K.mask >> r) & 1) != 0)); }); });
-      }
-      const bool finish = !conv && same;
-      for (int i = 0; i < NB; i++) ar[i] = sel(finish, xr[i], ar[i]);
-      _Pragma("unroll") for (int d = 0; d < 6; d++) ac[d] = sel(finish, xc[d], ac[d]);
-      conv = conv || finish;
-      MCG_TICK(ST_C_CHECK);
-      if (!__any(!conv)) break;
-      assembled = false;
-      // line search: smooth part = robot quadratic with H0 = M + equality rows (no limits), cube diag M
-      MCG_COUNT(CN_COUPLED_LS);
-      real lin0 = 0, quad = 0;
-      {
-        real L[NB * (NB + 1) / 2];
-        bool none[10]; _Pragma("unroll") for (int j = 0; j < 10; j++) none[j] = false;
-        build_H(L, none);
-        static_for<NB>([&](auto I) { constexpr int i = I; real ha = 0, hp = 0;
-          static_for<NB>([&](auto Jj) { constexpr int j = Jj;
-            if constexpr (PAT_H.nz[i > j ? i : j][i > j ? j : i]) { ha = fma(L[tri(i, j)], ar[j], ha); hp = fma(L[tri(i, j)], pr[j], hp); } });
-          lin0 += (ha - g0[i]) * pr[i]; quad += hp * pr[i]; });
-      }
-      _Pragma("unroll") for (int k = 0; k < 6; k++) { lin0 += (Md[k] * ac[k] - fs[k]) * pc[k]; quad += Md[k] * pc[k] * pc[k]; }
-      // limit rows join the piecewise part
-      real l_r0[10], l_dr[10];
-      _Pragma("unroll") for (int j = 0; j < 10; j++) { l_r0[j] = sgl[j] * ar[j] - arefl[j]; l_dr[j] = sgl[j] * pr[j]; }
-      // phi'(alpha) is piecewise linear and increasing: Newton on it (slope = quad + sum over active rows of D dr^2) lands
-      // exactly on the root once it is on the right piece; a bracket [lo, hi] with bisection as the fallback keeps it safe.
-      auto dphi = [&](real al, real& slope) {
-        real sacc = lin0 + al * quad; slope = quad;
-        dphi_rows(al, sacc, slope);
-        _Pragma("unroll") for (int j = 0; j < 10; j++) { const real rr = l_r0[j] + al * l_dr[j]; const bool on = sgl[j] != 0 && rr < 0;
-          sacc += sel(on, Dl[j] * rr * l_dr[j], 0.0); slope += sel(on, Dl[j] * l_dr[j] * l_dr[j], 0.0); }
-        return sacc;
-      };
-      real lo = 0, hi = 2, sl;
-      const bool beyond = dphi(hi, sl) < 0;
-      real al = 1.0;
-      for (int b = 0; b < 8; b++) {
-        const real f = dphi(al, sl);
-        const bool neg = f < 0;
-        lo = sel(neg, al, lo); hi = sel(neg, hi, al);
-        const real nw = al - f / sl;
-        const real nx = sel(nw > lo && nw < hi, nw, 0.5 * (lo + hi));
-        const bool moved = fabs(nx - al) > 1e-15 * fmax(1.0, fabs(al));     // on the root's own linear piece Newton stays put
-        al = nx;
-        if (!__any(moved && !conv && !beyond)) break;                         // wave-uniform exit
-      }
-      const real alpha = sel(beyond, 2.0, al);
-      for (int i = 0; i < NB; i++) ar[i] = sel(conv, ar[i], ar[i] + alpha * pr[i]);
-      _Pragma("unroll") for (int d = 0; d < 6; d++) ac[d] = sel(conv, ac[d], ac[d] + alpha * pc[d]);
-      _Pragma("unroll") for (int j = 0; j < 10; j++) { const bool now = (sgl[j] != 0) && (sgl[j] * ar[j] - arefl[j] < 0); actl[j] = sel(conv, actl[j], now); }
-      remask(alpha, conv);
+      const bool done = CS.template coupled_linesearch<ADD_M>(&Mm);
       MCG_TICK(ST_C_LS);
+      if (done) break;
+      assembled = false;
     }
-#ifdef MCG_DBG_PRINT
-    if (blockIdx.x == 0 && threadIdx.x == 0) printf("[coupled done] ac %.6e %.6e %.6e %.6e %.6e %.6e conv %d\n", ac[0], ac[1], ac[2], ac[3], ac[4], ac[5], (int)conv);
-#endif
-    _Pragma("unroll") for (int k = 0; k < 6; k++) a_c[k] = ac[k];
+    for (int i = 0; i < NB; i++) io->a[i] = Mm.ar[i];
+    _Pragma("unroll") for (int k = 0; k < 6; k++) io->a_c[k] = Mm.ac[k];
+  }
+  template <bool ADD_M>
+  MCG_DEV void solve_coupled_call(const real* g0, const real* Dl, const real* arefl, const real* sgl, const real* qdr, real* ar) {
+    SolveIO io;
+    io.Cb = Cb; io.dr[0] = dr[0]; io.dr[1] = dr[1]; io.pm_bits = pm_bits; io.ncon = ncon; io.touch[0] = touch[0]; io.touch[1] = touch[1]; io.any_pad = any_pad;
+    for (int i = 0; i < NB; i++) { io.g0[i] = g0[i]; io.qd[i] = qdr[i]; io.a[i] = ar[i]; }
+    _Pragma("unroll") for (int j = 0; j < 10; j++) { io.Dl[j] = Dl[j]; io.arefl[j] = arefl[j]; io.sgl[j] = sgl[j]; }
+    solve_coupled_outlined<ADD_M>((unsigned)(uintptr_t)S.base, &io);
+    for (int i = 0; i < NB; i++) ar[i] = io.a[i];
+    _Pragma("unroll") for (int k = 0; k < 6; k++) a_c[k] = io.a_c[k];
     solved = true;
   }
 

@@ -36,7 +36,7 @@ constexpr real MINVAL = 1e-15, MINIMP = 1e-4, MAXIMP = 0.9999;
 // Opt-in stage clocks (-DMCG_STAGE_CLOCKS, development builds only; tools/stage_clocks.py): lane 0 of each wave
 // accumulates shader-clock deltas per pipeline stage in LDS and adds them to a device-global table at kernel end.
 enum { ST_LOAD = 0, ST_CTRL, ST_TRIG, ST_RNE, ST_ACT, ST_CRB, ST_ROWS, ST_G0, ST_NEWTON, ST_EULER, ST_COLLIDE, ST_CUBE,
-       ST_COUPLED, ST_CUBE_FIN, ST_POST, ST_N_BUILD, ST_N_FACTOR, ST_N_SOLVE, ST_N_CHECK, ST_E_RHS, ST_R_AX5, ST_R_CONNECT, ST_R_LIMITS, ST_C_MASK, ST_C_ASSEMBLE, ST_C_SCHUR, ST_C_SOLVE, ST_C_CHECK, ST_C_LS, ST_W2_WAIT1, ST_W2_COLLIDE, ST_W2_CUBE, ST_W2_WAIT2, ST_W1_WAIT, ST_COUNT,
+       ST_COUPLED, ST_CUBE_FIN, ST_POST, ST_N_BUILD, ST_N_FACTOR, ST_N_SOLVE, ST_N_CHECK, ST_E_RHS, ST_R_AX5, ST_R_CONNECT, ST_R_LIMITS, ST_C_MASK, ST_C_ASSEMBLE, ST_C_SCHUR, ST_C_SOLVE, ST_C_CHECK, ST_C_LS, ST_W2_WAIT1, ST_W2_COLLIDE, ST_W2_CUBE, ST_W2_WAIT2, ST_W1_WAIT, ST_A_ENTRY, ST_A_G, ST_A_TWIST, ST_A_LOOP, ST_A_MAP, ST_A_STORE, ST_COUNT,
        CN_SUBSTEP = 0, CN_NEWTON_IT, CN_LINESEARCH, CN_CUBE_IT, CN_CUBE_LS, CN_COUPLED, CN_COUPLED_IT, CN_COUPLED_LS, CN_CONTACTS, CN_COUNT };
 #ifdef MCG_STAGE_CLOCKS
 __device__ unsigned long long g_stage_clocks[ST_COUNT + CN_COUNT];      // stage clocks, then event counts (summed over waves)
@@ -851,7 +851,7 @@ MCG_DEV void robot_substep(ModelPtr Pm, Robot& S, real* qlag6, const LS MS, CPL*
   if constexpr (CPL::enabled) {
     if (__any(CP->any_pad)) {     // wave-uniform: every lane of the wave takes the coupled path (same minimiser)
       MCG_TICK(ST_G0);
-      CP->solve_coupled(build_H, g0, Dl, arefl, sgl, S.qd, a);
+      CP->template solve_coupled_call<SPL::early_heq>(g0, Dl, arefl, sgl, S.qd, a);      // out of line, on copies (mcg_cube.hpp)
       conv = true;
       MCG_TICK(ST_COUPLED);
     }

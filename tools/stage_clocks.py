@@ -19,7 +19,9 @@ NAMES = ["load", "controller", "sincos", "rne", "actuation", "crb->M", "rows: we
          "coupled: initial masks", "coupled: assembly over contacts", "coupled: Schur complement", "coupled: LDL + back-substitution",
          "coupled: consistency + line-search rows", "coupled: line search + remask",
          "cube wave: waiting for q (S1)", "cube wave: collision", "cube wave: solve + finish", "cube wave: waiting at S2",
-         "robot wave: waiting at S2"]
+         "robot wave: waiting at S2",
+         "assemble phase: entry loads", "assemble phase: G <- H_eq, Cm <- 0", "assemble phase: twist columns, relative twists",
+         "assemble phase: contact loop", "assemble phase: mapping to dofs", "assemble phase: stores"]
 COUNTS = ["robot sub-steps", "robot Newton iterations", "robot line searches", "cube Newton iterations", "cube line searches",
           "coupled solves", "coupled Newton iterations", "coupled line searches", "wave-max contacts (per collision pass)"]
 fresh = "--fresh-actions" in sys.argv
