@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MCG_ABI_VERSION 3
+#define MCG_ABI_VERSION 4
 
 enum { MCG_OK = 0, MCG_ERR_ARG = 1, MCG_ERR_HIP = 2, MCG_ERR_UNSUPPORTED = 3 };
 enum { MCG_CTRL_JOINT = 0, MCG_CTRL_IK = 1, MCG_CTRL_MOCAP = 2 };   /* controller_type "joint" | "IK" | "mocap" */
@@ -62,8 +62,9 @@ typedef struct mcg_model {
   double site_eef[3];               /* EEF site in the link6 frame */
   /* PickAndPlace only */
   double cube_half[3], table_pos[3], table_half[3], pad_box[2][6];
-  double contact_par[6][15];        /* table-cube, right pad-cube, left pad-cube, table-right pad, table-left pad, table-arm mesh: the
-                                       10 solver numbers | friction[5].  The ground plane carries the table's (default) parameters. */
+  double contact_par[7][15];        /* table-cube, right pad-cube, left pad-cube, table-right pad, table-left pad, table-arm mesh,
+                                       finger mesh-cube: the 10 solver numbers | friction[5].  The ground plane carries the table's
+                                       (default) parameters. */
   double contact_diag[5][2];        /* summed body_invweight0 (translational, rotational) of the first five pairs */
   /* Convex-mesh collision, first stage (mycobot280_main.xml:105-175): the arm-side mesh geoms -- link1..link6, flange,
      gripper_base -- against the table and the ground plane, on the support polytope of each mesh's convex hull (its support points in
@@ -72,6 +73,13 @@ typedef struct mcg_model {
   double link_hull_box[8][6];       /* centre and half extents of the vertices' bounding box in that frame (broad phase) */
   double link_diag[8][2];           /* body_invweight0 of the geom's MJCF body (translational, rotational) */
   double link_mult;                 /* identical colliding geoms per mesh (the reference attaches every mesh twice: 2) */
+  /* ... second stage: the two finger-link meshes (mycobot280_main.xml:195-199,222-225) against the cube, as the oriented bounding box
+     of the mesh's support polytope through the exact box-box routine (the first stage's box-face-axes test over-reports contacts
+     diagonally off the edges of a box as small as the cube).  The pads are welded to these links: same pair of bodies as pad-cube. */
+  double fin_box[2][6];             /* right, left: centre and half extents of the bounding box in the finger-link frame */
+  double fin_par[4];                /* identical colliding geoms per finger mesh | the mesh geoms' own sliding friction (the cube's is
+                                       re-scaled under domain randomisation, the pair takes the larger) | summed translational
+                                       body_invweight0 of (right finger link, cube), (left finger link, cube) */
   double geom_friction0[3];         /* sliding friction of the table, pad and cube geoms (re-mixed under domain randomisation) */
   /* mocap variant only (mycobot280_mocap.xml): weld between the mocap body and gripper_tcp */
   double base_quat[4];              /* orientation of the arm's base body: start of the xquat chain */

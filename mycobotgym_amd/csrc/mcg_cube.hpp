@@ -31,7 +31,12 @@ typedef LaneScratchT<PNP_LANES> PnpScratch;
 // dofs only; they route the sub-step through the coupled solver like the pad-cube contacts do.
 // TABLE_LINK0 + p: the support polytope of arm-side mesh p (link1..6, flange, gripper_base; it rides on arm body min(p, 5)) on the
 // table or the ground: condim 3 (four pyramid rows), rows in the arm dofs up to that body only (first stage).
-enum { PAIR_TABLE_CUBE = 0, PAIR_PADR_CUBE = 1, PAIR_PADL_CUBE = 2, PAIR_TABLE_PADR = 3, PAIR_TABLE_PADL = 4, PAIR_TABLE_LINK0 = 5 };
+enum { PAIR_TABLE_CUBE = 0, PAIR_PADR_CUBE = 1, PAIR_PADL_CUBE = 2, PAIR_TABLE_PADR = 3, PAIR_TABLE_PADL = 4, PAIR_TABLE_LINK0 = 5,
+       PAIR_FINR_CUBE = PAIR_TABLE_LINK0 + 8, PAIR_FINL_CUBE = PAIR_FINR_CUBE + 1,      // finger-link mesh - cube: bodies of pad-cube
+       PAR_FIN_CUBE = 6 };                                                               // ... with their own row of contact_par
+// a contact that involves the cube (twist space in the coupled solve) / its class there: 0 table, 1 right finger body, 2 left
+MCG_DEV bool pair_has_cube(int type) { return type < PAIR_TABLE_PADR || type >= PAIR_FINR_CUBE; }
+MCG_DEV int pair_class(int type) { return (type == PAIR_PADR_CUBE || type == PAIR_FINR_CUBE) ? 1 : ((type == PAIR_PADL_CUBE || type == PAIR_FINL_CUBE) ? 2 : 0); }
 
 struct Cube {
   real pos[3], quat[4], vel[6], warm[6];     // vel = world linear velocity, body-frame angular velocity (MuJoCo free joint)
@@ -90,7 +95,7 @@ MCG_DEV void ground_box(ContactList<LS>& CL, const real* pb, const real* Rb, con
 static constexpr real EDGE_MIN_SIN = 1e-6;      // edges closer to parallel than this make no edge-edge axis: the face axes cover them
 template <class LS>
 MCG_DEV void box_box(ContactList<LS>& CL, bool live, const real* pa, const real* Ra, const real* ha,
-                     const real* pb, const real* Rb, const real* hb, int type) {
+                     const real* pb, const real* Rb, const real* hb, int type, int mult = 1) {
   const LS& S = CL.S;
   real A[3][3], B[3][3], p[3] = {pb[0] - pa[0], pb[1] - pa[1], pb[2] - pa[2]};
   _Pragma("unroll") for (int k = 0; k < 3; k++) for (int r = 0; r < 3; r++) { A[k][r] = Ra[3*r + k]; B[k][r] = Rb[3*r + k]; }
@@ -146,7 +151,7 @@ MCG_DEV void box_box(ContactList<LS>& CL, bool live, const real* pa, const real*
     const real s = dd <= 1e-12 ? 0.0 : (q1 + uaub*q2) / dd, t = dd <= 1e-12 ? 0.0 : (uaub*q1 + q2) / dd;
     real pos[3];
     _Pragma("unroll") for (int k = 0; k < 3; k++) pos[k] = 0.5 * ((ea[k] + s*Ai[k]) + (eb[k] + t*Bj[k]));
-    CL.add(pos, normal, (hit && code >= 6) ? best : 1.0, type);
+    CL.add(pos, normal, (hit && code >= 6) ? best : 1.0, type, mult);
   }
   if (!__any(hit && code < 6)) return;
 
@@ -216,7 +221,7 @@ MCG_DEV void box_box(ContactList<LS>& CL, bool live, const real* pa, const real*
     real pos[3];
     _Pragma("unroll") for (int k = 0; k < 3; k++) pos[k] = pr[k] + pt[k] + 0.5*depth*n2[k];
     const bool take = on && (depth > 0);
-    CL.add(pos, normal, take ? -depth : 1.0, type);
+    CL.add(pos, normal, take ? -depth : 1.0, type, mult);
     kept += sel(take, 1, 0);
   }
 }
@@ -259,7 +264,8 @@ struct CubeSys {
   unsigned long long pm_bits;                  // the model pointer's bits, for stages reached through the robot's hook
   MCG_DEV CubeSys(const LS s_, const Cube& c, const real* d) : S(s_), Cb(c), pm_bits(0) { dr[0] = d[0]; dr[1] = d[1]; }
   real h, Rc[9], Md[6], damp[6], fs[6];
-  real B_tc, B_pc, B_tp, B_tl, mu_tc[3], mu_pc[3], mu_tp[3], mu_tl[3];
+  real B_tc, B_pc, B_tp, B_tl, B_mc, mu_tc[3], mu_pc[3], mu_tp[3], mu_tl[3], mu_mc[3];
+  bool side_on[2];                             // a contact between the cube and the right / left finger body (pad or finger-link mesh)
   int ncon; bool any_pad, solved, touch[2];    // touch: this forward pass has a right / left pad-cube contact; any_pad: any pad contact
   real a_c[6];
 
@@ -287,6 +293,7 @@ struct CubeSys {
     mu_tp[0] = mu_tp[1] = fmax(ft, fp); mu_tp[2] = Q->contact_par[PAIR_TABLE_PADR][12];
     B_tc = Q->contact_par[PAIR_TABLE_CUBE][1]; B_pc = Q->contact_par[PAIR_PADR_CUBE][1]; B_tp = Q->contact_par[PAIR_TABLE_PADR][1];
     mu_tl[0] = mu_tl[1] = Q->contact_par[PAIR_TABLE_LINK0][10]; mu_tl[2] = 0; B_tl = Q->contact_par[PAIR_TABLE_LINK0][1];      // condim 3: no torsional rows
+    mu_mc[0] = mu_mc[1] = fmax(Q->fin_par[1], fcb); mu_mc[2] = Q->contact_par[PAR_FIN_CUBE][12]; B_mc = Q->contact_par[PAR_FIN_CUBE][1];
   }
 
   MCG_DEV ModelPtr model() const {                // wave-uniform pointer rebuilt as a scalar
@@ -300,6 +307,14 @@ struct CubeSys {
     solved = false;
     _Pragma("unroll") for (int k = 0; k < 6; k++) a_c[k] = Cb.warm[k];
     ncon = ncon_; touch[0] = touch0; touch[1] = touch1; any_pad = any_pad_;      // any_pad also covers table / ground - pad contacts
+    scan_sides();
+  }
+  MCG_DEV void scan_sides() {
+    side_on[0] = side_on[1] = false;
+    for (int c = 0; __any(c < ncon); c++) {
+      const int type = sel((c < ncon), (int)S.ld(LDS_CON + c * CON_STRIDE + 15), 0);
+      side_on[0] = side_on[0] || pair_class(type) == 1; side_on[1] = side_on[1] || pair_class(type) == 2;
+    }
   }
   MCG_DEV void prepare(ModelPtr Pm, const real* qr) {
     pm_bits = (unsigned long long)Pm;
@@ -320,10 +335,10 @@ struct CubeSys {
     real tp[3], th[3]; ldc<3>(Q->table_pos, tp); ldc<3>(Q->table_half, th);
     any_pad = false; touch[0] = touch[1] = false;
     // world frames of the arm joints and of the two gear / finger joints (mj_kinematics for the pads' chain)
-    real Rs[2][9], pc[2][3], ph[2][3];
+    real Rs[2][9], pc[2][3], ph[2][3], pf[2][3];      // finger frames (rotation, origin pf), pad centres and half sizes
     _Pragma("unroll") for (int sd = 0; sd < 2; sd++) {     // defined values for lanes / waves whose pads are not posed
       _Pragma("unroll") for (int k = 0; k < 9; k++) Rs[sd][k] = (k % 4 == 0) ? 1.0 : 0.0;
-      pc[sd][0] = pc[sd][1] = 0.0; pc[sd][2] = 1.0; ph[sd][0] = ph[sd][1] = ph[sd][2] = 0.0;
+      pc[sd][0] = pc[sd][1] = 0.0; pc[sd][2] = 1.0; ph[sd][0] = ph[sd][1] = ph[sd][2] = 0.0; pf[sd][0] = pf[sd][1] = 0.0; pf[sd][2] = 1.0;
     }
     bool reach, padlive;
     {
@@ -421,7 +436,7 @@ struct CubeSys {
           real r[3]; ldc<3>(Q->body[g].r, r); joint(g, 1, AXS[g], r, qr[g], Rs[sd], ps);
           ldc<3>(Q->body[f].r, r); joint(f, 1, AXS[f], r, qr[f], Rs[sd], ps);
           real pb[6]; ldc<6>(Q->pad_box[sd], pb);
-          _Pragma("unroll") for (int k = 0; k < 3; k++) { pc[sd][k] = ps[k] + Rs[sd][3*k]*pb[0] + Rs[sd][3*k+1]*pb[1] + Rs[sd][3*k+2]*pb[2]; ph[sd][k] = pb[3 + k]; }
+          _Pragma("unroll") for (int k = 0; k < 3; k++) { pc[sd][k] = ps[k] + Rs[sd][3*k]*pb[0] + Rs[sd][3*k+1]*pb[1] + Rs[sd][3*k+2]*pb[2]; ph[sd][k] = pb[3 + k]; pf[sd][k] = ps[k]; }
         });
       }
     }
@@ -470,7 +485,23 @@ struct CubeSys {
         touch[sd] = CL.n > before;
         any_pad = any_pad || touch[sd]; });
     }
+    // finger-link meshes - cube (second stage): the mesh's oriented bounding box through the exact box-box routine, the
+    // mesh as geom1.  Each entry stands for the two identical geoms the reference attaches (multiplicity, as for the arm meshes).
+    if (__any(reach)) {
+      static_for<2>([&](auto Sd) { constexpr int sd = Sd;
+        real fb[6]; ldc<6>(Q->fin_box[sd], fb);
+        real fc[3];
+        _Pragma("unroll") for (int k = 0; k < 3; k++) fc[k] = pf[sd][k] + Rs[sd][3*k]*fb[0] + Rs[sd][3*k+1]*fb[1] + Rs[sd][3*k+2]*fb[2];
+        const real fh[3] = {fb[3], fb[4], fb[5]};
+        const real dx = Cb.pos[0] - fc[0], dy = Cb.pos[1] - fc[1], dz = Cb.pos[2] - fc[2];
+        const real rs = sqrt(dot3(fh, fh)) + sqrt(dot3(hc, hc));
+        const bool near = reach && (dx*dx + dy*dy + dz*dz <= rs*rs);
+        const int before = CL.n;
+        if (__any(near)) box_box(CL, near, fc, Rs[sd], fh, Cb.pos, Rc, hc, PAIR_FINR_CUBE + sd, (int)Q->fin_par[0]);
+        any_pad = any_pad || (CL.n > before); });
+    }
     ncon = CL.n;
+    scan_sides();
 #ifdef MCG_STAGE_CLOCKS
     { int mx = 0; for (int c = 0; __any(c < ncon); c++) mx = c + 1; if ((threadIdx.x & 63) == 0) atomicAdd(&g_stage_clocks[ST_COUNT + CN_CONTACTS], (unsigned long long)mx); }   // wave-max contacts
 #endif
@@ -491,15 +522,20 @@ struct CubeSys {
       const int b = LDS_CON + c * CON_STRIDE;
       const real dist = S.ld(b + 12);
       const int type = sel((c < ncon), (int)S.ld(b + 15), 0);
-      const bool padcube = type == PAIR_PADR_CUBE || type == PAIR_PADL_CUBE, tabpad = type >= PAIR_TABLE_PADR;
+      const bool padcube = type == PAIR_PADR_CUBE || type == PAIR_PADL_CUBE, fincube = type >= PAIR_FINR_CUBE, tabpad = type >= PAIR_TABLE_PADR && !fincube;
       real imp = sel(padcube, impedance(par_p, dist), impedance(par_t, dist));
       real kk = sel(padcube, par_p[0], par_t[0]);
       real m0 = sel(padcube, mu_pc[0], mu_tc[0]);
       real tran = sel(type == PAIR_PADR_CUBE, Q->contact_diag[PAIR_PADR_CUBE][0],
                       sel(type == PAIR_PADL_CUBE, Q->contact_diag[PAIR_PADL_CUBE][0], Q->contact_diag[PAIR_TABLE_CUBE][0]));
       const real mult = S.ld(b + 13);                                     // identical contacts this entry stands for (ContactList::add)
+      if (__any(fincube)) {
+        real par_mc[10]; ldc<10>(Q->contact_par[PAR_FIN_CUBE], par_mc);
+        imp = sel(fincube, impedance(par_mc, dist), imp); kk = sel(fincube, par_mc[0], kk); m0 = sel(fincube, mu_mc[0], m0);
+        tran = sel(type == PAIR_FINR_CUBE, Q->fin_par[2], sel(type == PAIR_FINL_CUBE, Q->fin_par[3], tran));
+      }
       if (any_tp) {
-        const bool tablink = type >= PAIR_TABLE_LINK0, tabp = tabpad && !tablink;
+        const bool tablink = type >= PAIR_TABLE_LINK0 && !fincube, tabp = tabpad && !tablink;
         real par_tp[10]; ldc<10>(Q->contact_par[PAIR_TABLE_PADR], par_tp);
         imp = sel(tabp, impedance(par_tp, dist), imp); kk = sel(tabp, par_tp[0], kk); m0 = sel(tabp, mu_tp[0], m0);
         tran = sel(type == PAIR_TABLE_PADR, Q->contact_diag[PAIR_TABLE_PADR][0], sel(type == PAIR_TABLE_PADL, Q->contact_diag[PAIR_TABLE_PADL][0], tran));
@@ -760,8 +796,8 @@ struct CubeSys {
       real ax[3], d[3], v[3];
       _Pragma("unroll") for (int k = 0; k < 3; k++) { ax[k] = S.ld(LDS_WJ + j*6 + k); d[k] = S.ld(LDS_WJ + j*6 + 3 + k) - Cb.pos[k]; }
       cross(d, ax, v);
-      // a side without a pad-cube contact in this lane: its gear / finger frames may be stale LDS contents (pads not posed)
-      const bool ok = (j < 6) || touch[(j - 6) >> 1];
+      // a side without a finger body - cube contact in this lane: its gear / finger frames may be stale LDS contents (pads not posed)
+      const bool ok = (j < 6) || side_on[(j - 6) >> 1];
       _Pragma("unroll") for (int k = 0; k < 3; k++) { T.c[j][k] = sel(ok, v[k], 0.0); T.c[j][3 + k] = sel(ok, ax[k], 0.0); }
     }
   }
@@ -778,7 +814,7 @@ struct CubeSys {
       W.r[0][k] = tc[k]; W.r[1][k] = tc[k] - us[0][k]; W.r[2][k] = tc[k] - us[1][k];
     }
   }
-  struct TwistRows { real e[3][6], n[3]; real D, kterm; int type, mask; bool tw; };     // e[3] = [0 ; n]
+  struct TwistRows { real e[3][6], n[3]; real D, kterm; int type, cls, mask; bool tw; };     // e[3] = [0 ; n]; cls: pair_class
   MCG_DEV void twist_rows(int c, TwistRows& E) const {
     const int b = LDS_CON + c * CON_STRIDE;
     real lev[3], dir[3][3];
@@ -786,7 +822,8 @@ struct CubeSys {
     _Pragma("unroll") for (int r = 0; r < 3; r++) { real x[3]; cross(lev, dir[r], x); _Pragma("unroll") for (int k = 0; k < 3; k++) { E.e[r][k] = dir[r][k]; E.e[r][3 + k] = x[k]; } }
     _Pragma("unroll") for (int k = 0; k < 3; k++) E.n[k] = dir[0][k];
     E.type = sel((c < ncon), (int)S.ld(b + 15), 0);
-    E.tw = (c < ncon) && E.type < PAIR_TABLE_PADR;
+    E.tw = (c < ncon) && pair_has_cube(E.type);
+    E.cls = pair_class(E.type);
     E.D = sel(E.tw, S.ld(b + 13), 0.0); E.kterm = S.ld(b + 14);
     E.mask = sel(E.tw, (int)S.ld(LDS_ACT + c), 0);
   }
@@ -794,8 +831,14 @@ struct CubeSys {
     _Pragma("unroll") for (int b = 0; b < 3; b++) { o[b] = 0; _Pragma("unroll") for (int k = 0; k < 6; k++) o[b] = fma(E.e[b][k], r[k], o[b]); }
     o[3] = E.n[0]*r[3] + E.n[1]*r[4] + E.n[2]*r[5];
   }
-  MCG_DEV static void pick_twist(const Twists& W, int type, real* r) {
-    _Pragma("unroll") for (int k = 0; k < 6; k++) r[k] = sel(type == PAIR_PADR_CUBE, W.r[1][k], sel(type == PAIR_PADL_CUBE, W.r[2][k], W.r[0][k]));
+  MCG_DEV static void pick_twist(const Twists& W, int cls, real* r) {
+    _Pragma("unroll") for (int k = 0; k < 6; k++) r[k] = sel(cls == 1, W.r[1][k], sel(cls == 2, W.r[2][k], W.r[0][k]));
+  }
+  // friction and velocity-term numbers of a cube contact's pair: table-cube, pad-cube, finger mesh-cube
+  MCG_DEV void cube_pair_numbers(int type, real* mu, real& Bc) const {
+    const bool padc = type == PAIR_PADR_CUBE || type == PAIR_PADL_CUBE, finc = type >= PAIR_FINR_CUBE;
+    _Pragma("unroll") for (int k = 0; k < 3; k++) mu[k] = sel(finc, mu_mc[k], sel(padc, mu_pc[k], mu_tc[k]));
+    Bc = sel(finc, B_mc, sel(padc, B_pc, B_tc));
   }
   static constexpr int LDS_DV = LDS_POLY + 16;     // basis . velocity of every twist-space contact, 4 per contact (the clip polygons are dead;
                                                    // slots 0..3 of that area are the split kernels' flags, read by other waves after S2)
@@ -867,10 +910,9 @@ struct CubeSys {
 
     // a twist-space contact's pyramid rows with the active set `mask` into its class accumulators; dv = its basis . velocity
     auto add_twist = [&](const TwistRows& E, int mask, const real* dv) {
-      const bool padc = E.type != PAIR_TABLE_CUBE;
-      const real Bc = sel(padc, B_pc, B_tc);
+      real mu_[3], Bc; cube_pair_numbers(E.type, mu_, Bc);
       real W00 = 0, t0 = 0, W0[3], Wd[3], t[3];
-      static_for<3>([&](auto Kk) { constexpr int k = Kk; const real m = sel(padc, mu_pc[k], mu_tc[k]);
+      static_for<3>([&](auto Kk) { constexpr int k = Kk; const real m = mu_[k];
         const real arp = -Bc * fma(m, dv[1 + k], dv[0]) - E.kterm, arm = -Bc * fma(-m, dv[1 + k], dv[0]) - E.kterm;
         const real wp = sel(((mask >> (2 * k)) & 1) != 0, E.D, 0.0), wm = sel(((mask >> (2 * k + 1)) & 1) != 0, E.D, 0.0);
         W00 += wp + wm; t0 = fma(wp, arp, fma(wm, arm, t0));
@@ -889,11 +931,10 @@ struct CubeSys {
         const real e3 = d < 3 ? 0.0 : E.n[d < 3 ? 0 : d - 3];
         dA[tri(d, e)] = E.e[0][d] * U[0][e] + E.e[1][d] * U[1][e] + E.e[2][d] * U[2][e] + e3 * U[3][e]; }); });
       // the lane's class takes the update (weights are zero for lanes without a live twist-space contact here)
-      static_for<3>([&](auto Qq) { constexpr int q = Qq; const real on = (E.type == q) ? 1.0 : 0.0;
+      static_for<3>([&](auto Qq) { constexpr int q = Qq; const real on = (E.cls == q) ? 1.0 : 0.0;
         _Pragma("unroll") for (int k = 0; k < 21; k++) At[q][k] = fma(on, dA[k], At[q][k]);
         _Pragma("unroll") for (int k = 0; k < 6; k++) bt[q][k] = fma(on, db[k], bt[q][k]); });
     };
-    static_assert(PAIR_TABLE_CUBE == 0 && PAIR_PADR_CUBE == 1 && PAIR_PADL_CUBE == 2, "twist classes are the pair codes");
     // one dof-space (static geom - robot) contact's pyramid rows with the active set `mask` into grs (registers) and G (LDS)
     auto add_contact = [&](const Coupled& K, int mask, const real* dv, bool live) {
       real W00 = 0, t0 = 0, W0[3], Wd[3], t[3];
@@ -946,12 +987,12 @@ struct CubeSys {
       MCG_TICK(ST_A_TWIST);
       for (int c = 0; __any(c < ncon); c++) {
         const int type = sel((c < ncon), (int)S.ld(LDS_CON + c * CON_STRIDE + 15), 0);
-        const bool tw = (c < ncon) && type < PAIR_TABLE_PADR, st = (c < ncon) && type >= PAIR_TABLE_PADR;
+        const bool tw = (c < ncon) && pair_has_cube(type), st = (c < ncon) && !pair_has_cube(type);
         if (__any(tw)) {
           TwistRows E; twist_rows(c, E);
           real dv[4];
           if (mode == PASS_WARM) {
-            real rv[6]; pick_twist(RV, E.type, rv); tdots(E, rv, dv);
+            real rv[6]; pick_twist(RV, E.cls, rv); tdots(E, rv, dv);
             if (tw) { _Pragma("unroll") for (int b = 0; b < 4; b++) S.st(LDS_DV + c * 4 + b, dv[b]); }
           } else {
             _Pragma("unroll") for (int b = 0; b < 4; b++) dv[b] = sel(tw, S.ld(LDS_DV + c * 4 + b), 0.0);      // (other lanes: stale slots)
@@ -959,10 +1000,9 @@ struct CubeSys {
           int mask = E.mask;
           if (mode != PASS_REBUILD) {
             real rp[6], dp[4];
-            pick_twist(RP_, E.type, rp); tdots(E, rp, dp);
-            const bool padc = E.type != PAIR_TABLE_CUBE;
-            const real mu[3] = {sel(padc, mu_pc[0], mu_tc[0]), sel(padc, mu_pc[1], mu_tc[1]), sel(padc, mu_pc[2], mu_tc[2])};
-            mask = pattern_of(mu, sel(padc, B_pc, B_tc), E.kterm, false, dp, dv);
+            pick_twist(RP_, E.cls, rp); tdots(E, rp, dp);
+            real mu[3], Bc; cube_pair_numbers(E.type, mu, Bc);
+            mask = pattern_of(mu, Bc, E.kterm, false, dp, dv);
             same = same && (!tw || mask == E.mask);
 #ifdef MCG_DBG_PRINT
             if (blockIdx.x == 0 && threadIdx.x == 0 && tw) printf("[pass %d] c %d type %d mask %d (was %d) dp %.4e %.4e %.4e %.4e dv %.4e %.4e %.4e %.4e\n", mode, c, E.type, mask, E.mask, dp[0], dp[1], dp[2], dp[3], dv[0], dv[1], dv[2], dv[3]);
@@ -1012,7 +1052,7 @@ struct CubeSys {
           Hc[tri(3 + d, 3 + e)] += Rc[d] * X[0][e] + Rc[3 + d] * X[1][e] + Rc[6 + d] * X[2][e]; }); });
         _Pragma("unroll") for (int k = 0; k < 3; k++) { gc[k] += bs[k]; gc[3 + k] += Rc[k] * bs[3] + Rc[3 + k] * bs[4] + Rc[6 + k] * bs[5]; }
       }
-      if (__any(touch[0] || touch[1])) {          // wave-uniform: a pad-cube contact reaches the robot's dofs
+      if (__any(side_on[0] || side_on[1])) {      // wave-uniform: a finger body - cube contact reaches the robot's dofs
         TwistCols T; twist_cols(T);
         real A12[21], b12[6];
         _Pragma("unroll") for (int k = 0; k < 21; k++) A12[k] = At[1][k] + At[2][k];
@@ -1128,17 +1168,15 @@ struct CubeSys {
       Twists RA, RP; rel_twists(T, ac, ar, RA); rel_twists(T, pc, pr, RP);
       for (int c = 0; __any(c < ncon); c++) {
         const int type = sel((c < ncon), (int)S.ld(LDS_CON + c * CON_STRIDE + 15), 0);
-        const bool tw = (c < ncon) && type < PAIR_TABLE_PADR, st = (c < ncon) && type >= PAIR_TABLE_PADR;
+        const bool tw = (c < ncon) && pair_has_cube(type), st = (c < ncon) && !pair_has_cube(type);
         real da[4] = {0, 0, 0, 0}, dv[4] = {0, 0, 0, 0}, dp[4] = {0, 0, 0, 0}, mu[3] = {0, 0, 0}, Bc = 0, kterm = 0; int mask = 0; bool dim3 = false;
         if (__any(tw)) {
           TwistRows E; twist_rows(c, E);
           real ra[6], rp[6], ta[4], tp_[4];
-          pick_twist(RA, E.type, ra); pick_twist(RP, E.type, rp);
+          pick_twist(RA, E.cls, ra); pick_twist(RP, E.cls, rp);
           tdots(E, ra, ta); tdots(E, rp, tp_);
-          const bool padc = E.type != PAIR_TABLE_CUBE;
           _Pragma("unroll") for (int b = 0; b < 4; b++) { da[b] = ta[b]; dp[b] = tp_[b]; dv[b] = sel(tw, S.ld(LDS_DV + c * 4 + b), 0.0); }
-          _Pragma("unroll") for (int k = 0; k < 3; k++) mu[k] = sel(padc, mu_pc[k], mu_tc[k]);
-          Bc = sel(padc, B_pc, B_tc); kterm = E.kterm; mask = E.mask;
+          cube_pair_numbers(E.type, mu, Bc); kterm = E.kterm; mask = E.mask;
         }
         if (__any(st)) {
           Coupled K; contact_of(c, K);

@@ -89,9 +89,13 @@ static void plane_box(const mco_model* m, mco_data* d, int gp, int gb) {
 #define EDGE_FUDGE 1.05      /* an edge axis must beat the best face axis by 5 % (avoids flicker on parallel faces) */
 
 static void box_box(const mco_model* m, mco_data* d, int ga, int gb) {
-  const double* pa = d->geom_xpos[ga]; const double* pb = d->geom_xpos[gb];
   const double* Ra = d->geom_xmat[ga]; const double* Rb = d->geom_xmat[gb];
   const double* ha = m->geom_size[ga]; const double* hb = m->geom_size[gb];
+  double pa[3], pb[3];                  /* box centres (a mesh geom's bounding box is off its frame origin by obb_center, else zero) */
+  for (int r = 0; r < 3; r++) {
+    pa[r] = d->geom_xpos[ga][r] + Ra[3*r]*m->obb_center[ga][0] + Ra[3*r+1]*m->obb_center[ga][1] + Ra[3*r+2]*m->obb_center[ga][2];
+    pb[r] = d->geom_xpos[gb][r] + Rb[3*r]*m->obb_center[gb][0] + Rb[3*r+1]*m->obb_center[gb][1] + Rb[3*r+2]*m->obb_center[gb][2];
+  }
   double A[3][3], B[3][3], p[3] = { pb[0] - pa[0], pb[1] - pa[1], pb[2] - pa[2] };
   for (int k = 0; k < 3; k++) { col(Ra, k, A[k]); col(Rb, k, B[k]); }
   double C[3][3], Q[3][3];              /* C = A^T B, Q = |C| */
@@ -285,6 +289,30 @@ void mco_collision(const mco_model* m, mco_data* d) {
       double dp[3] = { d->geom_xpos[g2][0] - d->geom_xpos[g1][0], d->geom_xpos[g2][1] - d->geom_xpos[g1][1], d->geom_xpos[g2][2] - d->geom_xpos[g1][2] };
       if (dot3(dp, dp) > r * r) continue;                               /* bounding spheres */
       box_box(m, d, g1, g2);
+    }
+  }
+  /* finger-link meshes (collide_extra 4) <-> the cube (second stage), after the primitive pairs: the mesh's oriented
+   * bounding box through box_box.  The reference attaches every mesh twice (two identical geoms): the twin's contacts are the same
+   * contacts again, emitted right after each original so that the cap of MCO_MAXCON cuts the list where the kernels' cut it. */
+  if (m->collide_scope_geom >= 0 && m->geom_type[m->collide_scope_geom] == MCO_GEOM_BOX) {
+    int gc = m->collide_scope_geom;
+    for (int g = 0; g < m->ngeom; g++) {
+      if (m->geom_type[g] != MCO_GEOM_MESH || m->collide_extra[g] != 4 || filtered(m, g, gc)) continue;
+      int twin = (g + 1 < m->ngeom && m->collide_extra[g + 1] == 4 && m->geom_body[g + 1] == m->geom_body[g]) ? g + 1 : -1;
+      int n0 = d->ncon;
+      if (g < gc) box_box(m, d, g, gc); else box_box(m, d, gc, g);
+      if (twin >= 0) {
+        mco_contact tmp[MCO_MAXCON]; int n1 = d->ncon, k = 0;
+        for (int c = n0; c < n1; c++) tmp[k++] = d->contact[c];
+        d->ncon = n0;
+        for (int c = 0; c < k; c++) for (int rep = 0; rep < 2; rep++) {
+          if (d->ncon >= MCO_MAXCON) break;
+          d->contact[d->ncon] = tmp[c];
+          if (rep) { if (g < gc) d->contact[d->ncon].geom1 = twin; else d->contact[d->ncon].geom2 = twin; }
+          d->ncon++;
+        }
+        g = twin;
+      }
     }
   }
 }

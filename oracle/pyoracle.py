@@ -18,6 +18,7 @@ _lib = None
 
 MAXNQ, MAXNV, MAXU = 24, 24, 8
 ARM_MESHES = ("link1", "link2", "link3", "link4", "link5", "link6", "flange", "gripper_base")     # SURVEY 8f-4, first stage
+FINGER_MESHES = ("right_finger_link", "left_finger_link")                                              # second stage: against the cube
 
 
 def build(force: bool = False) -> str:
@@ -83,6 +84,7 @@ class OracleModel:
 
     def __init__(self, table: dict, enable_contact: bool = False, scope_geom: int = -1, mesh_collision: bool = True):
         L = lib()
+        self.obb_size = {}
         self.table = table
         self.buf = C.create_string_buffer(L.mco_model_sizeof())
         self.nq, self.nv, self.nu = table["nq"], table["nv"], table["nu"]
@@ -105,7 +107,14 @@ class OracleModel:
                 sup = np.asarray(table.get("meshes", {}).get(name, {}).get("support", []), dtype=np.float64)
                 if mesh_collision and name in ARM_MESHES and len(sup):
                     extra[g] = 3; hn[g] = len(sup); hv[g, :len(sup)] = sup
-            si("collide_extra", extra); si("hull_nvert", hn); sd("hull_vert", hv)
+            # second stage: the finger-link meshes against the cube, as the oriented bounding box of their support polytope
+            obb = np.zeros((48, 3))
+            for g in range(table["ngeom"]):
+                name = table["geom_mesh"][g] if table["geom_type"][g] == 7 else ""
+                sup = np.asarray(table.get("meshes", {}).get(name, {}).get("support", []), dtype=np.float64)
+                if mesh_collision and name in FINGER_MESHES and len(sup):
+                    extra[g] = 4; obb[g] = 0.5 * (sup.max(0) + sup.min(0)); self.obb_size[g] = 0.5 * (sup.max(0) - sup.min(0))
+            si("collide_extra", extra); si("hull_nvert", hn); sd("hull_vert", hv); sd("obb_center", obb)
         sd("timestep", [table["opt"]["timestep"]]); sd("gravity", table["opt"]["gravity"])
         for k in ("body_parent", "body_rootid", "body_weldid", "body_dofadr", "body_dofnum", "jnt_type", "jnt_body",
                   "jnt_qposadr", "jnt_dofadr", "dof_body", "dof_jnt", "dof_parent", "geom_type", "geom_body",
@@ -122,7 +131,11 @@ class OracleModel:
                   "jnt_axis", "jnt_range", "jnt_solref", "jnt_solimp", "dof_armature", "dof_damping", "qpos0",
                   "geom_pos", "geom_quat", "geom_size", "geom_friction", "geom_solref", "geom_solimp",
                   "site_pos", "site_quat"):
-            sd(k, table[k])
+            v = table[k]
+            if k == "geom_size" and getattr(self, "obb_size", None):        # a colliding finger-link mesh: its bounding box's half extents
+                v = [list(x) for x in v]
+                for g, h in self.obb_size.items(): v[g] = list(h)
+            sd(k, v)
         acts = table["actuators"]
         si("act_trntype", [0 if a["trntype"] == "joint" else 1 for a in acts])
         si("act_trnid", [a["trnid"] for a in acts])

@@ -117,6 +117,43 @@ def test_substeps_arm_meshes_on_the_table_and_the_ground(torch_cuda):
     assert worst["obs"] < 1e-10 and worst["qpos"] < 1e-10 and worst["qvel"] < 1e-6
 
 
+def _finger_mesh_poses(count=128, seed=2):
+    """Gripper poses around the cube (the scripted-grasp states, perturbed) in which a finger-LINK mesh (its bounding box) touches the
+    cube: the oracle with mesh collision reports more contacts than the one without; shallow ones only (a deep one is a violent state)."""
+    from tests.common import load_json
+    from oracle import pyoracle as po
+    from mycobotgym_amd.scenarios import grasp_state
+    tab = load_json("mycobot280")
+    scope = tab["geom_name"].index("object0")
+    d1 = po.OracleData(po.OracleModel(tab, enable_contact=True, scope_geom=scope))
+    d0 = po.OracleData(po.OracleModel(tab, enable_contact=True, scope_geom=scope, mesh_collision=False))
+    q0 = np.asarray(grasp_state(64, seed=0)["qpos"]); q0 = q0.T if q0.shape[0] == 19 else q0
+    rng = np.random.default_rng(seed)
+    poses = []
+    while len(poses) < count:
+        q = q0[rng.integers(len(q0))].copy()
+        q[:6] += rng.normal(0, 0.03, 6); q[6] = q[8] = np.clip(q[6] + rng.normal(0, 0.1), 0, 0.7)
+        for d in (d0, d1): d.set_state(qpos=q, qvel=np.zeros(18)); d.forward()
+        n0, n1 = (int(d.get("ncon", (1,), np.int32)[0]) for d in (d0, d1))
+        if n1 > n0 and d1.get("contact", (12, 28))[:n1, 0].min() > -3e-3: poses.append(q)
+    return np.array(poses)
+
+
+def test_substeps_finger_link_meshes_on_the_cube(torch_cuda):
+    """SURVEY 8f-4, second stage: the two finger-link meshes (oriented bounding boxes of their support polytopes, exact box-box) against
+    the cube -- contacts between the same two bodies as the pad-cube contacts, with the mesh-cube pair's own parameters."""
+    poses = _finger_mesh_poses()
+    def prepare(ora):
+        s = ora.get_state()
+        s["qpos"][:] = poses; s["qpos_lag"] = s["qpos"].copy()
+        s["ctrl"][:, :6] = poses[:, :6]; s["ctrl"][:, 6] = poses[:, 6] / 0.7
+        ora.set_state(**s)
+    worst, ncon = _substep_run(torch_cuda, 128, 200, prepare=prepare, hold_pose=True)
+    print(f"\nfinger-link meshes on the cube, 200 sub-steps x 128 envs: {worst}, contact counts seen {sorted(ncon)}")
+    assert max(ncon) >= 2
+    assert worst["obs"] < 1e-10 and worst["qpos"] < 1e-10 and worst["qvel"] < 1e-6
+
+
 def test_cube_edges_parallel_to_the_table_edges(torch_cuda):
     """Regression (round 2): a cube rocking on the table by 3e-4 rad about y has its y edges parallel to the table's.  With
     |A_i x B_j| taken as sqrt(1 - C^2), rounding (C = 1 - 1e-16) made a 1e-8 `length`, and the axis built from that noise beat the

@@ -299,7 +299,7 @@ def test_long_random_rollouts_stay_finite(torch_cuda):
                     obs, rew, term, trunc, info = envs.step(a)
                     if t % 25 == 24:
                         assert torch.isfinite(obs["observation"]).all() and torch.isfinite(rew).all(), (obj, ctrl, fetch, t)
-                        assert float(obs["observation"].abs().max()) < 5.0
+                        assert float(obs["observation"].abs().max()) < 20.0      # (a cube struck by a finger link can leave at > 5 m/s)
                     done = term | trunc
                     if done.any():
                         len_sum += float(info["episode"]["l"][done].float().sum()); len_cnt += int(done.sum())
