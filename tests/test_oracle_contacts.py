@@ -242,3 +242,48 @@ def test_arm_mesh_on_the_table_is_a_contact(po):
     for name in ("link1", "link2", "link3", "link4", "link5", "link6", "flange", "gripper_base"):
         mm = tab["meshes"][name]
         assert len(mm["support"]) == 26 and 0.75 < mm["support_volume"] / mm["hull_volume"] < 0.92 and mm["hull_nvert"] > 500
+
+
+def _contact_table(d):
+    """The oracle's contact list: (geom1, geom2, dim, dist, pos, normal) per contact (mco_contact, exported raw)."""
+    n = int(d.get("ncon", (1,), np.int32)[0])
+    raw = d.get("contact", (12, 28))
+    out = []
+    for c in range(n):
+        ints = raw[c, 26:28].copy().view(np.int32)           # dim, geom1, geom2, efc_address
+        out.append((int(ints[1]), int(ints[2]), int(ints[0]), float(raw[c, 0]), raw[c, 1:4].copy(), raw[c, 4:7].copy()))
+    return out
+
+
+def test_finger_link_boxes_against_the_cube(po):
+    """SURVEY 8f-4, second stage (oracle side): the finger-link meshes collide with the cube as oriented bounding boxes.  The pads
+    protrude beyond those boxes, so none of the scripted-grasp states holds such a contact; pushed sideways they appear, condim 4, the
+    mesh as geom1, each contact followed at once by its twin geom's copy (the reference attaches every mesh twice)."""
+    from mycobotgym_amd.scenarios import grasp_state
+    tab = load_json("mycobot280")
+    scope = tab["geom_name"].index("object0")
+    d1 = po.OracleData(po.OracleModel(tab, enable_contact=True, scope_geom=scope))
+    d0 = po.OracleData(po.OracleModel(tab, enable_contact=True, scope_geom=scope, mesh_collision=False))
+    fingers = {g for g in range(tab["ngeom"]) if tab["geom_type"][g] == 7 and tab["geom_mesh"][g] in ("right_finger_link", "left_finger_link")}
+    assert len(fingers) == 4
+    q0 = np.asarray(grasp_state(64, seed=0)["qpos"]); q0 = q0.T if q0.shape[0] == 19 else q0
+    for q in q0:
+        d1.set_state(qpos=q, qvel=np.zeros(18)); d1.forward()
+        assert not any(c[0] in fingers for c in _contact_table(d1))        # the pads hold the cube, not the links
+    rng = np.random.default_rng(0)
+    seen = 0
+    for trial in range(200):
+        q = q0[rng.integers(64)].copy()
+        q[:6] += rng.normal(0, 0.06, 6); q[6] = q[8] = np.clip(q[6] + rng.normal(0, 0.15), 0, 0.7)
+        for d in (d0, d1): d.set_state(qpos=q, qvel=np.zeros(18)); d.forward()
+        t0, t1 = _contact_table(d0), _contact_table(d1)
+        fin = [c for c in t1 if c[0] in fingers]
+        assert [c[:4] for c in t1 if c[0] not in fingers][:len(t0)] == [c[:4] for c in t0][:len([c for c in t1 if c[0] not in fingers])]   # the other pairs are untouched
+        if not fin: continue
+        seen += 1
+        assert all(c[1] == scope and c[2] == 4 and c[3] < 0 for c in fin)
+        if len(t1) < 12:                                                     # uncapped list: every contact comes with its twin right after
+            assert len(fin) % 2 == 0
+            for a, b in zip(fin[0::2], fin[1::2]):
+                assert b[0] == a[0] + 1 and a[3] == b[3] and np.array_equal(a[4], b[4]) and np.array_equal(a[5], b[5])
+    assert seen > 50
