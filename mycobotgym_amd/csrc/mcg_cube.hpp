@@ -790,6 +790,7 @@ struct CubeSys {
   // A contact costs ~400 instructions per pass (was ~2 000 with per-entry LDS read-modify-writes of G and Cm), the mapping ~1 500 per
   // iteration.  Contacts between a static geom and the robot alone (table / ground - pad, - arm mesh) keep the dof-space path
   // (contact_of / add_contact below), executed only when a lane of the wave holds one at that list position.
+  struct CubeConsts { real pos[3], mu[3][3], B[3]; int ncon; };      // (filled by hoist(), below)
   struct TwistCols { real c[10][6]; };          // arm 0..5, gear / finger right (6, 7), gear / finger left (8, 9)
   MCG_DEV void twist_cols(TwistCols& T) const {
     _Pragma("unroll") for (int j = 0; j < 10; j++) {
@@ -815,10 +816,11 @@ struct CubeSys {
     }
   }
   struct TwistRows { real e[3][6], n[3]; real D, kterm; int type, cls, mask; bool tw; };     // e[3] = [0 ; n]; cls: pair_class
-  MCG_DEV void twist_rows(int c, TwistRows& E) const {
+  MCG_DEV void twist_rows(const CubeConsts& K, int c, TwistRows& E) const {
+    const int ncon = K.ncon;
     const int b = LDS_CON + c * CON_STRIDE;
     real lev[3], dir[3][3];
-    _Pragma("unroll") for (int k = 0; k < 3; k++) { lev[k] = S.ld(b + k) - Cb.pos[k]; dir[0][k] = S.ld(b + 3 + k); dir[1][k] = S.ld(b + 6 + k); dir[2][k] = S.ld(b + 9 + k); }
+    _Pragma("unroll") for (int k = 0; k < 3; k++) { lev[k] = S.ld(b + k) - K.pos[k]; dir[0][k] = S.ld(b + 3 + k); dir[1][k] = S.ld(b + 6 + k); dir[2][k] = S.ld(b + 9 + k); }
     _Pragma("unroll") for (int r = 0; r < 3; r++) { real x[3]; cross(lev, dir[r], x); _Pragma("unroll") for (int k = 0; k < 3; k++) { E.e[r][k] = dir[r][k]; E.e[r][3 + k] = x[k]; } }
     _Pragma("unroll") for (int k = 0; k < 3; k++) E.n[k] = dir[0][k];
     E.type = sel((c < ncon), (int)S.ld(b + 15), 0);
@@ -835,10 +837,20 @@ struct CubeSys {
     _Pragma("unroll") for (int k = 0; k < 6; k++) r[k] = sel(cls == 1, W.r[1][k], sel(cls == 2, W.r[2][k], W.r[0][k]));
   }
   // friction and velocity-term numbers of a cube contact's pair: table-cube, pad-cube, finger mesh-cube
-  MCG_DEV void cube_pair_numbers(int type, real* mu, real& Bc) const {
+  // The handful of object fields the contact loops read, copied to locals ONCE per phase: through `this` (a generic pointer that may
+  // alias LDS) each of them is a flat load repeated after every LDS store, and with one wave per SIMD every such load is a fully
+  // exposed memory round trip -- the PMC view of the scripted grasp has ~3 500 VMEM reads per coupled sub-step, about the whole of its
+  // time at ~300 clocks each.  (Copying the WHOLE object was slower: section 5 of DESIGN.md.)
+  MCG_DEV CubeConsts hoist() const {
+    CubeConsts K;
+    _Pragma("unroll") for (int k = 0; k < 3; k++) { K.pos[k] = Cb.pos[k]; K.mu[0][k] = mu_tc[k]; K.mu[1][k] = mu_pc[k]; K.mu[2][k] = mu_mc[k]; }
+    K.B[0] = B_tc; K.B[1] = B_pc; K.B[2] = B_mc; K.ncon = ncon;
+    return K;
+  }
+  MCG_DEV static void cube_pair_numbers(const CubeConsts& K, int type, real* mu, real& Bc) {
     const bool padc = type == PAIR_PADR_CUBE || type == PAIR_PADL_CUBE, finc = type >= PAIR_FINR_CUBE;
-    _Pragma("unroll") for (int k = 0; k < 3; k++) mu[k] = sel(finc, mu_mc[k], sel(padc, mu_pc[k], mu_tc[k]));
-    Bc = sel(finc, B_mc, sel(padc, B_pc, B_tc));
+    _Pragma("unroll") for (int k = 0; k < 3; k++) mu[k] = sel(finc, K.mu[2][k], sel(padc, K.mu[1][k], K.mu[0][k]));
+    Bc = sel(finc, K.B[2], sel(padc, K.B[1], K.B[0]));
   }
   static constexpr int LDS_DV = LDS_POLY + 16;     // basis . velocity of every twist-space contact, 4 per contact (the clip polygons are dead;
                                                    // slots 0..3 of that area are the split kernels' flags, read by other waves after S2)
@@ -872,6 +884,7 @@ struct CubeSys {
   __device__ __noinline__ bool coupled_assemble(CoupledMem* Mm, int mode) { return coupled_assemble_impl<ADD_M>(Mm, mode); }
   template <bool ADD_M>
   MCG_DEV bool coupled_assemble_impl(CoupledMem* Mm, int mode) {
+    const CubeConsts KC = hoist();
     real pr_[NB], pc_[6];                        // the pass's point
     const bool at_x = mode == PASS_FUSED;
     for (int i = 0; i < NB; i++) pr_[i] = at_x ? Mm->xr[i] : Mm->ar[i];
@@ -910,7 +923,7 @@ struct CubeSys {
 
     // a twist-space contact's pyramid rows with the active set `mask` into its class accumulators; dv = its basis . velocity
     auto add_twist = [&](const TwistRows& E, int mask, const real* dv) {
-      real mu_[3], Bc; cube_pair_numbers(E.type, mu_, Bc);
+      real mu_[3], Bc; cube_pair_numbers(KC, E.type, mu_, Bc);
       real W00 = 0, t0 = 0, W0[3], Wd[3], t[3];
       static_for<3>([&](auto Kk) { constexpr int k = Kk; const real m = mu_[k];
         const real arp = -Bc * fma(m, dv[1 + k], dv[0]) - E.kterm, arm = -Bc * fma(-m, dv[1 + k], dv[0]) - E.kterm;
@@ -985,11 +998,11 @@ struct CubeSys {
         if (mode != PASS_REBUILD) rel_twists(T, pc_, pr_, RP_);
       }
       MCG_TICK(ST_A_TWIST);
-      for (int c = 0; __any(c < ncon); c++) {
-        const int type = sel((c < ncon), (int)S.ld(LDS_CON + c * CON_STRIDE + 15), 0);
-        const bool tw = (c < ncon) && pair_has_cube(type), st = (c < ncon) && !pair_has_cube(type);
+      for (int c = 0; __any(c < KC.ncon); c++) {
+        const int type = sel((c < KC.ncon), (int)S.ld(LDS_CON + c * CON_STRIDE + 15), 0);
+        const bool tw = (c < KC.ncon) && pair_has_cube(type), st = (c < KC.ncon) && !pair_has_cube(type);
         if (__any(tw)) {
-          TwistRows E; twist_rows(c, E);
+          TwistRows E; twist_rows(KC, c, E);
           real dv[4];
           if (mode == PASS_WARM) {
             real rv[6]; pick_twist(RV, E.cls, rv); tdots(E, rv, dv);
@@ -1001,7 +1014,7 @@ struct CubeSys {
           if (mode != PASS_REBUILD) {
             real rp[6], dp[4];
             pick_twist(RP_, E.cls, rp); tdots(E, rp, dp);
-            real mu[3], Bc; cube_pair_numbers(E.type, mu, Bc);
+            real mu[3], Bc; cube_pair_numbers(KC, E.type, mu, Bc);
             mask = pattern_of(mu, Bc, E.kterm, false, dp, dv);
             same = same && (!tw || mask == E.mask);
 #ifdef MCG_DBG_PRINT
@@ -1154,6 +1167,7 @@ struct CubeSys {
   __device__ __noinline__ bool coupled_linesearch(CoupledMem* Mm) { return coupled_linesearch_impl<ADD_M>(Mm); }
   template <bool ADD_M>
   MCG_DEV bool coupled_linesearch_impl(CoupledMem* Mm) {
+    const CubeConsts KC = hoist();
     real ar[NB], ac[6], pr[NB], pc[6], qd[NB], sgl[10], arefl[10];
     for (int i = 0; i < NB; i++) { ar[i] = Mm->ar[i]; pr[i] = Mm->xr[i] - ar[i]; qd[i] = Mm->qd[i]; }
     _Pragma("unroll") for (int d = 0; d < 6; d++) { ac[d] = Mm->ac[d]; pc[d] = Mm->xc[d] - ac[d]; }
@@ -1166,17 +1180,17 @@ struct CubeSys {
     {
       TwistCols T; twist_cols(T);
       Twists RA, RP; rel_twists(T, ac, ar, RA); rel_twists(T, pc, pr, RP);
-      for (int c = 0; __any(c < ncon); c++) {
-        const int type = sel((c < ncon), (int)S.ld(LDS_CON + c * CON_STRIDE + 15), 0);
-        const bool tw = (c < ncon) && pair_has_cube(type), st = (c < ncon) && !pair_has_cube(type);
+      for (int c = 0; __any(c < KC.ncon); c++) {
+        const int type = sel((c < KC.ncon), (int)S.ld(LDS_CON + c * CON_STRIDE + 15), 0);
+        const bool tw = (c < KC.ncon) && pair_has_cube(type), st = (c < KC.ncon) && !pair_has_cube(type);
         real da[4] = {0, 0, 0, 0}, dv[4] = {0, 0, 0, 0}, dp[4] = {0, 0, 0, 0}, mu[3] = {0, 0, 0}, Bc = 0, kterm = 0; int mask = 0; bool dim3 = false;
         if (__any(tw)) {
-          TwistRows E; twist_rows(c, E);
+          TwistRows E; twist_rows(KC, c, E);
           real ra[6], rp[6], ta[4], tp_[4];
           pick_twist(RA, E.cls, ra); pick_twist(RP, E.cls, rp);
           tdots(E, ra, ta); tdots(E, rp, tp_);
           _Pragma("unroll") for (int b = 0; b < 4; b++) { da[b] = ta[b]; dp[b] = tp_[b]; dv[b] = sel(tw, S.ld(LDS_DV + c * 4 + b), 0.0); }
-          cube_pair_numbers(E.type, mu, Bc); kterm = E.kterm; mask = E.mask;
+          cube_pair_numbers(KC, E.type, mu, Bc); kterm = E.kterm; mask = E.mask;
         }
         if (__any(st)) {
           Coupled K; contact_of(c, K);
@@ -1193,8 +1207,8 @@ struct CubeSys {
             const real m = odd ? -mu[k] : mu[k];
             const bool absent = dim3 && k == 2;
             const real r0 = sel(absent, 1.0, fma(m, da[1 + k], da[0]) - (-Bc * fma(m, dv[1 + k], dv[0]) - kterm)), jp = sel(absent, 0.0, fma(m, dp[1 + k], dp[0]));
-            if (c < ncon) { S.st(LDS_ROW + (c * 6 + r) * 2, r0); S.st(LDS_ROW + (c * 6 + r) * 2 + 1, jp); }      // absent: a row that never activates
-            same = same && (c >= ncon || ((r0 + jp) < 0) == (((mask >> r) & 1) != 0)); }); });
+            if (c < KC.ncon) { S.st(LDS_ROW + (c * 6 + r) * 2, r0); S.st(LDS_ROW + (c * 6 + r) * 2 + 1, jp); }      // absent: a row that never activates
+            same = same && (c >= KC.ncon || ((r0 + jp) < 0) == (((mask >> r) & 1) != 0)); }); });
       }
     }
     const bool finish = !conv && same;
