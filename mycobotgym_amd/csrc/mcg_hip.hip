@@ -242,7 +242,11 @@ __global__ __launch_bounds__(SPLIT ? 192 : 64) void step_reach_kernel(Cfg C, Vie
   }
 
   guard_robot(E.R, E.qlag6);
-  load_episode(V, i, E);
+  // The row addresses of the state arrays must be RECOMPUTED here, not carried: the compiler otherwise keeps the 49 addresses it formed
+  // for load_robot alive across the whole sub-step loop for store_env -- spilled, they were the kernel's entire scratch frame (396 B
+  // per lane) and, as scratch lines, half of its HBM traffic.  An opaque copy of the env index cuts the common subexpressions.
+  int i_tail = i; asm volatile("" : "+v"(i_tail));
+  load_episode(V, i_tail, E);
   if (C.block_gripper) {       // _step_callback (mycobot.py:300-306): finger joints := 0, then mj_forward removes the lag
     E.R.q[7] = 0; E.R.q[9] = 0;
     for (int k = 0; k < 6; k++) E.qlag6[k] = E.R.q[k];
@@ -276,7 +280,7 @@ __global__ __launch_bounds__(SPLIT ? 192 : 64) void step_reach_kernel(Cfg C, Vie
     for (int k = 0; k < 3; k++) ag[k] = sel(done, ag2[k], ag[k]);
   }
   write_obs(O, i, 10, obs, ag, E.goal);
-  store_env(V, i, E);
+  store_env(V, i_tail, E);
   MCG_TICK(ST_POST);
   MCG_TICK_FLUSH();
 }
@@ -640,7 +644,8 @@ __global__ __launch_bounds__(DUAL ? 256 : PNP_LANES) void step_pnp_kernel(Cfg C,
     E.touch = MS.ld(XCH_T0) != 0.0;
   }
   guard_robot(E.R, E.qlag6);
-  load_episodep(V, i, E);
+  int i_tail = i; asm volatile("" : "+v"(i_tail));      // recompute the state rows' addresses for the tail (see step_reach_kernel)
+  load_episodep(V, i_tail, E);
   {   // same guard for the cube: back to its model pose at rest
     bool bad = false;
     for (int k = 0; k < 3; k++) bad = bad || bad_value(E.Cb.pos[k]);
@@ -703,7 +708,7 @@ __global__ __launch_bounds__(DUAL ? 256 : PNP_LANES) void step_pnp_kernel(Cfg C,
     for (int k = 0; k < 3; k++) ag[k] = sel(done, ag2[k], ag[k]);
   }
   write_obs(O, i, D, obs, ag, E.goal);
-  store_envp(V, i, E);
+  store_envp(V, i_tail, E);
   MCG_TICK(ST_POST);
   MCG_TICK_FLUSH();
 }
