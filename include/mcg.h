@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MCG_ABI_VERSION 4
+#define MCG_ABI_VERSION 5
 
 enum { MCG_OK = 0, MCG_ERR_ARG = 1, MCG_ERR_HIP = 2, MCG_ERR_UNSUPPORTED = 3 };
 enum { MCG_CTRL_JOINT = 0, MCG_CTRL_IK = 1, MCG_CTRL_MOCAP = 2 };   /* controller_type "joint" | "IK" | "mocap" */
@@ -72,6 +72,9 @@ typedef struct mcg_model {
   double link_hull[8][26][3];       /* vertices in the frame of the engine body the geom rides on: polytope p on body min(p, 5) */
   double link_hull_box[8][6];       /* centre and half extents of the vertices' bounding box in that frame (broad phase) */
   double link_diag[8][2];           /* body_invweight0 of the geom's MJCF body (translational, rotational) */
+  double link_ext[8][13][2];        /* least and largest d . v over the polytope's vertices for the 13 canonical directions d of the body
+                                       frame (axes, face diagonals, space diagonals, integer components; order: MCG_DIR13 in
+                                       csrc/mcg_cube.hpp): extra separating axes of the table test */
   double link_mult;                 /* identical colliding geoms per mesh (the reference attaches every mesh twice: 2) */
   /* ... second stage: the two finger-link meshes (mycobot280_main.xml:195-199,222-225) against the cube, as the oriented bounding box
      of the mesh's support polytope through the exact box-box routine (the first stage's box-face-axes test over-reports contacts

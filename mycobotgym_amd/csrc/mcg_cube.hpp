@@ -34,6 +34,8 @@ typedef LaneScratchT<PNP_LANES> PnpScratch;
 enum { PAIR_TABLE_CUBE = 0, PAIR_PADR_CUBE = 1, PAIR_PADL_CUBE = 2, PAIR_TABLE_PADR = 3, PAIR_TABLE_PADL = 4, PAIR_TABLE_LINK0 = 5,
        PAIR_FINR_CUBE = PAIR_TABLE_LINK0 + 8, PAIR_FINL_CUBE = PAIR_FINR_CUBE + 1,      // finger-link mesh - cube: bodies of pad-cube
        PAR_FIN_CUBE = 6 };                                                               // ... with their own row of contact_par
+// the 13 canonical directions of a polytope's frame (axes, face diagonals, space diagonals): extra separating axes of the table test
+constexpr int MCG_DIR13[13][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}, {1, 1, 0}, {1, -1, 0}, {1, 0, 1}, {1, 0, -1}, {0, 1, 1}, {0, 1, -1}, {1, 1, 1}, {1, 1, -1}, {1, -1, 1}, {1, -1, -1}};
 // a contact that involves the cube (twist space in the coupled solve) / its class there: 0 table, 1 right finger body, 2 left
 MCG_DEV bool pair_has_cube(int type) { return type < PAIR_TABLE_PADR || type >= PAIR_FINR_CUBE; }
 MCG_DEV int pair_class(int type) { return (type == PAIR_PADR_CUBE || type == PAIR_FINR_CUBE) ? 1 : ((type == PAIR_PADL_CUBE || type == PAIR_FINL_CUBE) ? 2 : 0); }
@@ -391,6 +393,17 @@ struct CubeSys {
             depth = sel(tp_, dp, depth); axis = sel(tp_, a, axis); plus = sel(tp_, true, plus);
             const bool tn_ = dn < depth;
             depth = sel(tn_, dn, depth); axis = sel(tn_, a, axis); plus = sel(tn_, false, plus);
+          }
+          // ... or one of the polytope's own 13 canonical axes separates (mcg_model.link_ext): without them a link diagonally off an
+          // edge of the table counts as touching whenever its table-aligned extent overlaps the table
+          if (__any(!sep)) {
+            real ext[26]; ldc<26>(&H->link_ext[pi][0][0], ext);
+            static_for<13>([&](auto Kk) { constexpr int k = Kk;
+              real w[3];
+              _Pragma("unroll") for (int r = 0; r < 3; r++) w[r] = MCG_DIR13[k][0] * Rio[3*r] + MCG_DIR13[k][1] * Rio[3*r+1] + MCG_DIR13[k][2] * Rio[3*r+2];
+              const real rel = (pio[0] - tp[0]) * w[0] + (pio[1] - tp[1]) * w[1] + (pio[2] - tp[2]) * w[2];
+              const real rad = th[0] * fabs(w[0]) + th[1] * fabs(w[1]) + th[2] * fabs(w[2]);
+              sep = sep || (rel + ext[2*k] > rad) || (rel + ext[2*k + 1] < -rad); });
           }
           const bool topface = (axis == 2) && plus;
           real wd[3] = {wz[0], wz[1], wz[2]};

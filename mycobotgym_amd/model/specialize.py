@@ -247,6 +247,8 @@ def specialize(m: dict, weld_rule: str = "common") -> dict:
         # --- convex-mesh collision, first stage: support polytopes of the arm-side mesh geoms, in engine body frames
         names = ("link1", "link2", "link3", "link4", "link5", "link6", "flange", "gripper_base")
         hull = np.zeros((8, 26, 3)); box = np.zeros((8, 6)); ldiag = np.zeros((8, 2)); mult = set()
+        dir13 = np.array([(1, 0, 0), (0, 1, 0), (0, 0, 1), (1, 1, 0), (1, -1, 0), (1, 0, 1), (1, 0, -1), (0, 1, 1), (0, 1, -1), (1, 1, 1), (1, 1, -1), (1, -1, 1), (1, -1, -1)], dtype=float)      # MCG_DIR13 (csrc/mcg_cube.hpp), DIR13 (oracle/mco_collision.c)
+        lext = np.zeros((8, 13, 2))
         for p, nm in enumerate(names):
             gs = [g for g in range(m["ngeom"]) if m["geom_type"][g] == 7 and m["geom_mesh"][g] == nm
                   and m["geom_contype"][g] and m["geom_conaffinity"][g]]
@@ -260,13 +262,14 @@ def specialize(m: dict, weld_rule: str = "common") -> dict:
             hull[p, :len(v)] = v; hull[p, len(v):] = v[0]                      # padded with a repeat: extremes and first occurrences unchanged
             box[p] = np.concatenate([0.5 * (v.max(0) + v.min(0)), 0.5 * (v.max(0) - v.min(0))])
             ldiag[p] = biw[m["geom_body"][g]]
+            proj = v @ dir13.T; lext[p, :, 0] = proj.min(0); lext[p, :, 1] = proj.max(0)
             mult.add(len(gs))
             condim, fri, solref, solimp = mix_contact(m, gt, g)
             assert condim == 3
         assert len(mult) == 1
         cp.append(np.concatenate([_solparams(solref, solimp, h), fri]))
         out["contact_par"] = np.array(cp)    # + row 5: table - arm mesh (condim 3)
-        out["link_hull"] = hull; out["link_hull_box"] = box; out["link_diag"] = ldiag; out["link_mult"] = float(mult.pop())
+        out["link_hull"] = hull; out["link_hull_box"] = box; out["link_diag"] = ldiag; out["link_ext"] = lext; out["link_mult"] = float(mult.pop())
         for p in range(8):                # mcg_body.hull_rad: the free broad-phase number that travels with the body's other constants
             out["body"][min(p, 5), 15] = max(out["body"][min(p, 5), 15], float(np.linalg.norm(hull[p], axis=1).max()))
         # --- second stage: the finger-link meshes against the cube, as the bounding box (finger-link frame) of their support polytope.
