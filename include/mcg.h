@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MCG_ABI_VERSION 5
+#define MCG_ABI_VERSION 6
 
 enum { MCG_OK = 0, MCG_ERR_ARG = 1, MCG_ERR_HIP = 2, MCG_ERR_UNSUPPORTED = 3 };
 enum { MCG_CTRL_JOINT = 0, MCG_CTRL_IK = 1, MCG_CTRL_MOCAP = 2 };   /* controller_type "joint" | "IK" | "mocap" */
@@ -76,11 +76,13 @@ typedef struct mcg_model {
                                        frame (axes, face diagonals, space diagonals, integer components; order: MCG_DIR13 in
                                        csrc/mcg_cube.hpp): extra separating axes of the table test */
   double link_mult;                 /* identical colliding geoms per mesh (the reference attaches every mesh twice: 2) */
-  /* ... second stage: the two finger-link meshes (mycobot280_main.xml:195-199,222-225) against the cube, as the oriented bounding box
-     of the mesh's support polytope through the exact box-box routine (the first stage's box-face-axes test over-reports contacts
-     diagonally off the edges of a box as small as the cube).  The pads are welded to these links: same pair of bodies as pad-cube. */
-  double fin_box[2][6];             /* right, left: centre and half extents of the bounding box in the finger-link frame */
-  double fin_par[4];                /* identical colliding geoms per finger mesh | the mesh geoms' own sliding friction (the cube's is
+  /* ... second stage: the two finger-link meshes (mycobot280_main.xml:195-199,222-225) against the cube, on
+     the same support polytopes: separating-axis test over the cube's three face axes and the polytope's 13 canonical axes, one contact
+     along the axis of least penetration.  The pads are welded to the finger links: same pair of bodies as the pad-cube contacts. */
+  double fin_hull[2][26][3];        /* right, left finger link: vertices in the finger-link frame */
+  double fin_ext[2][13][2];         /* least and largest d . v over those vertices for the 13 canonical directions (as link_ext) */
+  double fin_box[2][6];             /* centre and half extents of the vertices' bounding box in that frame (broad phase) */
+  double fin_par[4];                /* identical colliding geoms per mesh | the mesh geoms' own sliding friction (the cube's is
                                        re-scaled under domain randomisation, the pair takes the larger) | summed translational
                                        body_invweight0 of (right finger link, cube), (left finger link, cube) */
   double geom_friction0[3];         /* sliding friction of the table, pad and cube geoms (re-mixed under domain randomisation) */

@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("MCG_LIB") or os.path.join(_HERE, "libmycobot_hip.so")
 
 MCG_OK, MCG_ERR_ARG, MCG_ERR_HIP, MCG_ERR_UNSUPPORTED = 0, 1, 2, 3
 CTRL_JOINT, CTRL_IK, CTRL_MOCAP = 0, 1, 2
-ABI_VERSION = 5
+ABI_VERSION = 6
 REWARD_SPARSE, REWARD_DENSE, REWARD_SHAPING = 0, 1, 2
 
 d = C.c_double
@@ -44,7 +44,7 @@ class McgModel(C.Structure):
         ("contact_par", (d * 15) * 7),
         ("contact_diag", (d * 2) * 5),
         ("link_hull", ((d * 3) * 26) * 8), ("link_hull_box", (d * 6) * 8), ("link_diag", (d * 2) * 8), ("link_ext", ((d * 2) * 13) * 8), ("link_mult", d),
-        ("fin_box", (d * 6) * 2), ("fin_par", d * 4),
+        ("fin_hull", ((d * 3) * 26) * 2), ("fin_ext", ((d * 2) * 13) * 2), ("fin_box", (d * 6) * 2), ("fin_par", d * 4),
         ("geom_friction0", d * 3),
         ("base_quat", d * 4), ("weld_on", d), ("weld_par", d * 10), ("weld_diag", d * 2), ("weld_anchor", d * 3),
         ("weld_relpos", d * 3), ("weld_relquat", d * 4), ("weld_torquescale", d),

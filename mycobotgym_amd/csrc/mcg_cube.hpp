@@ -34,6 +34,9 @@ typedef LaneScratchT<PNP_LANES> PnpScratch;
 enum { PAIR_TABLE_CUBE = 0, PAIR_PADR_CUBE = 1, PAIR_PADL_CUBE = 2, PAIR_TABLE_PADR = 3, PAIR_TABLE_PADL = 4, PAIR_TABLE_LINK0 = 5,
        PAIR_FINR_CUBE = PAIR_TABLE_LINK0 + 8, PAIR_FINL_CUBE = PAIR_FINR_CUBE + 1,      // finger-link mesh - cube: bodies of pad-cube
        PAR_FIN_CUBE = 6 };                                                               // ... with their own row of contact_par
+constexpr int NCLS = 3;      // classes of cube contacts in the coupled solve: 0 table, 1 right finger body, 2 left.  (A fourth -- link6, for the
+                             // gripper base against the cube -- was built and measured: 27 more accumulator registers slow the WHOLE
+                             // coupled solve by 50 %, contacts or not: scripted grasp 11.4 -> 17.0 ms/step.  Not kept.)
 // the 13 canonical directions of a polytope's frame (axes, face diagonals, space diagonals): extra separating axes of the table test
 constexpr int MCG_DIR13[13][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}, {1, 1, 0}, {1, -1, 0}, {1, 0, 1}, {1, 0, -1}, {0, 1, 1}, {0, 1, -1}, {1, 1, 1}, {1, 1, -1}, {1, -1, 1}, {1, -1, -1}};
 // a contact that involves the cube (twist space in the coupled solve) / its class there: 0 table, 1 right finger body, 2 left
@@ -498,20 +501,82 @@ struct CubeSys {
         touch[sd] = CL.n > before;
         any_pad = any_pad || touch[sd]; });
     }
-    // finger-link meshes - cube (second stage): the mesh's oriented bounding box through the exact box-box routine, the
-    // mesh as geom1.  Each entry stands for the two identical geoms the reference attaches (multiplicity, as for the arm meshes).
+    // Finger-link meshes - cube (second stage; the oracle's box_polytope with full = 1, the mesh as geom1): right, left.  Separating-axis test over the cube's three face axes and the
+    // polytope's 13 canonical axes, ONE contact along the axis of least penetration: a cube face -> at the polytope's deepest vertex;
+    // a polytope axis -> at the cube's deepest corner along it.  Each entry stands for the two identical geoms the reference attaches.
     if (__any(reach)) {
-      static_for<2>([&](auto Sd) { constexpr int sd = Sd;
-        real fb[6]; ldc<6>(Q->fin_box[sd], fb);
-        real fc[3];
-        _Pragma("unroll") for (int k = 0; k < 3; k++) fc[k] = pf[sd][k] + Rs[sd][3*k]*fb[0] + Rs[sd][3*k+1]*fb[1] + Rs[sd][3*k+2]*fb[2];
-        const real fh[3] = {fb[3], fb[4], fb[5]};
-        const real dx = Cb.pos[0] - fc[0], dy = Cb.pos[1] - fc[1], dz = Cb.pos[2] - fc[2];
-        const real rs = sqrt(dot3(fh, fh)) + sqrt(dot3(hc, hc));
-        const bool near = reach && (dx*dx + dy*dy + dz*dz <= rs*rs);
+      auto mesh_cube = [&](int mi, const real* Rf, const real* pfr, int type) {
+        ModelPtr H = launder(Pm);
+        real fb[6]; ldc<6>(H->fin_box[mi], fb);
+        real cw[3];
+        _Pragma("unroll") for (int k = 0; k < 3; k++) cw[k] = pfr[k] + Rf[3*k]*fb[0] + Rf[3*k+1]*fb[1] + Rf[3*k+2]*fb[2] - Cb.pos[k];
+        const real rs = sqrt(fb[3]*fb[3] + fb[4]*fb[4] + fb[5]*fb[5]) + sqrt(dot3(hc, hc));
+        const bool near = reach && dot3(cw, cw) <= rs * rs;                 // bounding spheres
+        if (!__any(near)) return;
+        real lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY}, wlo[3][3], whi[3][3];
+        _Pragma("unroll") for (int a = 0; a < 3; a++) { _Pragma("unroll") for (int r = 0; r < 3; r++) wlo[a][r] = whi[a][r] = 0; }
+        for (int k = 0; k < 26; k++) {
+          real v[3]; ldc<3>(H->fin_hull[mi][k], v);
+          real w[3], rel[3];
+          _Pragma("unroll") for (int r = 0; r < 3; r++) { w[r] = pfr[r] + Rf[3*r]*v[0] + Rf[3*r+1]*v[1] + Rf[3*r+2]*v[2]; rel[r] = w[r] - Cb.pos[r]; }
+          _Pragma("unroll") for (int a = 0; a < 3; a++) {
+            const real c = rel[0]*Rc[a] + rel[1]*Rc[3 + a] + rel[2]*Rc[6 + a];          // along the cube's axis a
+            const bool lower = c < lo[a], higher = c > hi[a];                           // first occurrence of each extreme, as the oracle keeps it
+            lo[a] = sel(lower, c, lo[a]); hi[a] = sel(higher, c, hi[a]);
+            _Pragma("unroll") for (int r = 0; r < 3; r++) { wlo[a][r] = sel(lower, w[r], wlo[a][r]); whi[a][r] = sel(higher, w[r], whi[a][r]); }
+          }
+        }
+        bool sep = !near; real depth = INFINITY; int axis = 0; bool plus = true;
+        _Pragma("unroll") for (int a = 0; a < 3; a++) {
+          sep = sep || (lo[a] > hc[a]) || (hi[a] < -hc[a]);
+          const real dp = hc[a] - lo[a], dn = hi[a] + hc[a];
+          const bool tp_ = dp < depth;
+          depth = sel(tp_, dp, depth); axis = sel(tp_, a, axis); plus = sel(tp_, true, plus);
+          const bool tn_ = dn < depth;
+          depth = sel(tn_, dn, depth); axis = sel(tn_, a, axis); plus = sel(tn_, false, plus);
+        }
+        real nw[3] = {0, 0, 0};                                             // the normal when a polytope axis wins (cube -> mesh)
+        {
+          real ext[26]; ldc<26>(&H->fin_ext[mi][0][0], ext);
+          static_for<13>([&](auto Kk) { constexpr int k = Kk;
+            constexpr real il = 1.0 / (MCG_DIR13[k][0]*MCG_DIR13[k][0] + MCG_DIR13[k][1]*MCG_DIR13[k][1] + MCG_DIR13[k][2]*MCG_DIR13[k][2] == 1 ? 1.0 :
+                                       (MCG_DIR13[k][0]*MCG_DIR13[k][0] + MCG_DIR13[k][1]*MCG_DIR13[k][1] + MCG_DIR13[k][2]*MCG_DIR13[k][2] == 2 ? 1.4142135623730951 : 1.7320508075688772));
+            real w[3];
+            _Pragma("unroll") for (int r = 0; r < 3; r++) w[r] = MCG_DIR13[k][0] * Rf[3*r] + MCG_DIR13[k][1] * Rf[3*r+1] + MCG_DIR13[k][2] * Rf[3*r+2];
+            const real rel = (pfr[0] - Cb.pos[0]) * w[0] + (pfr[1] - Cb.pos[1]) * w[1] + (pfr[2] - Cb.pos[2]) * w[2];
+            real rad = 0;
+            _Pragma("unroll") for (int a = 0; a < 3; a++) rad += hc[a] * fabs(Rc[a]*w[0] + Rc[3 + a]*w[1] + Rc[6 + a]*w[2]);
+            sep = sep || (rel + ext[2*k] > rad) || (rel + ext[2*k + 1] < -rad);
+            const real dp = (rad - (rel + ext[2*k])) * il, dn = ((rel + ext[2*k + 1]) + rad) * il;
+            const bool tp_ = dp < depth;
+            depth = sel(tp_, dp, depth); axis = sel(tp_, 3 + k, axis);
+            _Pragma("unroll") for (int r = 0; r < 3; r++) nw[r] = sel(tp_, w[r] * il, nw[r]);
+            const bool tn_ = dn < depth;
+            depth = sel(tn_, dn, depth); axis = sel(tn_, 3 + k, axis);
+            _Pragma("unroll") for (int r = 0; r < 3; r++) nw[r] = sel(tn_, -w[r] * il, nw[r]); });
+        }
+        const bool face = axis < 3;
+        real n[3], pos[3];
+        _Pragma("unroll") for (int r = 0; r < 3; r++) {
+          const real ax = sel3(axis, Rc[3*r], Rc[3*r + 1], Rc[3*r + 2]);                // (axis >= 3 picks the third: unused then)
+          n[r] = sel(face, plus ? ax : -ax, nw[r]);                                       // from the cube to the mesh
+        }
+        real xb[3] = {Cb.pos[0], Cb.pos[1], Cb.pos[2]};                                   // the cube's deepest corner along n
+        _Pragma("unroll") for (int a = 0; a < 3; a++) {
+          const real sg = (n[0]*Rc[a] + n[1]*Rc[3 + a] + n[2]*Rc[6 + a]) > 0 ? 1.0 : -1.0;
+          _Pragma("unroll") for (int r = 0; r < 3; r++) xb[r] += sg * hc[a] * Rc[3*r + a];
+        }
+        _Pragma("unroll") for (int r = 0; r < 3; r++) {
+          const real wv = plus ? sel3(axis, wlo[0][r], wlo[1][r], wlo[2][r]) : sel3(axis, whi[0][r], whi[1][r], whi[2][r]);
+          pos[r] = sel(face, wv + 0.5 * depth * n[r], xb[r] - 0.5 * depth * n[r]);
+        }
+        const real nm[3] = {-n[0], -n[1], -n[2]};                                         // the mesh is geom1: normal from the mesh to the cube
         const int before = CL.n;
-        if (__any(near)) box_box(CL, near, fc, Rs[sd], fh, Cb.pos, Rc, hc, PAIR_FINR_CUBE + sd, (int)Q->fin_par[0]);
-        any_pad = any_pad || (CL.n > before); });
+        CL.add(pos, nm, sep ? 1.0 : -depth, type, (int)H->fin_par[0]);
+        any_pad = any_pad || (CL.n > before);
+      };
+      mesh_cube(0, Rs[0], pf[0], PAIR_FINR_CUBE);
+      mesh_cube(1, Rs[1], pf[1], PAIR_FINL_CUBE);
     }
     ncon = CL.n;
     scan_sides();
@@ -816,7 +881,7 @@ struct CubeSys {
     }
   }
   // relative twists of the three classes for cube vector vc (v ; omega body frame) and robot vector vr (12)
-  struct Twists { real r[3][6]; };
+  struct Twists { real r[NCLS][6]; };
   MCG_DEV void rel_twists(const TwistCols& T, const real* vc, const real* vr, Twists& W) const {
     real tc[6], ua[6], us[2][6];
     _Pragma("unroll") for (int k = 0; k < 3; k++) { tc[k] = vc[k]; tc[3 + k] = Rc[3*k]*vc[3] + Rc[3*k+1]*vc[4] + Rc[3*k+2]*vc[5]; }
@@ -929,8 +994,8 @@ struct CubeSys {
       _Pragma("unroll") for (int k = 0; k < 60; k++) S.st(CM + k, 0.0);
     }
     MCG_TICK(ST_A_G);
-    real At[3][21], bt[3][6];                    // twist-space accumulators: table-cube, right pad-cube, left pad-cube
-    _Pragma("unroll") for (int q = 0; q < 3; q++) { _Pragma("unroll") for (int k = 0; k < 21; k++) At[q][k] = 0; _Pragma("unroll") for (int k = 0; k < 6; k++) bt[q][k] = 0; }
+    real At[NCLS][21], bt[NCLS][6];              // twist-space accumulators: table-cube, right finger body-cube, left finger body-cube
+    _Pragma("unroll") for (int q = 0; q < NCLS; q++) { _Pragma("unroll") for (int k = 0; k < 21; k++) At[q][k] = 0; _Pragma("unroll") for (int k = 0; k < 6; k++) bt[q][k] = 0; }
     real grs[10];                                // static contacts' part of the robot right-hand side
     _Pragma("unroll") for (int j = 0; j < 10; j++) grs[j] = 0;
 
@@ -957,7 +1022,7 @@ struct CubeSys {
         const real e3 = d < 3 ? 0.0 : E.n[d < 3 ? 0 : d - 3];
         dA[tri(d, e)] = E.e[0][d] * U[0][e] + E.e[1][d] * U[1][e] + E.e[2][d] * U[2][e] + e3 * U[3][e]; }); });
       // the lane's class takes the update (weights are zero for lanes without a live twist-space contact here)
-      static_for<3>([&](auto Qq) { constexpr int q = Qq; const real on = (E.cls == q) ? 1.0 : 0.0;
+      static_for<NCLS>([&](auto Qq) { constexpr int q = Qq; const real on = (E.cls == q) ? 1.0 : 0.0;
         _Pragma("unroll") for (int k = 0; k < 21; k++) At[q][k] = fma(on, dA[k], At[q][k]);
         _Pragma("unroll") for (int k = 0; k < 6; k++) bt[q][k] = fma(on, db[k], bt[q][k]); });
     };

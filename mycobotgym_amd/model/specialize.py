@@ -272,9 +272,9 @@ def specialize(m: dict, weld_rule: str = "common") -> dict:
         out["link_hull"] = hull; out["link_hull_box"] = box; out["link_diag"] = ldiag; out["link_ext"] = lext; out["link_mult"] = float(mult.pop())
         for p in range(8):                # mcg_body.hull_rad: the free broad-phase number that travels with the body's other constants
             out["body"][min(p, 5), 15] = max(out["body"][min(p, 5), 15], float(np.linalg.norm(hull[p], axis=1).max()))
-        # --- second stage: the finger-link meshes against the cube, as the bounding box (finger-link frame) of their support polytope.
+        # --- second stage: the finger-link meshes against the cube, on their support polytopes.
         # The pads are welded to the finger links (same rigid bodies as the pad-cube pairs), but the inverse weights are the LINK's own.
-        fbox = np.zeros((2, 6)); fmult = set(); ffric = set(); ftran = []
+        fbox = np.zeros((2, 6)); fhull = np.zeros((2, 26, 3)); fext = np.zeros((2, 13, 2)); fmult = set(); ffric = set(); ftran = []
         for sd, (nm, fing, gp) in enumerate((("right_finger_link", 7, gr), ("left_finger_link", 9, gl))):
             gs = [g for g in range(m["ngeom"]) if m["geom_type"][g] == 7 and m["geom_mesh"][g] == nm
                   and m["geom_contype"][g] and m["geom_conaffinity"][g]]
@@ -282,18 +282,22 @@ def specialize(m: dict, weld_rule: str = "common") -> dict:
             assert gs and 4 <= len(sup) <= 26, nm
             g = gs[0]
             root, R, pw = weld_frames[m["geom_body"][g]]
-            assert root == fing and np.allclose(R, np.eye(3)), "finger-link mesh: rides on the finger body without rotation expected"
+            assert root == fing and np.allclose(R, np.eye(3)), "mesh rides on its engine body (finger / link6) without rotation expected"
             assert np.allclose(m["geom_pos"][g], 0) and np.allclose(m["geom_quat"][g], [1, 0, 0, 0])
-            assert m["body_weldid"][m["geom_body"][g]] == m["body_weldid"][m["geom_body"][gp]], "pad welded to its finger link expected"
-            fbox[sd] = np.concatenate([pw + 0.5 * (sup.max(0) + sup.min(0)), 0.5 * (sup.max(0) - sup.min(0))])
+            if gp is not None:
+                assert m["body_weldid"][m["geom_body"][g]] == m["body_weldid"][m["geom_body"][gp]], "pad welded to its finger link expected"
+            v = pw + sup @ R.T
+            fhull[sd, :len(v)] = v; fhull[sd, len(v):] = v[0]                 # padded with a repeat: extremes and first occurrences unchanged
+            fbox[sd] = np.concatenate([0.5 * (v.max(0) + v.min(0)), 0.5 * (v.max(0) - v.min(0))])
+            proj = v @ dir13.T; fext[sd, :, 0] = proj.min(0); fext[sd, :, 1] = proj.max(0)
             fmult.add(len(gs)); ffric.add(float(m["geom_friction"][g][0]))
             ftran.append(float(biw[m["geom_body"][g]][0] + bt(gc)[0]))
             condim, fri, solref, solimp = mix_contact(m, g, gc)
             assert condim == 4
-        assert len(fmult) == 1 and len(ffric) == 1
+        assert len(fmult) == 1 and len(ffric) == 1                  # (and one set of pair parameters: all three are default mesh geoms)
         cp.append(np.concatenate([_solparams(solref, solimp, h), fri]))
         out["contact_par"] = np.array(cp)    # + row 6: finger mesh - cube (condim 4)
-        out["fin_box"] = fbox; out["fin_par"] = np.array([float(fmult.pop()), ffric.pop()] + ftran)
+        out["fin_hull"] = fhull; out["fin_ext"] = fext; out["fin_box"] = fbox; out["fin_par"] = np.array([float(fmult.pop()), ffric.pop()] + ftran)
     return out
 
 

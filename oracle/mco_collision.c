@@ -238,7 +238,17 @@ static void plane_polytope(const mco_model* m, mco_data* d, int gp, int gm) {
   double pos[3] = { bw[0] - 0.5*best*n[0], bw[1] - 0.5*best*n[1], bw[2] - 0.5*best*n[2] };
   add_contact(m, d, gp, gm, pos, n, best);
 }
-static void box_polytope(const mco_model* m, mco_data* d, int gb, int gm) {
+/* Box <-> support polytope of a mesh.  Separating-axis test over the box's three face axes and the polytope's own 13 canonical axes
+ * (its frame's axes, face diagonals and space diagonals: the directions its vertices are support points of -- together they bound the
+ * polytope by its 26-DOP).  Without the 13 a polytope diagonally off an edge of the box counts as touching whenever its box-aligned
+ * extent overlaps the box (round 2: a finger 2.4 cm from the cube's centre; a link beside the table's edge).  ONE contact:
+ *   full = 0 (the static table): along the box FACE of least penetration, at the polytope's deepest vertex;
+ *   full = 1 (the cube):         along the axis of least penetration among all 16; for a polytope axis the contact sits at the box's
+ *                                deepest corner along it.
+ * flip: the mesh is geom1 and the box geom2 (a gripper mesh against the cube, which comes later in geom order): the contact's normal
+ * then points from the mesh to the box. */
+static const int DIR13[13][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}, {1, 1, 0}, {1, -1, 0}, {1, 0, 1}, {1, 0, -1}, {0, 1, 1}, {0, 1, -1}, {1, 1, 1}, {1, 1, -1}, {1, -1, 1}, {1, -1, -1}};
+static void box_polytope(const mco_model* m, mco_data* d, int gb, int gm, int full, int flip) {
   const double* pb = d->geom_xpos[gb]; const double* Rb = d->geom_xmat[gb]; const double* h = m->geom_size[gb];
   double lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
   double wlo[3][3], whi[3][3];                      /* the vertices that realise the extremes (first occurrence) */
@@ -253,11 +263,13 @@ static void box_polytope(const mco_model* m, mco_data* d, int gb, int gm) {
     }
   }
   for (int a = 0; a < 3; a++) if (lo[a] > h[a] || hi[a] < -h[a]) return;      /* a face axis separates */
-  /* ... or one of the polytope's own 13 canonical axes does (its frame's axes, face diagonals and space diagonals: the directions its
-   * vertices are support points of).  Without them a polytope diagonally off an edge of the box counts as touching whenever its
-   * box-aligned extent overlaps the box (round 2: a finger 2.4 cm from the cube's centre; a link beside the table's edge). */
+  double depth = INFINITY; int axis = 0, sign = 1; double n[3] = { 0, 0, 0 };
+  for (int a = 0; a < 3; a++) {
+    double dp = h[a] - lo[a], dn = hi[a] + h[a];    /* push the polytope out through face +a / -a */
+    if (dp < depth) { depth = dp; axis = a; sign = 1; }
+    if (dn < depth) { depth = dn; axis = a; sign = -1; }
+  }
   if (!m->rule[7]) {      /* study switch rule[7] = 1: the face axes alone (the first version of this test) */
-    static const int DIR13[13][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}, {1, 1, 0}, {1, -1, 0}, {1, 0, 1}, {1, 0, -1}, {0, 1, 1}, {0, 1, -1}, {1, 1, 1}, {1, 1, -1}, {1, -1, 1}, {1, -1, -1}};
     const double* Rm = d->geom_xmat[gm]; const double* pm = d->geom_xpos[gm];
     for (int k = 0; k < 13; k++) {
       double mn = INFINITY, mx = -INFINITY;
@@ -273,29 +285,38 @@ static void box_polytope(const mco_model* m, mco_data* d, int gb, int gm) {
       double rad = 0;
       for (int a = 0; a < 3; a++) { double ax[3]; col(Rb, a, ax); rad += h[a] * fabs(dot3(ax, w)); }
       if (rel + mn > rad || rel + mx < -rad) return;
+      if (full) {
+        int l2 = DIR13[k][0]*DIR13[k][0] + DIR13[k][1]*DIR13[k][1] + DIR13[k][2]*DIR13[k][2];
+        double il = 1.0 / (l2 == 1 ? 1.0 : (l2 == 2 ? 1.4142135623730951 : 1.7320508075688772));      /* the kernels' constants */
+        double dp = (rad - (rel + mn)) * il, dn = ((rel + mx) + rad) * il;        /* push the polytope out along +w / -w */
+        if (dp < depth) { depth = dp; axis = 3 + k; sign = 1; for (int r = 0; r < 3; r++) n[r] = w[r] * il; }
+        if (dn < depth) { depth = dn; axis = 3 + k; sign = -1; for (int r = 0; r < 3; r++) n[r] = -w[r] * il; }
+      }
     }
   }
-  double depth = INFINITY; int axis = 0, sign = 1;
-  for (int a = 0; a < 3; a++) {
-    double dp = h[a] - lo[a], dn = hi[a] + h[a];    /* push the polytope out through face +a / -a */
-    if (dp < depth) { depth = dp; axis = a; sign = 1; }
-    if (dn < depth) { depth = dn; axis = a; sign = -1; }
+  double pos[3];
+  if (axis < 3) {
+    col(Rb, axis, n); for (int k = 0; k < 3; k++) n[k] *= sign;               /* from the box to the mesh */
+    const double* w = sign > 0 ? wlo[axis] : whi[axis];                        /* the vertex deepest inside */
+    for (int k = 0; k < 3; k++) pos[k] = w[k] + 0.5*depth*n[k];
+  } else {                                                                     /* the box's deepest corner along n, half a depth back */
+    double xb[3] = { pb[0], pb[1], pb[2] };
+    for (int a = 0; a < 3; a++) { double ax[3]; col(Rb, a, ax); double sg = dot3(n, ax) > 0 ? 1.0 : -1.0; for (int k = 0; k < 3; k++) xb[k] += sg * h[a] * ax[k]; }
+    for (int k = 0; k < 3; k++) pos[k] = xb[k] - 0.5*depth*n[k];
   }
-  double n[3]; col(Rb, axis, n); for (int k = 0; k < 3; k++) n[k] *= sign;    /* from the box (geom1) to the mesh (geom2) */
-  const double* w = sign > 0 ? wlo[axis] : whi[axis];                          /* the vertex deepest inside */
-  double pos[3] = { w[0] + 0.5*depth*n[0], w[1] + 0.5*depth*n[1], w[2] + 0.5*depth*n[2] };
-  add_contact(m, d, gb, gm, pos, n, -depth);
+  if (flip) { double nn[3] = { -n[0], -n[1], -n[2] }; add_contact(m, d, gm, gb, pos, nn, -depth); }
+  else add_contact(m, d, gb, gm, pos, n, -depth);
 }
 
 void mco_collision(const mco_model* m, mco_data* d) {
   d->ncon = 0;
   /* static primitive <-> arm-side mesh (support polytope): these pairs first, mesh by mesh (the order the kernels emit them in) */
   for (int g2 = 0; g2 < m->ngeom; g2++) {
-    if (m->geom_type[g2] != MCO_GEOM_MESH || m->hull_nvert[g2] <= 0 || m->collide_extra[g2] != 3) continue;
+    if (m->geom_type[g2] != MCO_GEOM_MESH || m->hull_nvert[g2] <= 0 || (m->collide_extra[g2] != 3 && m->collide_extra[g2] != 5)) continue;
     for (int g1 = 0; g1 < m->ngeom; g1++) {
       if (m->collide_extra[g1] != 1 || filtered(m, g1, g2)) continue;
       if (m->geom_type[g1] == MCO_GEOM_PLANE) plane_polytope(m, d, g1, g2);
-      else if (m->geom_type[g1] == MCO_GEOM_BOX) box_polytope(m, d, g1, g2);
+      else if (m->geom_type[g1] == MCO_GEOM_BOX) box_polytope(m, d, g1, g2, 0, 0);
     }
   }
   for (int g1 = 0; g1 < m->ngeom; g1++) for (int g2 = g1 + 1; g2 < m->ngeom; g2++) {
@@ -313,28 +334,14 @@ void mco_collision(const mco_model* m, mco_data* d) {
       box_box(m, d, g1, g2);
     }
   }
-  /* finger-link meshes (collide_extra 4) <-> the cube (second stage), after the primitive pairs: the mesh's oriented
-   * bounding box through box_box.  The reference attaches every mesh twice (two identical geoms): the twin's contacts are the same
-   * contacts again, emitted right after each original so that the cap of MCO_MAXCON cuts the list where the kernels' cut it. */
+  /* finger-link meshes (collide_extra 4; 5 = a mesh that also collides with the static geoms above: the rule supports the gripper base
+   * that way, the build does not enable it -- a fourth contact class costs the kernels' coupled solve 50 %) <-> the cube (SURVEY 8f-4,
+   * second stage), after the primitive pairs, geom by geom (the reference attaches every mesh twice: the twin's contact follows at once) */
   if (m->collide_scope_geom >= 0 && m->geom_type[m->collide_scope_geom] == MCO_GEOM_BOX) {
     int gc = m->collide_scope_geom;
     for (int g = 0; g < m->ngeom; g++) {
-      if (m->geom_type[g] != MCO_GEOM_MESH || m->collide_extra[g] != 4 || filtered(m, g, gc)) continue;
-      int twin = (g + 1 < m->ngeom && m->collide_extra[g + 1] == 4 && m->geom_body[g + 1] == m->geom_body[g]) ? g + 1 : -1;
-      int n0 = d->ncon;
-      if (g < gc) box_box(m, d, g, gc); else box_box(m, d, gc, g);
-      if (twin >= 0) {
-        mco_contact tmp[MCO_MAXCON]; int n1 = d->ncon, k = 0;
-        for (int c = n0; c < n1; c++) tmp[k++] = d->contact[c];
-        d->ncon = n0;
-        for (int c = 0; c < k; c++) for (int rep = 0; rep < 2; rep++) {
-          if (d->ncon >= MCO_MAXCON) break;
-          d->contact[d->ncon] = tmp[c];
-          if (rep) { if (g < gc) d->contact[d->ncon].geom1 = twin; else d->contact[d->ncon].geom2 = twin; }
-          d->ncon++;
-        }
-        g = twin;
-      }
+      if (m->geom_type[g] != MCO_GEOM_MESH || m->hull_nvert[g] <= 0 || (m->collide_extra[g] != 4 && m->collide_extra[g] != 5) || filtered(m, g, gc)) continue;
+      box_polytope(m, d, gc, g, 1, g < gc);
     }
   }
 }

@@ -60,9 +60,10 @@ typedef struct mco_model {
    * least penetration.  hull_nvert[g] = 0: geom g's mesh does not collide. */
   int hull_nvert[48];
   double hull_vert[48][26][3];   /* geom frame */
-  /* second stage: a finger-link mesh (collide_extra 4) collides with the cube as the ORIENTED BOUNDING BOX of its support polytope in the
-   * geom frame (centre obb_center[g], half extents in geom_size[g]) through the exact box-box routine.  (Tried first and rejected: the
-   * box-face-axes test of the first stage reports a finger 2.4 cm from the cube's centre, diagonally off a cube edge, as touching.) */
+  /* second stage: a finger-link mesh (collide_extra 4; 5 = 3 and 4, unused) collides with the cube on the same support
+   * polytope, 16-axis separating-axis test, one contact along the axis of least penetration (mco_collision.c: box_polytope).  Tried and
+   * dropped: the mesh's oriented bounding box through box-box (obb_center: a box geom's centre offset, zero for real boxes) -- the
+   * finger link's hull fills only 51 % of its bounding box, and a held cube touched that box in 70 % of perturbed grasp states. */
   double obb_center[48][3];
   /* Study switches (oracle/rule_study.py): alternatives to [RECALL] rules the reference's keyframes can discriminate.
    * All zero = the adopted rule set, which is what the HIP kernels implement and every parity test runs.

@@ -18,7 +18,7 @@ _lib = None
 
 MAXNQ, MAXNV, MAXU = 24, 24, 8
 ARM_MESHES = ("link1", "link2", "link3", "link4", "link5", "link6", "flange", "gripper_base")     # SURVEY 8f-4, first stage
-FINGER_MESHES = ("right_finger_link", "left_finger_link")                                              # second stage: against the cube
+FINGER_MESHES = ("right_finger_link", "left_finger_link")                                            # second stage: against the cube
 
 
 def build(force: bool = False) -> str:
@@ -107,13 +107,13 @@ class OracleModel:
                 sup = np.asarray(table.get("meshes", {}).get(name, {}).get("support", []), dtype=np.float64)
                 if mesh_collision and name in ARM_MESHES and len(sup):
                     extra[g] = 3; hn[g] = len(sup); hv[g, :len(sup)] = sup
-            # second stage: the finger-link meshes against the cube, as the oriented bounding box of their support polytope
+            # second stage: the finger-link meshes against the cube, on the same support polytopes
             obb = np.zeros((48, 3))
             for g in range(table["ngeom"]):
                 name = table["geom_mesh"][g] if table["geom_type"][g] == 7 else ""
                 sup = np.asarray(table.get("meshes", {}).get(name, {}).get("support", []), dtype=np.float64)
                 if mesh_collision and name in FINGER_MESHES and len(sup):
-                    extra[g] = 4; obb[g] = 0.5 * (sup.max(0) + sup.min(0)); self.obb_size[g] = 0.5 * (sup.max(0) - sup.min(0))
+                    extra[g] = 5 if extra[g] == 3 else 4; hn[g] = len(sup); hv[g, :len(sup)] = sup
             si("collide_extra", extra); si("hull_nvert", hn); sd("hull_vert", hv); sd("obb_center", obb)
         sd("timestep", [table["opt"]["timestep"]]); sd("gravity", table["opt"]["gravity"])
         for k in ("body_parent", "body_rootid", "body_weldid", "body_dofadr", "body_dofnum", "jnt_type", "jnt_body",

@@ -255,10 +255,9 @@ def _contact_table(d):
     return out
 
 
-def test_finger_link_boxes_against_the_cube(po):
-    """SURVEY 8f-4, second stage (oracle side): the finger-link meshes collide with the cube as oriented bounding boxes.  The pads
-    protrude beyond those boxes, so none of the scripted-grasp states holds such a contact; pushed sideways they appear, condim 4, the
-    mesh as geom1, each contact followed at once by its twin geom's copy (the reference attaches every mesh twice)."""
+def test_gripper_meshes_against_the_cube(po):
+    """SURVEY 8f-4, second stage (oracle side): the finger-link meshes collide with the cube on their support polytopes.  The pads protrude beyond the links, so none of the scripted-grasp states holds such a contact; pushed sideways they
+    appear, condim 4, the mesh as geom1, one contact per geom, the twin geom's copy right after (the reference attaches every mesh twice)."""
     from mycobotgym_amd.scenarios import grasp_state
     tab = load_json("mycobot280")
     scope = tab["geom_name"].index("object0")
