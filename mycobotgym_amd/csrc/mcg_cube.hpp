@@ -271,6 +271,7 @@ struct CubeSys {
   real h, Rc[9], Md[6], damp[6], fs[6];
   real B_tc, B_pc, B_tp, B_tl, B_mc, mu_tc[3], mu_pc[3], mu_tp[3], mu_tl[3], mu_mc[3];
   bool side_on[2];                             // a contact between the cube and the right / left finger body (pad or finger-link mesh)
+  bool tab_on, stat_on;                        // ... between the cube and a static geom; between a static geom and the robot alone
   int ncon; bool any_pad, solved, touch[2];    // touch: this forward pass has a right / left pad-cube contact; any_pad: any pad contact
   real a_c[6];
 
@@ -315,10 +316,11 @@ struct CubeSys {
     scan_sides();
   }
   MCG_DEV void scan_sides() {
-    side_on[0] = side_on[1] = false;
+    side_on[0] = side_on[1] = tab_on = stat_on = false;
     for (int c = 0; __any(c < ncon); c++) {
       const int type = sel((c < ncon), (int)S.ld(LDS_CON + c * CON_STRIDE + 15), 0);
       side_on[0] = side_on[0] || pair_class(type) == 1; side_on[1] = side_on[1] || pair_class(type) == 2;
+      tab_on = tab_on || ((c < ncon) && pair_has_cube(type) && pair_class(type) == 0); stat_on = stat_on || ((c < ncon) && !pair_has_cube(type));
     }
   }
   MCG_DEV void prepare(ModelPtr Pm, const real* qr) {
@@ -994,38 +996,9 @@ struct CubeSys {
       _Pragma("unroll") for (int k = 0; k < 60; k++) S.st(CM + k, 0.0);
     }
     MCG_TICK(ST_A_G);
-    real At[NCLS][21], bt[NCLS][6];              // twist-space accumulators: table-cube, right finger body-cube, left finger body-cube
-    _Pragma("unroll") for (int q = 0; q < NCLS; q++) { _Pragma("unroll") for (int k = 0; k < 21; k++) At[q][k] = 0; _Pragma("unroll") for (int k = 0; k < 6; k++) bt[q][k] = 0; }
     real grs[10];                                // static contacts' part of the robot right-hand side
     _Pragma("unroll") for (int j = 0; j < 10; j++) grs[j] = 0;
 
-    // a twist-space contact's pyramid rows with the active set `mask` into its class accumulators; dv = its basis . velocity
-    auto add_twist = [&](const TwistRows& E, int mask, const real* dv) {
-      real mu_[3], Bc; cube_pair_numbers(KC, E.type, mu_, Bc);
-      real W00 = 0, t0 = 0, W0[3], Wd[3], t[3];
-      static_for<3>([&](auto Kk) { constexpr int k = Kk; const real m = mu_[k];
-        const real arp = -Bc * fma(m, dv[1 + k], dv[0]) - E.kterm, arm = -Bc * fma(-m, dv[1 + k], dv[0]) - E.kterm;
-        const real wp = sel(((mask >> (2 * k)) & 1) != 0, E.D, 0.0), wm = sel(((mask >> (2 * k + 1)) & 1) != 0, E.D, 0.0);
-        W00 += wp + wm; t0 = fma(wp, arp, fma(wm, arm, t0));
-        W0[k] = m * (wp - wm); Wd[k] = m * m * (wp + wm); t[k] = m * (wp * arp - wm * arm); });
-      // U_b = sum_b' W_bb' e_b' (arrow matrix), then dA = sum_b e_b U_b^T (symmetric), db = sum_b e_b t_b
-      real U[4][6], dA[21], db[6];
-      _Pragma("unroll") for (int d = 0; d < 6; d++) {
-        const real e3 = d < 3 ? 0.0 : E.n[d < 3 ? 0 : d - 3];
-        U[0][d] = W00 * E.e[0][d] + W0[0] * E.e[1][d] + W0[1] * E.e[2][d] + W0[2] * e3;
-        U[1][d] = W0[0] * E.e[0][d] + Wd[0] * E.e[1][d];
-        U[2][d] = W0[1] * E.e[0][d] + Wd[1] * E.e[2][d];
-        U[3][d] = W0[2] * E.e[0][d] + Wd[2] * e3;
-        db[d] = E.e[0][d] * t0 + E.e[1][d] * t[0] + E.e[2][d] * t[1] + e3 * t[2];
-      }
-      static_for<6>([&](auto Dd) { constexpr int d = Dd; static_for<d + 1>([&](auto Ee) { constexpr int e = Ee;
-        const real e3 = d < 3 ? 0.0 : E.n[d < 3 ? 0 : d - 3];
-        dA[tri(d, e)] = E.e[0][d] * U[0][e] + E.e[1][d] * U[1][e] + E.e[2][d] * U[2][e] + e3 * U[3][e]; }); });
-      // the lane's class takes the update (weights are zero for lanes without a live twist-space contact here)
-      static_for<NCLS>([&](auto Qq) { constexpr int q = Qq; const real on = (E.cls == q) ? 1.0 : 0.0;
-        _Pragma("unroll") for (int k = 0; k < 21; k++) At[q][k] = fma(on, dA[k], At[q][k]);
-        _Pragma("unroll") for (int k = 0; k < 6; k++) bt[q][k] = fma(on, db[k], bt[q][k]); });
-    };
     // one dof-space (static geom - robot) contact's pyramid rows with the active set `mask` into grs (registers) and G (LDS)
     auto add_contact = [&](const Coupled& K, int mask, const real* dv, bool live) {
       real W00 = 0, t0 = 0, W0[3], Wd[3], t[3];
@@ -1070,39 +1043,18 @@ struct CubeSys {
 
     {
       Twists RV, RP_;
-      {   // (the twist columns are rebuilt for the mapping below rather than kept live across the contact loop; likewise the point)
+      {   // (the twist columns are rebuilt for each class's mapping rather than kept live across the contact loops; likewise the point)
         TwistCols T; twist_cols(T);
         if (mode == PASS_WARM) { real qd[NB]; for (int i = 0; i < NB; i++) qd[i] = Mm->qd[i]; rel_twists(T, Cb.vel, qd, RV); }
         if (mode != PASS_REBUILD) rel_twists(T, pc_, pr_, RP_);
       }
       MCG_TICK(ST_A_TWIST);
-      for (int c = 0; __any(c < KC.ncon); c++) {
-        const int type = sel((c < KC.ncon), (int)S.ld(LDS_CON + c * CON_STRIDE + 15), 0);
-        const bool tw = (c < KC.ncon) && pair_has_cube(type), st = (c < KC.ncon) && !pair_has_cube(type);
-        if (__any(tw)) {
-          TwistRows E; twist_rows(KC, c, E);
-          real dv[4];
-          if (mode == PASS_WARM) {
-            real rv[6]; pick_twist(RV, E.cls, rv); tdots(E, rv, dv);
-            if (tw) { _Pragma("unroll") for (int b = 0; b < 4; b++) S.st(LDS_DV + c * 4 + b, dv[b]); }
-          } else {
-            _Pragma("unroll") for (int b = 0; b < 4; b++) dv[b] = sel(tw, S.ld(LDS_DV + c * 4 + b), 0.0);      // (other lanes: stale slots)
-          }
-          int mask = E.mask;
-          if (mode != PASS_REBUILD) {
-            real rp[6], dp[4];
-            pick_twist(RP_, E.cls, rp); tdots(E, rp, dp);
-            real mu[3], Bc; cube_pair_numbers(KC, E.type, mu, Bc);
-            mask = pattern_of(mu, Bc, E.kterm, false, dp, dv);
-            same = same && (!tw || mask == E.mask);
-#ifdef MCG_DBG_PRINT
-            if (blockIdx.x == 0 && threadIdx.x == 0 && tw) printf("[pass %d] c %d type %d mask %d (was %d) dp %.4e %.4e %.4e %.4e dv %.4e %.4e %.4e %.4e\n", mode, c, E.type, mask, E.mask, dp[0], dp[1], dp[2], dp[3], dv[0], dv[1], dv[2], dv[3]);
-#endif
-            if (tw && !conv) S.st(LDS_ACT + c, (real)mask);
-          }
-          add_twist(E, mask, dv);
-        }
-        if (__any(st)) {
+      // ---- static geom - robot contacts (dof space), where a lane of the wave holds one
+      if (__any(stat_on)) {
+        for (int c = 0; __any(c < KC.ncon); c++) {
+          const int type = sel((c < KC.ncon), (int)S.ld(LDS_CON + c * CON_STRIDE + 15), 0);
+          const bool st = (c < KC.ncon) && !pair_has_cube(type);
+          if (!__any(st)) continue;
           Coupled K; contact_of(c, K);
           K.D = sel(st, K.D, 0.0); K.mask = sel(st, K.mask, 0);
           real v8[8], dv[4], qd[NB];
@@ -1121,57 +1073,99 @@ struct CubeSys {
           add_contact(K, mask, dv, st);
         }
       }
-      MCG_TICK(ST_A_LOOP);
-      // ---- the accumulators into the dof-space system: cube block and right-hand sides (registers -> memory), G and Cm in LDS
+      // ---- the register part of the system starts from its smooth parts; every class of cube contacts then adds its own
       real gr[NB], Hc[21], gc[6];
       for (int i = 0; i < NB; i++) gr[i] = Mm->g0[i];
       _Pragma("unroll") for (int j = 0; j < 10; j++) gr[j] += (((act >> j) & 1) ? Mm->sgl[j] * Mm->Dl[j] * Mm->arefl[j] : 0.0) + grs[j];
       _Pragma("unroll") for (int k = 0; k < 21; k++) Hc[k] = 0;
       _Pragma("unroll") for (int k = 0; k < 6; k++) { Hc[tri(k, k)] = Md[k]; gc[k] = fs[k]; }
-      {
-        real As[21], bs[6];
-        _Pragma("unroll") for (int k = 0; k < 21; k++) As[k] = At[0][k] + At[1][k] + At[2][k];
-        _Pragma("unroll") for (int k = 0; k < 6; k++) bs[k] = bt[0][k] + bt[1][k] + bt[2][k];
-        // T_c^T As T_c, T_c = diag(I, Rc): [vv, vw Rc ; . , Rc^T ww Rc]
-        static_for<3>([&](auto Dd) { constexpr int d = Dd; static_for<d + 1>([&](auto Ee) { constexpr int e = Ee; Hc[tri(d, e)] += As[tri(d, e)]; }); });
-        real X[3][3];
-        static_for<3>([&](auto Dd) { constexpr int d = Dd; static_for<3>([&](auto Ee) { constexpr int e = Ee;       // Hc[3+d][e] = sum_k Rc[k][d] As[3+k][e]
-          Hc[tri(3 + d, e)] += Rc[d] * As[tri(3, e)] + Rc[3 + d] * As[tri(4, e)] + Rc[6 + d] * As[tri(5, e)]; }); });
-        static_for<3>([&](auto Kk) { constexpr int k = Kk; static_for<3>([&](auto Ee) { constexpr int e = Ee;       // X = ww Rc
-          X[k][e] = As[tri(3 + k, 3)] * Rc[e] + As[tri(3 + k, 4)] * Rc[3 + e] + As[tri(3 + k, 5)] * Rc[6 + e]; }); });
-        static_for<3>([&](auto Dd) { constexpr int d = Dd; static_for<d + 1>([&](auto Ee) { constexpr int e = Ee;
-          Hc[tri(3 + d, 3 + e)] += Rc[d] * X[0][e] + Rc[3 + d] * X[1][e] + Rc[6 + d] * X[2][e]; }); });
-        _Pragma("unroll") for (int k = 0; k < 3; k++) { gc[k] += bs[k]; gc[3 + k] += Rc[k] * bs[3] + Rc[3 + k] * bs[4] + Rc[6 + k] * bs[5]; }
-      }
-      if (__any(side_on[0] || side_on[1])) {      // wave-uniform: a finger body - cube contact reaches the robot's dofs
-        TwistCols T; twist_cols(T);
-        real A12[21], b12[6];
-        _Pragma("unroll") for (int k = 0; k < 21; k++) A12[k] = At[1][k] + At[2][k];
-        _Pragma("unroll") for (int k = 0; k < 6; k++) b12[k] = bt[1][k] + bt[2][k];
-        static_for<10>([&](auto Ii) { constexpr int i = Ii;
-          constexpr int cls = i < 6 ? 0 : (i < 8 ? 1 : 2);            // 0: both sides (arm), 1: right chain, 2: left chain
-          const real* A = cls == 0 ? A12 : At[cls];
-          const real* bb = cls == 0 ? b12 : bt[cls];
-          real pv[6];
-          _Pragma("unroll") for (int d = 0; d < 6; d++) { pv[d] = 0; _Pragma("unroll") for (int e = 0; e < 6; e++) pv[d] = fma(A[tri(d, e)], T.c[i][e], pv[d]); }
-          real gl = 0;
-          _Pragma("unroll") for (int d = 0; d < 6; d++) gl = fma(T.c[i][d], bb[d], gl);
-          gr[i] -= gl;
-          // G row i: the dofs k <= i of the same chain (arm dofs belong to both)
-          constexpr int nk = i < 8 ? i + 1 : 6 + (i - 8) + 1;
-          int kg[nk]; real og[nk], oc[6];
-          static_for<nk>([&](auto Kk) { constexpr int kk = Kk; constexpr int k = (i >= 8 && kk >= 6) ? kk + 2 : kk;
-            kg[kk] = GA + tri(i, k); og[kk] = S.ld(kg[kk]); });
-          _Pragma("unroll") for (int d = 0; d < 6; d++) oc[d] = S.ld(CM + i * 6 + d);
-          static_for<nk>([&](auto Kk) { constexpr int kk = Kk; constexpr int k = (i >= 8 && kk >= 6) ? kk + 2 : kk;
-            real v = 0;
-            _Pragma("unroll") for (int d = 0; d < 6; d++) v = fma(T.c[k][d], pv[d], v);
-            S.st(kg[kk], og[kk] + v); });
-          _Pragma("unroll") for (int d = 0; d < 3; d++) {
-            S.st(CM + i * 6 + d, oc[d] - pv[d]);
-            S.st(CM + i * 6 + 3 + d, oc[3 + d] - (Rc[d] * pv[3] + Rc[3 + d] * pv[4] + Rc[6 + d] * pv[5]));
-          } });
-      }
+      // ---- cube contacts, ONE CLASS AT A TIME (table, right finger body, left finger body): one 6x6 accumulator live instead of three.
+      // (Register files set the pace of this solve: a fourth accumulator set slowed the whole solve by 50 %, section 5 of DESIGN.md.)
+      static_for<NCLS>([&](auto Cc) { constexpr int cls = Cc;
+        const bool mine_any = cls == 0 ? tab_on : side_on[cls == 0 ? 0 : cls - 1];
+        if (!__any(mine_any)) return;
+        real A[21], bv[6];
+        _Pragma("unroll") for (int k = 0; k < 21; k++) A[k] = 0;
+        _Pragma("unroll") for (int k = 0; k < 6; k++) bv[k] = 0;
+        for (int c = 0; __any(c < KC.ncon); c++) {
+          const int type = sel((c < KC.ncon), (int)S.ld(LDS_CON + c * CON_STRIDE + 15), 0);
+          const bool mine = (c < KC.ncon) && pair_has_cube(type) && pair_class(type) == cls;
+          if (!__any(mine)) continue;
+          TwistRows E; twist_rows(KC, c, E);
+          E.D = sel(mine, E.D, 0.0); E.mask = sel(mine, E.mask, 0);
+          real dv[4];
+          if (mode == PASS_WARM) {
+            tdots(E, RV.r[cls], dv);
+            if (mine) { _Pragma("unroll") for (int b = 0; b < 4; b++) S.st(LDS_DV + c * 4 + b, dv[b]); }
+          } else {
+            _Pragma("unroll") for (int b = 0; b < 4; b++) dv[b] = sel(mine, S.ld(LDS_DV + c * 4 + b), 0.0);      // (other lanes: stale slots)
+          }
+          real mu_[3], Bc; cube_pair_numbers(KC, E.type, mu_, Bc);
+          int mask = E.mask;
+          if (mode != PASS_REBUILD) {
+            real dp[4]; tdots(E, RP_.r[cls], dp);
+            mask = pattern_of(mu_, Bc, E.kterm, false, dp, dv);
+            same = same && (!mine || mask == E.mask);
+#ifdef MCG_DBG_PRINT
+            if (blockIdx.x == 0 && threadIdx.x == 0 && mine) printf("[pass %d] c %d type %d mask %d (was %d) dp %.4e %.4e %.4e %.4e dv %.4e %.4e %.4e %.4e\n", mode, c, E.type, mask, E.mask, dp[0], dp[1], dp[2], dp[3], dv[0], dv[1], dv[2], dv[3]);
+#endif
+            if (mine && !conv) S.st(LDS_ACT + c, (real)mask);
+          }
+          // the contact's pyramid rows with the active set `mask` into the class accumulator
+          real W00 = 0, t0 = 0, W0[3], Wd[3], t[3];
+          static_for<3>([&](auto Kk) { constexpr int k = Kk; const real m = mu_[k];
+            const real arp = -Bc * fma(m, dv[1 + k], dv[0]) - E.kterm, arm = -Bc * fma(-m, dv[1 + k], dv[0]) - E.kterm;
+            const real wp = sel(((mask >> (2 * k)) & 1) != 0, E.D, 0.0), wm = sel(((mask >> (2 * k + 1)) & 1) != 0, E.D, 0.0);
+            W00 += wp + wm; t0 = fma(wp, arp, fma(wm, arm, t0));
+            W0[k] = m * (wp - wm); Wd[k] = m * m * (wp + wm); t[k] = m * (wp * arp - wm * arm); });
+          real U[4][6];
+          _Pragma("unroll") for (int d = 0; d < 6; d++) {
+            const real e3 = d < 3 ? 0.0 : E.n[d < 3 ? 0 : d - 3];
+            U[0][d] = W00 * E.e[0][d] + W0[0] * E.e[1][d] + W0[1] * E.e[2][d] + W0[2] * e3;
+            U[1][d] = W0[0] * E.e[0][d] + Wd[0] * E.e[1][d];
+            U[2][d] = W0[1] * E.e[0][d] + Wd[1] * E.e[2][d];
+            U[3][d] = W0[2] * E.e[0][d] + Wd[2] * e3;
+            bv[d] += E.e[0][d] * t0 + E.e[1][d] * t[0] + E.e[2][d] * t[1] + e3 * t[2];
+          }
+          static_for<6>([&](auto Dd) { constexpr int d = Dd; static_for<d + 1>([&](auto Ee) { constexpr int e = Ee;
+            const real e3 = d < 3 ? 0.0 : E.n[d < 3 ? 0 : d - 3];
+            A[tri(d, e)] += E.e[0][d] * U[0][e] + E.e[1][d] * U[1][e] + E.e[2][d] * U[2][e] + e3 * U[3][e]; }); });
+        }
+        // the class into the dof-space system.  Cube block: T_c^T A T_c, T_c = diag(I, Rc): [vv, vw Rc ; . , Rc^T ww Rc]
+        {
+          static_for<3>([&](auto Dd) { constexpr int d = Dd; static_for<d + 1>([&](auto Ee) { constexpr int e = Ee; Hc[tri(d, e)] += A[tri(d, e)]; }); });
+          real X[3][3];
+          static_for<3>([&](auto Dd) { constexpr int d = Dd; static_for<3>([&](auto Ee) { constexpr int e = Ee;
+            Hc[tri(3 + d, e)] += Rc[d] * A[tri(3, e)] + Rc[3 + d] * A[tri(4, e)] + Rc[6 + d] * A[tri(5, e)]; }); });
+          static_for<3>([&](auto Kk) { constexpr int k = Kk; static_for<3>([&](auto Ee) { constexpr int e = Ee;
+            X[k][e] = A[tri(3 + k, 3)] * Rc[e] + A[tri(3 + k, 4)] * Rc[3 + e] + A[tri(3 + k, 5)] * Rc[6 + e]; }); });
+          static_for<3>([&](auto Dd) { constexpr int d = Dd; static_for<d + 1>([&](auto Ee) { constexpr int e = Ee;
+            Hc[tri(3 + d, 3 + e)] += Rc[d] * X[0][e] + Rc[3 + d] * X[1][e] + Rc[6 + d] * X[2][e]; }); });
+          _Pragma("unroll") for (int k = 0; k < 3; k++) { gc[k] += bv[k]; gc[3 + k] += Rc[k] * bv[3] + Rc[3 + k] * bv[4] + Rc[6 + k] * bv[5]; }
+        }
+        if constexpr (cls > 0) {                   // the finger body's chain: arm 0..5, gear and finger of the side
+          constexpr int sd = cls - 1;
+          TwistCols T; twist_cols(T);
+          static_for<8>([&](auto Ii) { constexpr int il = Ii; constexpr int i = il < 6 ? il : 6 + 2 * sd + (il - 6);
+            real pv[6];
+            _Pragma("unroll") for (int d = 0; d < 6; d++) { pv[d] = 0; _Pragma("unroll") for (int e = 0; e < 6; e++) pv[d] = fma(A[tri(d, e)], T.c[i][e], pv[d]); }
+            real gl = 0;
+            _Pragma("unroll") for (int d = 0; d < 6; d++) gl = fma(T.c[i][d], bv[d], gl);
+            gr[i] -= gl;
+            int kg[il + 1]; real og[il + 1], oc[6];
+            static_for<il + 1>([&](auto Kk) { constexpr int kl = Kk; constexpr int k = kl < 6 ? kl : 6 + 2 * sd + (kl - 6);
+              kg[kl] = GA + tri(i, k); og[kl] = S.ld(kg[kl]); });
+            _Pragma("unroll") for (int d = 0; d < 6; d++) oc[d] = S.ld(CM + i * 6 + d);
+            static_for<il + 1>([&](auto Kk) { constexpr int kl = Kk; constexpr int k = kl < 6 ? kl : 6 + 2 * sd + (kl - 6);
+              real v = 0;
+              _Pragma("unroll") for (int d = 0; d < 6; d++) v = fma(T.c[k][d], pv[d], v);
+              S.st(kg[kl], og[kl] + v); });
+            _Pragma("unroll") for (int d = 0; d < 3; d++) {
+              S.st(CM + i * 6 + d, oc[d] - pv[d]);
+              S.st(CM + i * 6 + 3 + d, oc[3 + d] - (Rc[d] * pv[3] + Rc[3 + d] * pv[4] + Rc[6 + d] * pv[5]));
+            } });
+        } });
+      MCG_TICK(ST_A_LOOP);
       MCG_TICK(ST_A_MAP);
       for (int i = 0; i < NB; i++) Mm->gr[i] = gr[i];
       _Pragma("unroll") for (int k = 0; k < 21; k++) Mm->Hc[k] = Hc[k];
