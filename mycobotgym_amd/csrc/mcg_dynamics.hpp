@@ -350,7 +350,7 @@ constexpr int LDS_HEQ = NB * (NB + 1) / 2;            // H_eq = M + J^T D J over
 constexpr int LDS_SLOTS = 2 * (NB * (NB + 1) / 2);
 // two-wave variant (SplitA / helper_substep): factor of M + hB, its reciprocal pivots, and q published for the helper wave
 constexpr int LDS_FAC = LDS_SLOTS, LDS_FDINV = LDS_FAC + NB * (NB + 1) / 2, LDS_QB = LDS_FDINV + NB, LDS_QDB = LDS_QB + NB;
-constexpr int LDS_FS = LDS_QDB + NB, LDS_SLOTS_SPLIT = LDS_FS + NB;
+constexpr int LDS_FS = LDS_QDB + NB, LDS_WARM = LDS_FS + NB, LDS_QLAG = LDS_WARM + NB, LDS_SLOTS_SPLIT = LDS_QLAG + 6;      // LDS_WARM: qacc_warmstart parked between sub-steps; LDS_QLAG: q of the last forward pass
 // The lane's LDS column.  The pointer carries the LDS address space explicitly: passed through structs as a generic
 // pointer the accesses degrade to flat_load/flat_store with 64-bit address arithmetic instead of ds_read/ds_write
 // with immediate offsets.
@@ -585,10 +585,14 @@ MCG_DEV void crb_to_lds(ModelPtr Pm, const real* cs, const real* sn, const LS MS
 // A split policy says which pieces other waves provide and where the exchange slots are.
 // early_heq: the J^T D J part of H_eq is assembled (and the constraint part of g0 formed) BEFORE barrier S2, while the main wave
 // would otherwise wait for M; build_H then adds M on the fly.
-struct NoSplit { static constexpr bool enabled = false, rne_remote = false, factor_remote = false, early_heq = false;
-                 static constexpr int QB = 0, QDB = 0, FS = 0; };
-struct SplitMain { static constexpr bool enabled = true, rne_remote = true, factor_remote = true, early_heq = true;
-                   static constexpr int QB = LDS_QB, QDB = LDS_QDB, FS = LDS_FS; };
+// warm_lds: qacc_warmstart lives in LDS slots WARM.. between sub-steps instead of in registers.  The closed-form limit solve does not
+// read it; only the rare general iteration does -- but in registers it stays live through the factorisation, the kernel's register peak.
+// With it the Euler step also re-reads q(t), qd(t) from the slots they were published in for the other waves (QB, QDB) instead of
+// carrying them through the solve, and the lagged configuration (q of this forward pass, for observations and IK) goes to slots QLAG.
+struct NoSplit { static constexpr bool enabled = false, rne_remote = false, factor_remote = false, early_heq = false, warm_lds = false;
+                 static constexpr int QB = 0, QDB = 0, FS = 0, WARM = 0, QLAG = 0; };
+struct SplitMain { static constexpr bool enabled = true, rne_remote = true, factor_remote = true, early_heq = true, warm_lds = true;
+                   static constexpr int QB = LDS_QB, QDB = LDS_QDB, FS = LDS_FS, WARM = LDS_WARM, QLAG = LDS_QLAG; };
 
 // COMMIT = false: the new q / qd / qacc_warmstart go to *next and S stays as it was (speculative sub-step of the two-wave
 // PickAndPlace kernel: discarded when the helper wave's collision pass finds a pad contact).
@@ -603,7 +607,7 @@ MCG_DEV void robot_substep(ModelPtr Pm, Robot& S, real* qlag6, const LS MS, CPL*
     const TrigC T = load_trig();
     static_for<NB>([&](auto I) { constexpr int i = I; sincos_cw(T, AXS[i] * S.q[i], sn[i], cs[i]); });
   }
-  static_for<6>([&](auto I) { constexpr int i = I; qlag6[i] = S.q[i]; });
+  if constexpr (!(SPL::warm_lds && !CPL::enabled)) static_for<6>([&](auto I) { constexpr int i = I; qlag6[i] = S.q[i]; });      // (else: to LDS at the end of the sub-step)
   static_for<NB>([&](auto I) { constexpr int i = I; pin(sn[i]); pin(cs[i]); });
   MCG_FENCE();
 
@@ -844,9 +848,14 @@ MCG_DEV void robot_substep(ModelPtr Pm, Robot& S, real* qlag6, const LS MS, CPL*
   // ---- Newton iterations over the limit rows' active set, exact line search               (mj_fwdConstraint)
   // Wave-uniform loop; a lane that has converged keeps recomputing its own (unchanged) system and commits nothing.
   real a[NB];
-  static_for<NB>([&](auto I) { constexpr int i = I; a[i] = S.warm[i]; });
   bool act[10];
-  static_for<10>([&](auto I) { constexpr int j = I; act[j] = (sgl[j] != 0) && (sgl[j] * a[j] - arefl[j] < 0); });
+  if constexpr (SPL::warm_lds && !CPL::enabled) {     // the warm start is read below, and only if the general iteration runs
+    static_for<NB>([&](auto I) { constexpr int i = I; a[i] = 0; });
+    static_for<10>([&](auto I) { constexpr int j = I; act[j] = false; });
+  } else {
+    static_for<NB>([&](auto I) { constexpr int i = I; a[i] = S.warm[i]; });
+    static_for<10>([&](auto I) { constexpr int j = I; act[j] = (sgl[j] != 0) && (sgl[j] * a[j] - arefl[j] < 0); });
+  }
   bool conv = false;
   if constexpr (CPL::enabled) {
     if (__any(CP->any_pad)) {     // wave-uniform: every lane of the wave takes the coupled path (same minimiser)
@@ -926,6 +935,12 @@ MCG_DEV void robot_substep(ModelPtr Pm, Robot& S, real* qlag6, const LS MS, CPL*
     }
   }
   // General iteration (three or more violated limit rows in some lane of the wave: arm or finger limits, rare)
+  if constexpr (SPL::warm_lds && !CPL::enabled) {
+    if (__any(!conv)) {
+      static_for<NB>([&](auto I) { constexpr int i = I; a[i] = MS.ld(SPL::WARM + i); });
+      static_for<10>([&](auto I) { constexpr int j = I; act[j] = (sgl[j] != 0) && (sgl[j] * a[j] - arefl[j] < 0); });
+    }
+  }
   for (int it = 0; it < 50 && __any(!conv); it++) {
     MCG_COUNT(CN_NEWTON_IT);
     real L[NB * (NB + 1) / 2], dinv[NB], x[NB];
@@ -1024,8 +1039,11 @@ MCG_DEV void robot_substep(ModelPtr Pm, Robot& S, real* qlag6, const LS MS, CPL*
   }
   }
   static_for<NB>([&](auto I) { constexpr int i = I;
-    const real qd_new = fma(h, rhs[i], S.qd[i]), q_new = fma(h, qd_new, S.q[i]);
-    if constexpr (COMMIT) { S.qd[i] = qd_new; S.q[i] = q_new; S.warm[i] = a[i]; }
+    real q_old, qd_old;
+    if constexpr (SPL::warm_lds && !CPL::enabled) { q_old = MS.ld(SPL::QB + i); qd_old = MS.ld(SPL::QDB + i); if constexpr (i < 6) MS.st(SPL::QLAG + i, q_old); }
+    else { q_old = S.q[i]; qd_old = S.qd[i]; }
+    const real qd_new = fma(h, rhs[i], qd_old), q_new = fma(h, qd_new, q_old);
+    if constexpr (COMMIT) { S.qd[i] = qd_new; S.q[i] = q_new; if constexpr (SPL::warm_lds && !CPL::enabled) MS.st(SPL::WARM + i, a[i]); else S.warm[i] = a[i]; }
     else { next->qd[i] = qd_new; next->q[i] = q_new; next->warm[i] = a[i]; }
     if constexpr (SPL::enabled && COMMIT) { MS.st(SPL::QB + i, q_new); MS.st(SPL::QDB + i, qd_new); } });
   MCG_TICK_PIN(S.q, NB); MCG_TICK_PIN(S.qd, NB);

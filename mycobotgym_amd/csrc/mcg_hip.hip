@@ -200,7 +200,7 @@ __global__ __launch_bounds__(SPLIT ? 192 : 64) void step_reach_kernel(Cfg C, Vie
   MCG_TICK_INIT();
   Env E;
   load_robot(V, i, E);
-  if constexpr (SPLIT) static_for<NB>([&](auto I) { constexpr int k = I; MS.st(LDS_QB + k, E.R.q[k]); MS.st(LDS_QDB + k, E.R.qd[k]); });   // q(0), qd(0) for the other waves
+  if constexpr (SPLIT) static_for<NB>([&](auto I) { constexpr int k = I; MS.st(LDS_QB + k, E.R.q[k]); MS.st(LDS_QDB + k, E.R.qd[k]); MS.st(LDS_WARM + k, E.R.warm[k]); if constexpr (k < 6) MS.st(LDS_QLAG + k, E.qlag6[k]); });   // q(0), qd(0) for the other waves; warm start and lagged q parked
   MCG_TICK(ST_LOAD);
   float act[8];
   _Pragma("unroll") for (int k = 0; k < 8; k++) {   // act_dim is 7, 4 (fetch) or 8 (mocap): static indices keep the array in registers
@@ -222,7 +222,7 @@ __global__ __launch_bounds__(SPLIT ? 192 : 64) void step_reach_kernel(Cfg C, Vie
     }
     const real grip = C.grip_center + (real)act_last * C.grip_range;
     for (int c = 0; c < C.control_steps; c++) {
-      if (c > 0) eef_forward(P, E.qlag6, X, true);
+      if (c > 0) { if constexpr (SPLIT) for (int k = 0; k < 6; k++) E.qlag6[k] = MS.ld(LDS_QLAG + k); eef_forward(P, E.qlag6, X, true); }
       real dq[6];
       ik_delta(X, tpos, tquat, dq);
       for (int k = 0; k < 6; k++) E.R.ctrl[k] += dq[k];
@@ -241,6 +241,7 @@ __global__ __launch_bounds__(SPLIT ? 192 : 64) void step_reach_kernel(Cfg C, Vie
     for (int s = 0; s < C.frame_skip; s++) robot_substep<LaneScratch, NoCoupling, NoWeld, Split>(P, E.R, E.qlag6, MS);
   }
 
+  if constexpr (SPLIT) static_for<NB>([&](auto I) { constexpr int k = I; E.R.warm[k] = MS.ld(LDS_WARM + k); if constexpr (k < 6) E.qlag6[k] = MS.ld(LDS_QLAG + k); });     // warm start and lagged q back from LDS
   guard_robot(E.R, E.qlag6);
   // The row addresses of the state arrays must be RECOMPUTED here, not carried: the compiler otherwise keeps the 49 addresses it formed
   // for load_robot alive across the whole sub-step loop for store_env -- spilled, they were the kernel's entire scratch frame (396 B
@@ -479,8 +480,8 @@ constexpr int PNP_SLOTS_DUAL = PNP_SLOTS + NB;
 static_assert(PNP_SLOTS_DUAL * PNP_LANES * 8 <= 160 * 1024, "LDS of a CU");
 // robot-side split of the four-wave PickAndPlace kernel: M from the helper wave, passive - bias from the RNE wave, the constraint
 // part of H_eq assembled before barrier S2; the Euler step stays with M a (no room for the factor in LDS)
-struct SplitPnp { static constexpr bool enabled = true, rne_remote = true, factor_remote = false, early_heq = true;
-                  static constexpr int QB = XCH_Q, QDB = XCH_QD, FS = XCH_FS; };
+struct SplitPnp { static constexpr bool enabled = true, rne_remote = true, factor_remote = false, early_heq = true, warm_lds = false;
+                  static constexpr int QB = XCH_Q, QDB = XCH_QD, FS = XCH_FS, WARM = 0, QLAG = 0; };
 
 MCG_DEV void cube_to_lds(const PnpScratch MS, const Cube& Cb) {
   for (int k = 0; k < 3; k++) MS.st(XCH_CB + k, Cb.pos[k]);
