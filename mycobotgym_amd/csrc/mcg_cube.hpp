@@ -808,7 +808,7 @@ struct CubeSys {
   // in place of Cm_i: S = G - sum_d W_i[d] W_j[d] / D[d].
   static constexpr int GA = LDS_ROW, CM = LDS_ROW + NB * (NB + 1) / 2;
 #ifndef MCG_FULL_STEPS
-#define MCG_FULL_STEPS 3
+#define MCG_FULL_STEPS 4
 #endif
   static constexpr int FULL_STEPS = MCG_FULL_STEPS;
   static_assert(NB * (NB + 1) / 2 + 60 <= MAXCON * 12, "G and Cm must fit in the line-search row area");
