@@ -54,7 +54,7 @@ CASES = {
     "pnp-joint-dr": ("pnp", "joint", True, False),
     "pnp-joint-grasp": ("pnp", "joint", False, True),
 }
-DEFAULT_SECONDARY = ("reach-IK", "pnp-joint", "pnp-joint-grasp", "pnp-joint-dr")
+DEFAULT_SECONDARY = ("reach-IK", "pnp-joint", "pnp-joint-grasp", "pnp-joint-dr", "pnp-IK", "pnp-mocap")
 
 
 def describe(case, n, lockstep):

@@ -1,0 +1,360 @@
+// mcg_coop.hpp -- the coupled robot + cube solve of PickAndPlace, ONE ENVIRONMENT PER WAVE.
+//
+// Replaces, for an environment in which a contact reaches the robot (finger pad / finger link on the cube, pad or arm mesh on the
+// table / the ground), MuJoCo's mj_fwdConstraint over the 18 dofs (P9; call sites /root/reference/mycobotgym/envs/mycobot.py:170,193;
+// contact geoms mycobot280_main.xml:81,87,105-175,195-199,222-225,260-265).
+//
+// Why it exists.  The lane-parallel coupled solve (mcg_cube.hpp: one env per lane) makes all 32 environments of a wave walk the
+// longest contact list for the largest Newton iteration count whenever ONE of them touches something, and every instruction of that
+// walk waits on the previous one's memory round trip (one wave per SIMD): 355 us per coupled sub-step whatever the number of touching
+// environments.  Here the environments are routed one by one: the robot wave commits its speculative contact-free sub-step for the
+// environments that touch nothing, and each touching environment is solved by ONE WAVE WORKING ON IT ALONE -- the four waves of the
+// workgroup (robot, cube, M, RNE; all idle at that point of the sub-step) take the flagged environments in turn.
+//
+// The solve is the same primal Newton iteration as the oracle's (oracle/mco_physics.c: fwd_constraint), written densely over GENERIC
+// rows:    minimise  1/2 a^T H0 a - g0^T a + sum_r 1/2 D_r min(0, J_r a - aref_r)^2,    a = (robot 12, cube 6),
+// H0 = blockdiag(M + J_eq^T D J_eq, cube inertia), rows r = joint limits (10) and the pyramid rows of the contacts (6 or 4 each).
+//   * lanes = ROWS for everything per row: the row's Jacobian (18 numbers in registers, built once per solve from the contact's frame and
+//     the twist columns of the joints in its chain), residual, active bit (ballot), line-search terms;
+//   * lanes = MATRIX ROWS (lane i < 18 holds row i of H) for the assembly H = H0 + sum_active D J J^T (the active rows pass through a
+//     16-row LDS window), the L D L^T factorisation (pivot column broadcast lane by lane with v_readlane: no memory round trip on the
+//     dependent chain) and the two triangular solves (L^T through one LDS transpose);
+//   * a candidate x = H^-1 g that keeps the assumed active set IS the minimiser; otherwise an exact line search on the piecewise
+//     quadratic (Newton on phi', two 32-lane DPP reductions per evaluation) and the next iteration.
+// Any contact between any two of {static geom, cube, arm body b, finger body of a side} is a row here: there are no contact classes
+// and no per-class accumulators (what kept the gripper base - cube pair out of the lane-parallel solve).
+#pragma once
+
+#include "mcg_cube.hpp"
+
+namespace mcg {
+
+// ---- exchange slots of the four-wave kernel (all per-lane columns).
+// Clip-polygon slots (only the collision pass uses them, before barrier S2): flags and the cube's hand-over.
+constexpr int XCH_FLAG = LDS_POLY, XCH_T0 = LDS_POLY + 1, XCH_T1 = LDS_POLY + 2, XCH_NCON = LDS_POLY + 3;
+constexpr int XCH_CB = LDS_POLY + 4, XCH_QL7 = LDS_POLY + 23, XCH_DR = LDS_POLY + 30;      // cube: pos 3, quat 4, vel 6, warm 6; lagged pose 7; DR scales 2
+static_assert(XCH_DR + 2 <= LDS_POLY + 64, "exchange area exceeds the clip-polygon slots");
+// Line-search row area (LDS_ROW .. LDS_ROW + 144 slot rows of PNP_LANES doubles):
+//   [0, 24)    q(t), qd(t) for the other waves: written at the end of a sub-step, read right after S1, dead after S2 (the cube wave's
+//              own solve then uses the area; prepare() does NOT touch it -- it runs between S1 and S2, while the M and RNE waves read)
+//   [24, 80)   columns of the FLAGGED lanes only: inputs of their coupled solve, parked by the robot wave after S2.  (The cube wave's
+//              solve skips flagged lanes and leaves their columns alone.)
+//   [80, 144)  cooperative workspace, 512 doubles per wave, used between barriers S4 and S5 only (every lane-parallel solve is over)
+constexpr int XCH_Q = LDS_ROW, XCH_QD = LDS_ROW + NB;
+constexpr int PUB_G0 = LDS_ROW + 24, PUB_SD = PUB_G0 + NB, PUB_AREF = PUB_SD + 10, PUB_WARM = PUB_AREF + 10, PUB_QD = PUB_WARM + NB;
+constexpr int COOP_WS_ROW = LDS_ROW + 80, COOP_WS_DOUBLES = 512;
+static_assert(PUB_QD + NB == COOP_WS_ROW, "publish area");
+static_assert(COOP_WS_ROW * PNP_LANES + 4 * COOP_WS_DOUBLES <= (LDS_ROW + MAXCON * 12) * PNP_LANES, "cooperative workspace exceeds the row area");
+constexpr int COOP_NV = 18, COOP_WIN = 16, COOP_WSTRIDE = 20;          // window: 16 active rows x (J[18], D, D*aref)
+static_assert(COOP_WIN * COOP_WSTRIDE <= COOP_WS_DOUBLES && COOP_NV * COOP_NV <= COOP_WS_DOUBLES, "window / transpose buffer");
+constexpr int COOP_ROWS = 10 + 6 * MAXCON, COOP_SETS = (COOP_ROWS + PNP_LANES - 1) / PNP_LANES;      // limits first, then the contacts
+#ifndef MCG_COOP_FULL_STEPS
+#define MCG_COOP_FULL_STEPS 1
+#endif
+
+// ---- cross-lane helpers (32 active lanes = two DPP rows of 16)
+MCG_DEV real coop_rdlane(real v, int l) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+  return __hiloint2double(hi, lo);
+}
+template <int CTRL> MCG_DEV real coop_dpp(real v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+MCG_DEV real coop_sum32(real v) {      // sum over the 32 active lanes, the same (uniform) number in every lane
+  v += coop_dpp<0xB1>(v);              // quad_perm [1,0,3,2]
+  v += coop_dpp<0x4E>(v);              // quad_perm [2,3,0,1]
+  v += coop_dpp<0x141>(v);             // row_half_mirror
+  v += coop_dpp<0x140>(v);             // row_mirror: every lane of a 16-lane row holds the row's sum
+  return coop_rdlane(v, 0) + coop_rdlane(v, 16);
+}
+MCG_DEV void coop_lds_sync() {         // LDS traffic between lanes of one wave: order the compiler (the hardware keeps a wave's LDS ops in order)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+constexpr unsigned coop_row_mask(const Pattern& P, int i) { unsigned m = 0; for (int j = 0; j <= i; j++) m |= P.nz[i][j] ? (1u << j) : 0u; return m; }
+
+// One environment's coupled solve, by the 32 active lanes of the calling wave.  lds0 = slot 0 of lane 0 of the workgroup's array,
+// e = the environment's lane (its LDS column), ws = this wave's workspace.
+MCG_DEV void coop_solve(ModelPtr Pm, LdsPtr lds0, int e, LdsPtr ws) {
+  const int L = threadIdx.x & (PNP_LANES - 1);
+  const PnpScratch ME(lds0 + e);                   // env e's column: a uniform slot index is a broadcast read
+  MCG_COUNT(CN_COUPLED);
+  // ---- the environment's cube and pair numbers (uniform), as the lane-parallel solve derives them
+  Cube Cb; real drs[2];
+  for (int k = 0; k < 3; k++) Cb.pos[k] = ME.ld(XCH_CB + k);
+  for (int k = 0; k < 4; k++) Cb.quat[k] = ME.ld(XCH_CB + 3 + k);
+  for (int k = 0; k < 6; k++) { Cb.vel[k] = ME.ld(XCH_CB + 7 + k); Cb.warm[k] = ME.ld(XCH_CB + 13 + k); }
+  drs[0] = ME.ld(XCH_DR); drs[1] = ME.ld(XCH_DR + 1);
+  const int ncon = __builtin_amdgcn_readfirstlane((int)ME.ld(XCH_NCON));
+  CubeSys<PnpScratch> CS(ME, Cb, drs);
+  CS.pm_bits = (unsigned long long)Pm;
+  CS.derive(Pm);
+  // ---- which finger sides carry a contact (their gear / finger joint frames are posed), twist columns of the ten joints about the cube centre
+  bool side_any[2] = {false, false};
+  for (int c = 0; c < ncon; c++) {
+    const int type = (int)ME.ld(LDS_CON + c * CON_STRIDE + 15);
+    side_any[0] = side_any[0] || type == PAIR_PADR_CUBE || type == PAIR_TABLE_PADR || type == PAIR_FINR_CUBE;
+    side_any[1] = side_any[1] || type == PAIR_PADL_CUBE || type == PAIR_TABLE_PADL || type == PAIR_FINL_CUBE;
+  }
+  real tc[10][6];
+  _Pragma("unroll") for (int j = 0; j < 10; j++) {
+    real ax[3], d[3], v[3];
+    _Pragma("unroll") for (int k = 0; k < 3; k++) { ax[k] = ME.ld(LDS_WJ + j * 6 + k); d[k] = ME.ld(LDS_WJ + j * 6 + 3 + k) - Cb.pos[k]; }
+    cross(d, ax, v);
+    const bool ok = (j < 6) || side_any[(j - 6) >> 1];         // (a side without contacts: stale LDS)
+    _Pragma("unroll") for (int k = 0; k < 3; k++) { tc[j][k] = sel(ok, v[k], 0.0); tc[j][3 + k] = sel(ok, ax[k], 0.0); }
+  }
+  real qd[NB], vc[6];
+  _Pragma("unroll") for (int j = 0; j < NB; j++) qd[j] = ME.ld(PUB_QD + j);
+  _Pragma("unroll") for (int k = 0; k < 6; k++) vc[k] = Cb.vel[k];
+
+  // ---- rows.  Row r = 32 s + L of set s: r < 10 the limit of joint r; else pyramid row (r - 10) % 6 of contact (r - 10) / 6.
+  const int nrows = 10 + 6 * ncon;
+  const int nsets = (nrows + PNP_LANES - 1) / PNP_LANES;        // uniform; 1 .. COOP_SETS
+  real J[COOP_SETS][COOP_NV], Dr[COOP_SETS], aref[COOP_SETS];
+  _Pragma("unroll") for (int s = 0; s < COOP_SETS; s++) {
+    _Pragma("unroll") for (int j = 0; j < COOP_NV; j++) J[s][j] = 0;
+    Dr[s] = 0; aref[s] = 0;
+    if (s < nsets) {
+      const int r = PNP_LANES * s + L;
+      const bool is_lim = r < 10;
+      // limit row: J = sg e_j, D, aref from the robot wave
+      const int jl = sel(is_lim, r, 0);
+      const real sD = ME.ld(PUB_SD + jl), al = ME.ld(PUB_AREF + jl);
+      const real sgn = sel(sD > 0, 1.0, sel(sD < 0, -1.0, 0.0));
+      // contact row
+      const int rc = sel(is_lim, 0, r - 10);
+      const int c = sel(rc / 6 < MAXCON, rc / 6, MAXCON - 1), p = rc % 6;
+      const bool is_con = !is_lim && (rc / 6 < ncon);
+      const int b = LDS_CON + c * CON_STRIDE;
+      real lev[3], n[3], t1[3], t2[3];
+      _Pragma("unroll") for (int k = 0; k < 3; k++) { lev[k] = ME.ld(b + k) - Cb.pos[k]; n[k] = ME.ld(b + 3 + k); t1[k] = ME.ld(b + 6 + k); t2[k] = ME.ld(b + 9 + k); }
+      const real Dc = ME.ld(b + 13), kterm = ME.ld(b + 14);
+      const int type = sel(is_con, (int)ME.ld(b + 15), 0);
+      const bool padc = type == PAIR_PADR_CUBE || type == PAIR_PADL_CUBE, finc = type >= PAIR_FINR_CUBE;
+      const bool link = type >= PAIR_TABLE_LINK0 && !finc, tabp = (type == PAIR_TABLE_PADR || type == PAIR_TABLE_PADL);
+      const bool has_cube = pair_has_cube(type);
+      const int side = sel((type == PAIR_PADL_CUBE || type == PAIR_TABLE_PADL || type == PAIR_FINL_CUBE), 1, 0);
+      const bool finger = padc || finc || tabp;                                    // the robot body is the finger body of `side`
+      const int lbody = sel(link, sel(type - PAIR_TABLE_LINK0 < 5, type - PAIR_TABLE_LINK0, 5), sel(finger, 5, -1));      // last arm joint in the chain
+      const real rsign = sel(has_cube, -1.0, 1.0);                                 // robot geom is geom1 against the cube, geom2 against a static geom
+      real mu[3]; real Bc;
+      _Pragma("unroll") for (int k = 0; k < 3; k++)
+        mu[k] = sel(link, CS.mu_tl[k], sel(tabp, CS.mu_tp[k], sel(finc, CS.mu_mc[k], sel(padc, CS.mu_pc[k], CS.mu_tc[k]))));
+      Bc = sel(link, CS.B_tl, sel(tabp, CS.B_tp, sel(finc, CS.B_mc, sel(padc, CS.B_pc, CS.B_tc))));
+      const int kf = p >> 1;
+      const real m = sel((p & 1), -1.0, 1.0) * sel3(kf, mu[0], mu[1], mu[2]);
+      const bool absent = link && kf == 2;                                         // condim 3: no torsional pair of rows
+      real dlin[3], eang[3];
+      _Pragma("unroll") for (int k = 0; k < 3; k++) dlin[k] = n[k] + sel(kf == 0, m * t1[k], sel(kf == 1, m * t2[k], 0.0));
+      cross(lev, dlin, eang);
+      const real tau = sel(kf == 2, m, 0.0);
+      _Pragma("unroll") for (int k = 0; k < 3; k++) eang[k] = fma(tau, n[k], eang[k]);
+      const bool live = is_con && !absent;
+      // robot columns: joints of the chain
+      _Pragma("unroll") for (int j = 0; j < 10; j++) {
+        const bool member = live && ((j < 6) ? (j <= lbody) : (finger && ((j - 6) >> 1) == side));
+        const real dj = dlin[0] * tc[j][0] + dlin[1] * tc[j][1] + dlin[2] * tc[j][2] + eang[0] * tc[j][3] + eang[1] * tc[j][4] + eang[2] * tc[j][5];
+        J[s][j] = sel(member, rsign * dj, 0.0);
+      }
+      // cube columns: [dlin ; Rc^T eang]
+      _Pragma("unroll") for (int k = 0; k < 3; k++) {
+        J[s][12 + k] = sel(live && has_cube, dlin[k], 0.0);
+        J[s][15 + k] = sel(live && has_cube, CS.Rc[k] * eang[0] + CS.Rc[3 + k] * eang[1] + CS.Rc[6 + k] * eang[2], 0.0);
+      }
+      real vel = 0;
+      _Pragma("unroll") for (int j = 0; j < 10; j++) vel = fma(J[s][j], qd[j], vel);
+      _Pragma("unroll") for (int k = 0; k < 6; k++) vel = fma(J[s][12 + k], vc[k], vel);
+      Dr[s] = sel(live, Dc, 0.0); aref[s] = sel(live, -Bc * vel - kterm, 0.0);
+      // limit row over the top
+      _Pragma("unroll") for (int j = 0; j < 10; j++) J[s][j] = sel(is_lim, sel(j == jl, sgn, 0.0), J[s][j]);
+      Dr[s] = sel(is_lim, fabs(sD), Dr[s]); aref[s] = sel(is_lim, al, aref[s]);
+    }
+  }
+
+  // ---- H0 and g0, lane i < 18 holds row i (lanes 18.. shadow row 17 and are never read)
+  const int i = sel(L < COOP_NV, L, COOP_NV - 1);
+  real H0[COOP_NV], g0;
+  {
+    unsigned mE = 0, mM = 0;                     // pattern of the lane's own row (columns <= i)
+    static_for<NB>([&](auto I) { constexpr int k = I; mE = sel(i == k, coop_row_mask(PAT_E, k), mE); mM = sel(i == k, coop_row_mask(PAT_M, k), mM); });
+    const bool rob = i < NB;
+    const int ir = sel(rob, i, 0);
+    static_for<NB>([&](auto Jj) { constexpr int j = Jj;
+      // entry (i, j): below the diagonal in row i (lane-varying pattern bit), above it in row j (static row, lane-varying column)
+      const bool low = ir >= j;
+      const int slot = sel(low, ir * (ir + 1) / 2 + j, j * (j + 1) / 2 + ir);
+      const bool nzE = sel(low, ((mE >> j) & 1u) != 0u, ((coop_row_mask(PAT_E, j) >> ir) & 1u) != 0u);
+      const bool nzM = sel(low, ((mM >> j) & 1u) != 0u, ((coop_row_mask(PAT_M, j) >> ir) & 1u) != 0u);
+      const real he = ME.ld(LDS_HEQ + slot), hm = ME.ld(LDS_M + slot);
+      H0[j] = sel(rob, sel(nzE, he, 0.0) + sel(nzM, hm, 0.0), 0.0); });
+    static_for<6>([&](auto Kk) { constexpr int k = Kk; H0[NB + k] = sel(i == NB + k, CS.Md[k], 0.0); });
+    const real gr = ME.ld(PUB_G0 + ir);
+    real gcv = 0;
+    static_for<6>([&](auto Kk) { constexpr int k = Kk; gcv = sel(i == NB + k, CS.fs[k], gcv); });
+    g0 = sel(rob, gr, gcv);
+  }
+
+  // ---- the iterate: uniform copy a[] (every lane) and al (lane i holds a_i)
+  real a[COOP_NV];
+  _Pragma("unroll") for (int j = 0; j < NB; j++) a[j] = ME.ld(PUB_WARM + j);
+  _Pragma("unroll") for (int k = 0; k < 6; k++) a[NB + k] = Cb.warm[k];
+  real al = 0;
+  static_for<COOP_NV>([&](auto I) { constexpr int k = I; al = sel(i == k, a[k], al); });
+
+  for (int it = 0; it < 50; it++) {
+    MCG_COUNT(CN_COUPLED_IT);
+    // (a) residuals and the active set at a
+    real r0[COOP_SETS]; unsigned act[COOP_SETS];
+    _Pragma("unroll") for (int s = 0; s < COOP_SETS; s++) {
+      r0[s] = 0; act[s] = 0;
+      if (s < nsets) {
+        real acc = -aref[s];
+        _Pragma("unroll") for (int j = 0; j < COOP_NV; j++) acc = fma(J[s][j], a[j], acc);
+        r0[s] = acc;
+        act[s] = (unsigned)__ballot(Dr[s] > 0 && acc < 0);
+      }
+    }
+    // (b) H = H0 + sum_active D J J^T, g = g0 + sum_active D aref J: the active rows pass through a 16-row window in LDS
+    real H[COOP_NV], g = g0;
+    _Pragma("unroll") for (int j = 0; j < COOP_NV; j++) H[j] = H0[j];
+    _Pragma("unroll") for (int s = 0; s < COOP_SETS; s++) {
+      if (s < nsets && act[s] != 0u) {
+        const int nact = __popc(act[s]);
+        const int pos = __popc(act[s] & ((1u << L) - 1u));
+        const bool mine = ((act[s] >> L) & 1u) != 0u;
+        for (int w0 = 0; w0 < nact; w0 += COOP_WIN) {
+          coop_lds_sync();                                        // the window's previous readers are done
+          if (mine && pos >= w0 && pos < w0 + COOP_WIN) {
+            const int o = (pos - w0) * COOP_WSTRIDE;
+            _Pragma("unroll") for (int j = 0; j < COOP_NV; j++) ws[o + j] = J[s][j];
+            ws[o + 18] = Dr[s]; ws[o + 19] = Dr[s] * aref[s];
+          }
+          coop_lds_sync();
+          const int nw = sel(nact - w0 < COOP_WIN, nact - w0, COOP_WIN);
+          for (int t = 0; t < nw; t++) {
+            const int o = t * COOP_WSTRIDE;
+            const real ji = ws[o + i];
+            const real cD = ws[o + 18] * ji;
+            g = fma(ws[o + 19], ji, g);
+            _Pragma("unroll") for (int j = 0; j < COOP_NV; j++) H[j] = fma(cD, ws[o + j], H[j]);
+          }
+        }
+      }
+    }
+    // (c) gradient at a (lane i: (H a - g)_i), before the factorisation overwrites H
+    real grad = -g;
+    _Pragma("unroll") for (int j = 0; j < COOP_NV; j++) grad = fma(H[j], a[j], grad);
+    // (d) H = L D L^T in place: lane i ends with L[i][k] in H[k] (k < i); the pivot column travels by v_readlane
+    real dinv_l = 1.0;                              // lane i: 1 / D_i
+    static_for<COOP_NV>([&](auto Kk) { constexpr int k = Kk;
+      const real dk = coop_rdlane(H[k], k);
+      const real inv = rcp_nr(dk);
+      dinv_l = sel(i == k, inv, dinv_l);
+      const real lk = H[k] * inv;
+      static_for<COOP_NV - 1 - k>([&](auto Jj) { constexpr int j = k + 1 + Jj;
+        const real sj = coop_rdlane(H[k], j);                      // H[j][k] before scaling = L[j][k] D_k
+        H[j] = fma(-lk, sj, H[j]); });
+      H[k] = lk; });
+    // (e) x = H^-1 g.  Forward substitution in row layout; L^T through one LDS transpose for the backward pass.
+    real acc = g, y_l = 0;
+    static_for<COOP_NV>([&](auto Kk) { constexpr int k = Kk;
+      const real yk = coop_rdlane(acc, k);
+      y_l = sel(i == k, acc, y_l);
+      acc = fma(-sel(i > k, H[k], 0.0), yk, acc); });
+    coop_lds_sync();
+    if (L < COOP_NV) { _Pragma("unroll") for (int k = 0; k < COOP_NV; k++) ws[L * COOP_NV + k] = H[k]; }
+    coop_lds_sync();
+    real U[COOP_NV];                                 // U[j] = L[j][i]: column i of L
+    _Pragma("unroll") for (int j = 0; j < COOP_NV; j++) U[j] = ws[j * COOP_NV + i];
+    real bacc = y_l * dinv_l;
+    real x[COOP_NV];
+    static_for<COOP_NV>([&](auto Kk) { constexpr int j = COOP_NV - 1 - Kk;
+      x[j] = coop_rdlane(bacc, j);
+      bacc = fma(-sel(i < j, U[j], 0.0), x[j], bacc); });
+    real xl = 0;
+    static_for<COOP_NV>([&](auto I) { constexpr int k = I; xl = sel(i == k, x[k], xl); });
+    // (f) does the candidate keep the assumed active set?
+    real p[COOP_NV];
+    _Pragma("unroll") for (int j = 0; j < COOP_NV; j++) p[j] = x[j] - a[j];
+    real dr_[COOP_SETS];
+    bool same = true;
+    _Pragma("unroll") for (int s = 0; s < COOP_SETS; s++) {
+      dr_[s] = 0;
+      if (s < nsets) {
+        real dd = 0;
+        _Pragma("unroll") for (int j = 0; j < COOP_NV; j++) dd = fma(J[s][j], p[j], dd);
+        dr_[s] = dd;
+        const unsigned nw = (unsigned)__ballot(Dr[s] > 0 && (r0[s] + dd) < 0);
+        same = same && (nw == act[s]);
+      }
+    }
+    if (same || it < MCG_COOP_FULL_STEPS) {           // uniform.  A consistent candidate is the minimiser; the first iterations step to x anyway
+      _Pragma("unroll") for (int j = 0; j < COOP_NV; j++) a[j] = x[j];
+      al = xl;
+      if (same) break;
+      continue;
+    }
+    // (g) exact line search from a along p: phi'(alpha) = s0 + alpha quad_s + sum_rows D min(0, r0 + alpha dr) dr, piecewise linear, increasing
+    MCG_COUNT(CN_COUPLED_LS);
+    const real pl = xl - al;
+    const real q = -coop_sum32(sel(L < COOP_NV, grad * pl, 0.0));          // p^T H p
+    real t1s = 0, t2s = 0;
+    _Pragma("unroll") for (int s = 0; s < COOP_SETS; s++) {
+      const bool on = s < nsets && ((act[s] >> L) & 1u) != 0u;
+      t1s += sel(on, Dr[s] * r0[s] * dr_[s], 0.0); t2s += sel(on, Dr[s] * dr_[s] * dr_[s], 0.0);
+    }
+    const real s0 = -q - coop_sum32(t1s), quad = q - coop_sum32(t2s);
+    auto dphi = [&](real alp, real& slope) {
+      real f = 0, sl = 0;
+      _Pragma("unroll") for (int s = 0; s < COOP_SETS; s++) {
+        const real rr = r0[s] + alp * dr_[s];
+        const bool on = s < nsets && Dr[s] > 0 && rr < 0;
+        f += sel(on, Dr[s] * rr * dr_[s], 0.0); sl += sel(on, Dr[s] * dr_[s] * dr_[s], 0.0);
+      }
+      slope = quad + coop_sum32(sl);
+      return s0 + alp * quad + coop_sum32(f);
+    };
+    real lo = 0, hi = 2, sl;
+    const bool beyond = dphi(hi, sl) < 0;
+    real alp = 1.0;
+    for (int b = 0; b < 16; b++) {
+      const real f = dphi(alp, sl);
+      const bool neg = f < 0;
+      lo = sel(neg, alp, lo); hi = sel(neg, hi, alp);
+      const real nwt = alp - f / sl;
+      const real nx = sel(nwt > lo && nwt < hi, nwt, 0.5 * (lo + hi));
+      const bool moved = fabs(nx - alp) > 1e-15 * fmax(1.0, fabs(alp));      // on the root's own linear piece Newton stays put
+      alp = nx;
+      if (!moved || beyond) break;                                            // uniform
+    }
+    const real alpha = sel(beyond, 2.0, alp);
+    _Pragma("unroll") for (int j = 0; j < COOP_NV; j++) a[j] = fma(alpha, p[j], a[j]);
+    al = fma(alpha, pl, al);
+  }
+  // ---- hand the accelerations back: robot part where the warm start was, cube part in the cube's warm-start slots
+  if (L < NB) ME.st(PUB_WARM + L, al);
+  else if (L < COOP_NV) ME.st(XCH_CB + 13 + (L - NB), al);
+}
+
+// All four waves call this between barriers S4 and S5 with the same `mask` (bit l: lane l's environment is flagged): wave w solves
+// the flagged environments number w, w + 4, ...  Out of line: one copy of the code, its own register allocation.
+__device__ __noinline__ void coop_phase(unsigned long long model_bits, unsigned lds_base, unsigned mask, int wave) {
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)model_bits), hi = __builtin_amdgcn_readfirstlane((unsigned)(model_bits >> 32));
+  const ModelPtr P = (ModelPtr)(((unsigned long long)hi << 32) | lo);
+  const LdsPtr lds0 = (LdsPtr)(uintptr_t)__builtin_amdgcn_readfirstlane(lds_base);
+  unsigned m = __builtin_amdgcn_readfirstlane(mask);
+  const int w = __builtin_amdgcn_readfirstlane(wave);
+  const LdsPtr ws = lds0 + COOP_WS_ROW * PNP_LANES + w * COOP_WS_DOUBLES;
+  for (int k = 0; m != 0u; k++) {
+    const int e = __builtin_ctz(m);
+    m &= m - 1u;
+    if ((k & 3) == w) coop_solve(P, lds0, e, ws);
+  }
+}
+
+}  // namespace mcg

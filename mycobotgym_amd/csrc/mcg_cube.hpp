@@ -263,7 +263,7 @@ struct PadRows { real Jn[8], J1[8], J2[8], Jt[8]; };
 // The cube and its contacts for one sub-step: prepared before the robot's Newton solve, finished after it.
 template <class LS>
 struct CubeSys {
-  static constexpr bool enabled = true;
+  static constexpr bool enabled = true, publishes = false;
   const LS S; Cube Cb; real dr[2];             // by value: a reference into the env struct pins that struct in memory
                                                // (the model pointer is passed in: it must stay a scalar register)
   unsigned long long pm_bits;                  // the model pointer's bits, for stages reached through the robot's hook
@@ -586,12 +586,12 @@ struct CubeSys {
     { int mx = 0; for (int c = 0; __any(c < ncon); c++) mx = c + 1; if ((threadIdx.x & 63) == 0) atomicAdd(&g_stage_clocks[ST_COUNT + CN_CONTACTS], (unsigned long long)mx); }   // wave-max contacts
 #endif
     // Lanes with fewer contacts than their wave-mates still walk the longer list with zero weights: give them clean
-    // zeros to multiply (uninitialised LDS may hold NaN / inf, and 0 * NaN would poison the sums).
+    // zeros to multiply (uninitialised LDS may hold NaN / inf, and 0 * NaN would poison the sums).  Only the contact entries here:
+    // the line-search rows and the masks are cleared by the solves that use them (clean_rows) -- in the four-wave kernel the start
+    // of the row area holds q(t), qd(t) for the other waves, which still read them while this pass runs.
     for (int c = 0; __any(c < ncon); c++) {
       if (c >= ncon) {
         for (int k = 0; k < CON_STRIDE; k++) S.st(LDS_CON + c * CON_STRIDE + k, 0.0);
-        _Pragma("unroll") for (int k = 0; k < 12; k++) S.st(LDS_ROW + c * 12 + k, 0.0);
-        S.st(LDS_ACT + c, 0.0);
       }
     }
     // ---- P5 per-contact solver numbers (the 6 pyramid rows of a contact share D and the position term)
@@ -664,7 +664,26 @@ struct CubeSys {
   // Two passes over the contact list per Newton iteration: (A) active mask (from the warm start on the first
   // iteration) + assembly of H and g; (B) consistency of the mask at the solution x, the constraint forces at x and the
   // line-search data.  When the mask is consistent -- the usual case -- x is the minimiser and B's forces are final.
-  MCG_DEV void solve_alone() {
+  // zeros in the line-search rows and masks of the list positions this lane does not fill (see prepare()).  `skip`: the lane's column
+  // of the row area is not this solve's to touch (four-wave kernel: the robot wave parks the coupled solve's inputs there).
+  MCG_DEV void clean_rows(bool skip = false) const {
+    for (int c = 0; __any(c < ncon); c++) {
+      if (c >= ncon && !skip) {
+        _Pragma("unroll") for (int k = 0; k < 12; k++) S.st(LDS_ROW + c * 12 + k, 0.0);
+        S.st(LDS_ACT + c, 0.0);
+      }
+    }
+  }
+  // `skip`: this lane's env goes through the cooperative coupled solve instead; it walks the loops with an empty list and
+  // stores nothing (its result is discarded).
+  MCG_DEV void solve_alone(bool skip = false) {
+    const int ncon_all = ncon;
+    ncon = sel(skip, 0, ncon_all);
+    clean_rows(skip);
+    solve_alone_impl();
+    ncon = ncon_all;
+  }
+  MCG_DEV void solve_alone_impl() {
     derive(model());
     const real Bc = B_tc; const real mu[3] = {mu_tc[0], mu_tc[1], mu_tc[2]};
     real a[6];
@@ -1361,6 +1380,7 @@ struct CubeSys {
     CubeSys CS(MS, io->Cb, io->dr);
     CS.pm_bits = io->pm_bits;
     CS.adopt(CS.model(), io->ncon, io->touch[0], io->touch[1], io->any_pad);
+    CS.clean_rows();
     CoupledMem Mm;
     for (int i = 0; i < NB; i++) { Mm.g0[i] = io->g0[i]; Mm.qd[i] = io->qd[i]; Mm.ar[i] = io->a[i]; }
     _Pragma("unroll") for (int j = 0; j < 10; j++) { Mm.Dl[j] = io->Dl[j]; Mm.arefl[j] = io->arefl[j]; Mm.sgl[j] = io->sgl[j]; }

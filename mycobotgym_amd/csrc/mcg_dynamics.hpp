@@ -378,7 +378,9 @@ typedef LaneScratchT<64> LaneScratch;
 // One physics sub-step (mj_step) of the 12-dof robot.  `qlag` receives the positions the forward pass used.
 // Coupling hook: PickAndPlace passes an object that, when a finger pad touches the cube, solves the robot and cube
 // accelerations together (the Euler step needs no constraint force: M a carries it).  Reach passes NoCoupling (compiled out).
-struct NoCoupling { static constexpr bool enabled = false; };
+struct NoCoupling { static constexpr bool enabled = false, publishes = false; };
+// A hook with `publishes` (and not `enabled`) is handed the Newton system's smooth right-hand side and the limit rows once they are
+// complete: the four-wave PickAndPlace kernel parks them in LDS for the cooperative coupled solve (mcg_coop.hpp).
 
 // Mocap weld (mocap controller, mycobot.py:172-189; mocap.xml:15-20): six equality rows pull gripper_tcp to the mocap
 // body's pose.  NoWeld compiles the rows out (joint / IK controllers).
@@ -572,6 +574,22 @@ MCG_DEV void crb_to_lds(ModelPtr Pm, const real* cs, const real* sn, const LS MS
       asm volatile("" ::: "memory");      // the M entries of this body are in LDS before the next block starts
       MCG_FENCE();
     });
+}
+
+// P10, velocity part: at the minimiser the gradient vanishes, M a = qfrc_smooth + J^T f over ALL rows (equality, limit, weld,
+// contact), so the right-hand side of (M + hB) a' = qfrc_smooth + qfrc_constraint is M a: no Jacobian is live after the solve.
+// rhs <- (M + hB)^-1 M a from the LDS-resident M.
+template <class LS>
+MCG_DEV void euler_accel(ModelPtr Pm, real h, const LS MS, const real* a, real* rhs) {
+  real Mh[NB * (NB + 1) / 2], dinv[NB];
+  static_for<NB>([&](auto I) { constexpr int i = I;
+    static_for<i + 1>([&](auto Jj) { constexpr int j = Jj; if constexpr (PAT_M.nz[i][j]) Mh[tri(i, j)] = MS.ld(LDS_M + tri(i, j)); }); });
+  static_for<NB>([&](auto I) { constexpr int i = I; real sacc = 0;
+    static_for<NB>([&](auto Jj) { constexpr int j = Jj;
+      if constexpr (PAT_M.nz[i > j ? i : j][i > j ? j : i]) sacc = fma(Mh[tri(i, j)], a[j], sacc); }); rhs[i] = sacc; });
+  { ModelPtr Q = launder(Pm); static_for<NB>([&](auto I) { constexpr int i = I; Mh[tri(i, i)] = fma(h, Q->body[i].damping, Mh[tri(i, i)]); }); }
+  ldl_factor<PAT_M>(Mh, dinv);
+  ldl_solve<PAT_M>(Mh, dinv, rhs);
 }
 
 // Three-wave variant (Reach, grids of at most one workgroup per CU, where 3 of the 4 SIMDs of a CU would idle): the workgroup
@@ -832,6 +850,7 @@ MCG_DEV void robot_substep(ModelPtr Pm, Robot& S, real* qlag6, const LS MS, CPL*
     if constexpr (SPL::rne_remote) static_for<NB>([&](auto I) { constexpr int i = I; fs[i] += MS.ld(SPL::FS + i); });
   }
   static_for<NB>([&](auto I) { constexpr int i = I; g0[i] += fs[i]; });
+  if constexpr (CPL::publishes) CP->publish(g0, Dl, arefl, sgl, S.qd, S.warm);
   if constexpr (!SPL::early_heq) assemble_heq(std::true_type{});
   auto build_H = [&](real* H, const bool* act_) {
     static_for<NB>([&](auto I) { constexpr int i = I;
@@ -1023,20 +1042,8 @@ MCG_DEV void robot_substep(ModelPtr Pm, Robot& S, real* qlag6, const LS MS, CPL*
     ldl_solve<PAT_M>(Lf, dinv, rhs);
     static_for<NB>([&](auto I) { constexpr int i = I; rhs[i] = fma(-h, rhs[i], a[i]); });
   } else {
-  // At the minimiser the gradient vanishes: M a = qfrc_smooth + J^T f over ALL rows (equality, limit, weld, contact), so the
-  // right-hand side of (M + hB) a' = qfrc_smooth + qfrc_constraint is M a: no Jacobian is live after the Newton solve.
   MCG_TICK(ST_E_RHS);
-  {
-    real Mh[NB * (NB + 1) / 2], dinv[NB];
-    static_for<NB>([&](auto I) { constexpr int i = I;
-      static_for<i + 1>([&](auto Jj) { constexpr int j = Jj; if constexpr (PAT_M.nz[i][j]) Mh[tri(i, j)] = MS.ld(LDS_M + tri(i, j)); }); });
-    static_for<NB>([&](auto I) { constexpr int i = I; real sacc = 0;
-      static_for<NB>([&](auto Jj) { constexpr int j = Jj;
-        if constexpr (PAT_M.nz[i > j ? i : j][i > j ? j : i]) sacc = fma(Mh[tri(i, j)], a[j], sacc); }); rhs[i] = sacc; });
-    { ModelPtr Q = launder(Pm); static_for<NB>([&](auto I) { constexpr int i = I; Mh[tri(i, i)] = fma(h, Q->body[i].damping, Mh[tri(i, i)]); }); }
-    ldl_factor<PAT_M>(Mh, dinv);
-    ldl_solve<PAT_M>(Mh, dinv, rhs);
-  }
+  euler_accel(Pm, h, MS, a, rhs);
   }
   static_for<NB>([&](auto I) { constexpr int i = I;
     real q_old, qd_old;

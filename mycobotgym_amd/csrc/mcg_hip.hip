@@ -16,6 +16,7 @@
 #include "mcg.h"
 #include "mcg_dynamics.hpp"
 #include "mcg_cube.hpp"
+#include "mcg_coop.hpp"
 #include "model_gen.h"
 
 using namespace mcg;
@@ -455,26 +456,22 @@ MCG_DEV void pnp_substep(ModelPtr P, EnvP& E, const PnpScratch MS, const WLD& W)
   robot_substep<PnpScratch, NoCoupling, WLD>(P, E.R, E.qlag6, MS, nullptr, &W);
 }
 
-// ------------------------------------------------------------------------------- two-wave PickAndPlace (DUAL)
-// Without a pad contact the cube's sub-step (collision, 6x6 Newton, integration) and the robot's are independent.  When the
-// grid has at most one workgroup per CU the workgroup gets a second wave over the same 32 environments: the CUBE wave owns
-// the cube for the whole env-step while the ROBOT wave runs the robot pipeline speculatively (results held back).  Two
-// workgroup barriers per sub-step:
+// ------------------------------------------------------------------------------- four-wave PickAndPlace (DUAL)
+// Without a contact that reaches the robot the cube's sub-step (collision, 6x6 Newton, integration) and the robot's are independent.
+// The workgroup has four waves over the same 32 environments: ROBOT (the robot pipeline, speculatively: results held back), CUBE
+// (owns the cube for the whole env-step), M (composite rigid bodies) and RNE (bias forces), as in the Reach kernel.  Barriers per
+// sub-step:
 //   S1  q(t), qd(t) of the robot are published         (the cube wave needs the pads' pose for the collision pass)
-//   S2  M, passive - bias (helper and RNE waves, as in the Reach kernel) and the collision results are published
-//   S4  both sides are done                            (all waves take the same wave-uniform decision from the flags)
-// no pad contact in the wave: the robot wave commits, the cube wave has already advanced the cube.  Otherwise the cube wave
-// has left the cube untouched and published it; the robot wave discards its result, runs the coupled sub-step
-// (pnp_substep_coupled, as the one-wave kernel does) and hands the cube back (barrier S3).
-// Exchange area: the clip-polygon slots, which only the collision pass uses.
-constexpr int XCH_FLAG = LDS_POLY, XCH_T0 = LDS_POLY + 1, XCH_T1 = LDS_POLY + 2, XCH_NCON = LDS_POLY + 3;
-constexpr int XCH_CB = LDS_POLY + 4, XCH_QL7 = LDS_POLY + 23;
-static_assert(XCH_QL7 + 7 <= LDS_POLY + 64, "exchange area exceeds the clip-polygon slots");
-// q(t), qd(t) for the other waves sit at the start of the line-search row area: they are written at the end of a sub-step (every
-// solve that uses that area is over by then), read right after S1, and dead before the cube wave's solve touches the area after
-// S2.  (The clip-polygon slots will not do: the collision pass overwrites them while the helper and RNE waves still read; the
-// H_eq area would, but then the robot wave could not assemble the constraint part of H_eq BEFORE S2, while it waits for M.)
-constexpr int XCH_Q = LDS_ROW, XCH_QD = LDS_ROW + NB;
+//   S2  M, passive - bias, the collision results and each lane's FLAG (a contact reaches the robot) are published
+//   S4  both sides are done; every wave reads the same flags
+//   S5  only when some lane is flagged: the cooperative coupled solves are done
+// Routing is PER ENVIRONMENT.  An unflagged lane commits: the robot wave its speculative sub-step, the cube wave its cube-alone solve.
+// A flagged lane's cube is left as it was and handed over in LDS, the robot wave parks the inputs of the coupled solve next to it
+// (PubHook, right after S2), and between S4 and S5 the four waves -- all idle at that point -- solve the flagged environments ONE
+// ENVIRONMENT PER WAVE (mcg_coop.hpp).  The robot wave then redoes the Euler step of its flagged lanes with the coupled acceleration,
+// the cube wave advances their cubes with theirs.  (Round 2 ran the whole wave through a lane-parallel coupled sub-step whenever one
+// lane was flagged: 17 contact-free sub-steps' worth of time for one touching environment.)
+// Exchange slots: mcg_coop.hpp.
 constexpr int XCH_FS = PNP_SLOTS;                 // 12 more slots: 640 x 32 lanes x 8 B = the CU's 160 KB exactly
 constexpr int PNP_SLOTS_DUAL = PNP_SLOTS + NB;
 static_assert(PNP_SLOTS_DUAL * PNP_LANES * 8 <= 160 * 1024, "LDS of a CU");
@@ -482,6 +479,21 @@ static_assert(PNP_SLOTS_DUAL * PNP_LANES * 8 <= 160 * 1024, "LDS of a CU");
 // part of H_eq assembled before barrier S2; the Euler step stays with M a (no room for the factor in LDS)
 struct SplitPnp { static constexpr bool enabled = true, rne_remote = true, factor_remote = false, early_heq = true, warm_lds = false;
                   static constexpr int QB = XCH_Q, QDB = XCH_QD, FS = XCH_FS, WARM = 0, QLAG = 0; };
+
+// the robot wave's hook into robot_substep: park a flagged lane's Newton inputs in its own column of the row area
+struct PubHook {
+  static constexpr bool enabled = false, publishes = true;
+  const PnpScratch S;
+  MCG_DEV void publish(const real* g0, const real* Dl, const real* arefl, const real* sgl, const real* qd, const real* warm) const {
+    const bool flag = S.ld(XCH_FLAG) != 0.0;                         // the cube wave wrote it before S2
+    if (__any(flag)) {                                               // wave-uniform
+      if (flag) {                                                    // plain LDS stores of live registers
+        static_for<NB>([&](auto I) { constexpr int k = I; S.st(PUB_G0 + k, g0[k]); S.st(PUB_WARM + k, warm[k]); S.st(PUB_QD + k, qd[k]); });
+        static_for<10>([&](auto I) { constexpr int j = I; S.st(PUB_SD + j, sgl[j] * Dl[j]); S.st(PUB_AREF + j, arefl[j]); });
+      }
+    }
+  }
+};
 
 MCG_DEV void cube_to_lds(const PnpScratch MS, const Cube& Cb) {
   for (int k = 0; k < 3; k++) MS.st(XCH_CB + k, Cb.pos[k]);
@@ -493,9 +505,10 @@ MCG_DEV void cube_from_lds(const PnpScratch MS, Cube& Cb) {
   for (int k = 0; k < 4; k++) Cb.quat[k] = MS.ld(XCH_CB + 3 + k);
   for (int k = 0; k < 6; k++) { Cb.vel[k] = MS.ld(XCH_CB + 7 + k); Cb.warm[k] = MS.ld(XCH_CB + 13 + k); }
 }
+MCG_DEV unsigned flagged_lanes(const PnpScratch MS) { return (unsigned)__ballot(MS.ld(XCH_FLAG) != 0.0); }      // the same in all four waves
 
 // the cube wave's whole env-step
-MCG_DEV void cube_wave(const View& V, ModelPtr P, const PnpScratch MS, int i, int total) {
+MCG_DEV void cube_wave(const View& V, ModelPtr P, const PnpScratch MS, unsigned lds0, int i, int total) {
   Cube Cb; real dr[2], qlag7[7];
   for (int k = 0; k < 3; k++) Cb.pos[k] = V.qpos(12 + k, i);
   for (int k = 0; k < 4; k++) Cb.quat[k] = V.qpos(15 + k, i);
@@ -513,25 +526,27 @@ MCG_DEV void cube_wave(const View& V, ModelPtr P, const PnpScratch MS, int i, in
     CS.prepare(P, q10);
     touch = CS.touch[0] && CS.touch[1];
     MCG_TICK2(ST_W2_COLLIDE);
-    const bool coupled = __any(CS.any_pad);                         // wave-uniform; the robot wave reads the same flags
-    MS.st(XCH_FLAG, CS.any_pad ? 1.0 : 0.0);
-    if (coupled) {                                                  // hand the (normalised, not advanced) cube over
-      cube_to_lds(MS, CS.Cb);
-      MS.st(XCH_T0, CS.touch[0] ? 1.0 : 0.0); MS.st(XCH_T1, CS.touch[1] ? 1.0 : 0.0); MS.st(XCH_NCON, (real)CS.ncon);
+    const bool flag = CS.any_pad;                                   // a contact of this lane's environment reaches the robot
+    const bool coupled = __any(flag);                               // wave-uniform
+    MS.st(XCH_FLAG, flag ? 1.0 : 0.0);
+    if (coupled) {
+      if (flag) {                                                   // hand the (normalised, not advanced) cube over
+        cube_to_lds(MS, CS.Cb);
+        MS.st(XCH_NCON, (real)CS.ncon); MS.st(XCH_DR, dr[0]); MS.st(XCH_DR + 1, dr[1]);
+      }
     }
     __syncthreads();                                                // S2 (the robot side's "M and bias ready")
-    if (!coupled) {
-      CS.solve_alone();
-      CS.finish(qlag7);
-      Cb = CS.Cb;
-    }
+    CS.solve_alone(flag);                                           // flagged lanes walk an empty list, store nothing
+    if (!coupled) { CS.finish(qlag7); Cb = CS.Cb; }
     MCG_TICK2(ST_W2_CUBE);
-    __syncthreads();                                                // S4: end of the sub-step
+    __syncthreads();                                                // S4: end of the lane-parallel part
     MCG_TICK2(ST_W2_WAIT2);
     if (coupled) {
-      __syncthreads();                                              // S5: the robot wave has run the coupled sub-step
-      cube_from_lds(MS, Cb);
-      for (int k = 0; k < 7; k++) qlag7[k] = MS.ld(XCH_QL7 + k);
+      coop_phase((unsigned long long)P, lds0, flagged_lanes(MS), 1);
+      MCG_TICK2(ST_COUPLED);
+      __syncthreads();                                              // S5
+      _Pragma("unroll") for (int k = 0; k < 6; k++) CS.a_c[k] = sel(flag, MS.ld(XCH_CB + 13 + k), CS.a_c[k]);
+      CS.finish(qlag7); Cb = CS.Cb;
     }
   }
   cube_to_lds(MS, Cb);
@@ -542,36 +557,43 @@ MCG_DEV void cube_wave(const View& V, ModelPtr P, const PnpScratch MS, int i, in
 
 // the robot wave's sub-step
 template <class WLD>
-MCG_DEV void pnp_substep_robot(ModelPtr P, EnvP& E, const PnpScratch MS, const WLD& W) {
+MCG_DEV void pnp_substep_robot(ModelPtr P, EnvP& E, const PnpScratch MS, unsigned lds0, const WLD& W) {
   Robot nx;
-  robot_substep<PnpScratch, NoCoupling, WLD, SplitPnp, false>(P, E.R, E.qlag6, MS, nullptr, &W, &nx);     // S1, S2 inside
+  PubHook hook{MS};
+  robot_substep<PnpScratch, PubHook, WLD, SplitPnp, false>(P, E.R, E.qlag6, MS, &hook, &W, &nx);     // S1, S2 inside
   MCG_TICK(ST_POST);
   __syncthreads();                                                  // S4
   MCG_TICK(ST_W1_WAIT);
-  const bool coupled = __any(MS.ld(XCH_FLAG) != 0.0);
-  if (coupled) {
-    CoupledIO<WLD> io; io.E = E; io.W = W;
-    cube_from_lds(MS, io.E.Cb);
-    io.ncon = (int)MS.ld(XCH_NCON); io.touch[0] = MS.ld(XCH_T0) != 0.0; io.touch[1] = MS.ld(XCH_T1) != 0.0; io.any_pad = MS.ld(XCH_FLAG) != 0.0;
-    pnp_substep_coupled<WLD>((unsigned long long)P, &io, (unsigned)(uintptr_t)MS.base);
-    E.R = io.E.R;
-    for (int k = 0; k < 6; k++) E.qlag6[k] = io.E.qlag6[k];
-    cube_to_lds(MS, io.E.Cb);
-    for (int k = 0; k < 7; k++) MS.st(XCH_QL7 + k, io.E.qlag7[k]);
-    static_for<NB>([&](auto I) { constexpr int k = I; MS.st(XCH_Q + k, E.R.q[k]); MS.st(XCH_QD + k, E.R.qd[k]); });
+  const bool flag = MS.ld(XCH_FLAG) != 0.0;
+  const unsigned mask = (unsigned)__ballot(flag);
+  if (mask != 0u) {                                                 // wave-uniform, the same in all four waves
+    coop_phase((unsigned long long)P, lds0, mask, 0);
+    MCG_TICK(ST_COUPLED);
     __syncthreads();                                                // S5
-  } else {
-    static_for<NB>([&](auto I) { constexpr int k = I; E.R.q[k] = nx.q[k]; E.R.qd[k] = nx.qd[k]; E.R.warm[k] = nx.warm[k];
-                                 MS.st(XCH_Q + k, nx.q[k]); MS.st(XCH_QD + k, nx.qd[k]); });
+    // Euler step of the flagged lanes with the coupled acceleration (M a carries the contact forces); the others keep theirs
+    real a[NB], rhs[NB];
+    static_for<NB>([&](auto I) { constexpr int k = I; a[k] = sel(flag, MS.ld(PUB_WARM + k), nx.warm[k]); });
+    const real h = launder(P)->timestep;
+    euler_accel(P, h, MS, a, rhs);
+    static_for<NB>([&](auto I) { constexpr int k = I;
+      const real qd_new = fma(h, rhs[k], E.R.qd[k]), q_new = fma(h, qd_new, E.R.q[k]);
+      nx.qd[k] = sel(flag, qd_new, nx.qd[k]); nx.q[k] = sel(flag, q_new, nx.q[k]); nx.warm[k] = a[k]; });
+    MCG_TICK(ST_EULER);
   }
+  static_for<NB>([&](auto I) { constexpr int k = I; E.R.q[k] = nx.q[k]; E.R.qd[k] = nx.qd[k]; E.R.warm[k] = nx.warm[k];
+                               MS.st(XCH_Q + k, nx.q[k]); MS.st(XCH_QD + k, nx.qd[k]); });
 }
 
 // the helper / RNE waves of the four-wave PickAndPlace kernel: same barriers as the cube wave
-MCG_DEV void pnp_side_wave(ModelPtr P, const PnpScratch MS, int total, bool rne) {
+MCG_DEV void pnp_side_wave(ModelPtr P, const PnpScratch MS, unsigned lds0, int total, bool rne) {
   for (int s = 0; s < total; s++) {
     if (rne) rne_substep<SplitPnp>(P, MS); else helper_substep<SplitPnp>(P, MS);      // S1, S2 inside
     __syncthreads();                                                // S4
-    if (__any(MS.ld(XCH_FLAG) != 0.0)) __syncthreads();             // S5 (coupled sub-step)
+    const unsigned mask = flagged_lanes(MS);
+    if (mask != 0u) {
+      coop_phase((unsigned long long)P, lds0, mask, rne ? 3 : 2);
+      __syncthreads();                                              // S5
+    }
   }
   __syncthreads();                                                  // end of the env-step
 }
@@ -584,13 +606,17 @@ __global__ __launch_bounds__(DUAL ? 256 : PNP_LANES) void step_pnp_kernel(Cfg C,
   if (DUAL && lane >= PNP_LANES) return;         // DUAL: four waves of 32 active lanes: robot, cube, helper (M), RNE
   const PnpScratch MS(&lds[0][lane]);
   const ModelPtr P = as_model_ptr(Pg);
-  const int i = blockIdx.x * PNP_LANES + lane;
-  if (i >= C.n) return;                          // the same lanes leave in both waves: barriers stay matched
+  const int i_raw = blockIdx.x * PNP_LANES + lane;
+  if (!DUAL && i_raw >= C.n) return;
+  // DUAL: every wave keeps its 32 lanes (the cooperative coupled solve works with all of them); in a ragged last workgroup the surplus
+  // lanes shadow the last environment: same inputs, same instruction stream, the same values stored to the same places
+  const int i = (DUAL && i_raw >= C.n) ? C.n - 1 : i_raw;
+  const unsigned lds0 = (unsigned)(uintptr_t)(LdsPtr)&lds[0][0];
   if constexpr (DUAL) {
     if (threadIdx.x >= 64) {
       const int total = (CONTROLLER == MCG_CTRL_IK ? C.control_steps : 1) * C.frame_skip;
-      if (threadIdx.x < 128) cube_wave(V, P, MS, i, total);
-      else pnp_side_wave(P, MS, total, threadIdx.x >= 192);
+      if (threadIdx.x < 128) cube_wave(V, P, MS, lds0, i, total);
+      else pnp_side_wave(P, MS, lds0, total, threadIdx.x >= 192);
       return;
     }
   }
@@ -600,7 +626,7 @@ __global__ __launch_bounds__(DUAL ? 256 : PNP_LANES) void step_pnp_kernel(Cfg C,
   if constexpr (DUAL) static_for<NB>([&](auto I) { constexpr int k = I; MS.st(XCH_Q + k, E.R.q[k]); MS.st(XCH_QD + k, E.R.qd[k]); });   // q(0), qd(0) for the other waves
   MCG_TICK(ST_LOAD);
   E.touch = false;
-  auto substep = [&](const auto& W) { if constexpr (DUAL) pnp_substep_robot(P, E, MS, W); else pnp_substep(P, E, MS, W); };
+  auto substep = [&](const auto& W) { if constexpr (DUAL) pnp_substep_robot(P, E, MS, lds0, W); else pnp_substep(P, E, MS, W); };
   float act[8];
   _Pragma("unroll") for (int k = 0; k < 8; k++) {   // act_dim is 7, 4 (fetch) or 8 (mocap): static indices keep the array in registers
     const float x = (k < C.act_dim) ? actions[(size_t)i * C.act_dim + (k < C.act_dim ? k : 0)] : 0.f;

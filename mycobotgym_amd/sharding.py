@@ -28,7 +28,7 @@ def reduce_episode_stats(ep_return: torch.Tensor, ep_length: torch.Tensor, is_su
                          (is_success.double() * d).sum()])
     if device is not None:
         stats = stats.to(device)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dist.is_available() and dist.is_initialized():        # also at world size 1: the call the multi-GPU job makes is the call that is tested
         dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=group)
     n, r, l, s = stats.tolist()
     return {"episodes": n, "mean_return": r / n if n else float("nan"), "mean_length": l / n if n else float("nan"),

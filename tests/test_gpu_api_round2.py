@@ -296,7 +296,9 @@ def test_bad_state_guard(torch_cuda, has_object):
 # ------------------------------------------------------------------------------------------------- RCCL, one rank
 def test_rccl_single_rank_reduction(torch_cuda, tmp_path):
     """The logging collective through RCCL itself (backend "nccl"), world size 1 on this box's one GPU: the call the 8-GPU run makes
-    (sharding.reduce_episode_stats on device tensors), executed by the real library rather than gloo."""
+    (sharding.reduce_episode_stats on device tensors).  reduce_episode_stats issues dist.all_reduce whenever a process group exists
+    (no world-size guard); that the library really ran a collective is read from RCCL's own log (NCCL_DEBUG_SUBSYS=COLL prints one
+    "AllReduce" line per call)."""
     code = r'''
 import os, sys, json
 sys.path.insert(0, %r)
@@ -316,8 +318,12 @@ assert dist.get_backend() == "nccl"
 json.dump(st, open(%r, "w"))
 dist.destroy_process_group()
 ''' % (ROOT, str(tmp_path / "rccl.json"))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", NCCL_DEBUG="INFO", NCCL_DEBUG_SUBSYS="INIT,COLL")
     p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-2000:]
+    log = p.stdout + p.stderr
+    coll = [ln for ln in log.splitlines() if "AllReduce" in ln]
+    print("\nRCCL log lines naming the collective:", len(coll), coll[:2])
+    assert coll, "RCCL logged no AllReduce: the collective did not run\n" + log[-1500:]
     st = json.load(open(tmp_path / "rccl.json"))
     assert st["episodes"] == 256 and st["mean_length"] == 50.0 and st["mean_return"] < 0
