@@ -1,6 +1,7 @@
 """In-tree build of the HIP library (gfx950 only)."""
 from __future__ import annotations
 
+import glob
 import os
 import shutil
 import subprocess
@@ -8,9 +9,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(_HERE)
 SRC = os.path.join(_HERE, "csrc", "mcg_hip.hip")
-DEPS = [SRC, os.path.join(_HERE, "csrc", "mcg_dynamics.hpp"), os.path.join(_HERE, "csrc", "mcg_cube.hpp"),
-        os.path.join(_HERE, "csrc", "model_gen.h"),
-        os.path.join(ROOT, "include", "mcg.h")]
+DEPS = sorted(glob.glob(os.path.join(_HERE, "csrc", "*"))) + [os.path.join(ROOT, "include", "mcg.h")]      # every source and header
 OUT = os.path.join(_HERE, "libmycobot_hip.so")
 
 

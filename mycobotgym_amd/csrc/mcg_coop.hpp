@@ -46,7 +46,7 @@ constexpr int COOP_WS_ROW = LDS_ROW + 80, COOP_WS_DOUBLES = 512;
 static_assert(PUB_QD + NB == COOP_WS_ROW, "publish area");
 static_assert(COOP_WS_ROW * PNP_LANES + 4 * COOP_WS_DOUBLES <= (LDS_ROW + MAXCON * 12) * PNP_LANES, "cooperative workspace exceeds the row area");
 constexpr int COOP_NV = 18, COOP_WIN = 16, COOP_WSTRIDE = 20;          // window: 16 active rows x (J[18], D, D*aref)
-static_assert(COOP_WIN * COOP_WSTRIDE <= COOP_WS_DOUBLES && COOP_NV * COOP_NV <= COOP_WS_DOUBLES, "window / transpose buffer");
+static_assert(COOP_WIN * COOP_WSTRIDE <= COOP_WS_DOUBLES && COOP_NV * COOP_NV + COOP_NV <= COOP_WS_DOUBLES, "window / matrix buffer");
 constexpr int COOP_ROWS = 10 + 6 * MAXCON, COOP_SETS = (COOP_ROWS + PNP_LANES - 1) / PNP_LANES;      // limits first, then the contacts
 #ifndef MCG_COOP_FULL_STEPS
 #define MCG_COOP_FULL_STEPS 1
@@ -75,21 +75,36 @@ MCG_DEV void coop_lds_sync() {         // LDS traffic between lanes of one wave:
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Stage clocks of the cooperative solve (-DMCG_STAGE_CLOCKS): accumulated in registers, added to the global table once per coop_phase
+// (one atomic per tick from a thousand waves would itself be the largest stage).
+#ifdef MCG_STAGE_CLOCKS
+struct CoopClocks { unsigned long long last, t[ST_CO_IDLE - ST_CO_SETUP]; unsigned n[5]; };      // n: solves, iterations, line searches, active rows, evaluations
+#define COOP_COUNT(k, v) do { CK.n[k] += (unsigned)(v); } while (0)
+#define COOP_TICK(k) do { const unsigned long long t_ = __builtin_readcyclecounter(); CK.t[(k) - ST_CO_SETUP] += t_ - CK.last; CK.last = t_; } while (0)
+#else
+struct CoopClocks {};
+#define COOP_TICK(k) do {} while (0)
+#define COOP_COUNT(k, v) do {} while (0)
+#endif
+
 constexpr unsigned coop_row_mask(const Pattern& P, int i) { unsigned m = 0; for (int j = 0; j <= i; j++) m |= P.nz[i][j] ? (1u << j) : 0u; return m; }
 
 // One environment's coupled solve, by the 32 active lanes of the calling wave.  lds0 = slot 0 of lane 0 of the workgroup's array,
 // e = the environment's lane (its LDS column), ws = this wave's workspace.
-MCG_DEV void coop_solve(ModelPtr Pm, LdsPtr lds0, int e, LdsPtr ws) {
+template <int NSETS>
+MCG_DEV void coop_solve(ModelPtr Pm, LdsPtr lds0, int e, LdsPtr ws, int ncon, CoopClocks& CK) {
   const int L = threadIdx.x & (PNP_LANES - 1);
   const PnpScratch ME(lds0 + e);                   // env e's column: a uniform slot index is a broadcast read
-  MCG_COUNT(CN_COUPLED);
+  COOP_COUNT(0, 1);
+#ifdef MCG_STAGE_CLOCKS
+  CK.last = __builtin_readcyclecounter();
+#endif
   // ---- the environment's cube and pair numbers (uniform), as the lane-parallel solve derives them
   Cube Cb; real drs[2];
   for (int k = 0; k < 3; k++) Cb.pos[k] = ME.ld(XCH_CB + k);
   for (int k = 0; k < 4; k++) Cb.quat[k] = ME.ld(XCH_CB + 3 + k);
   for (int k = 0; k < 6; k++) { Cb.vel[k] = ME.ld(XCH_CB + 7 + k); Cb.warm[k] = ME.ld(XCH_CB + 13 + k); }
   drs[0] = ME.ld(XCH_DR); drs[1] = ME.ld(XCH_DR + 1);
-  const int ncon = __builtin_amdgcn_readfirstlane((int)ME.ld(XCH_NCON));
   CubeSys<PnpScratch> CS(ME, Cb, drs);
   CS.pm_bits = (unsigned long long)Pm;
   CS.derive(Pm);
@@ -112,11 +127,12 @@ MCG_DEV void coop_solve(ModelPtr Pm, LdsPtr lds0, int e, LdsPtr ws) {
   _Pragma("unroll") for (int j = 0; j < NB; j++) qd[j] = ME.ld(PUB_QD + j);
   _Pragma("unroll") for (int k = 0; k < 6; k++) vc[k] = Cb.vel[k];
 
+  COOP_TICK(ST_CO_SETUP);
   // ---- rows.  Row r = 32 s + L of set s: r < 10 the limit of joint r; else pyramid row (r - 10) % 6 of contact (r - 10) / 6.
   const int nrows = 10 + 6 * ncon;
-  const int nsets = (nrows + PNP_LANES - 1) / PNP_LANES;        // uniform; 1 .. COOP_SETS
-  real J[COOP_SETS][COOP_NV], Dr[COOP_SETS], aref[COOP_SETS];
-  _Pragma("unroll") for (int s = 0; s < COOP_SETS; s++) {
+  const int nsets = (nrows + PNP_LANES - 1) / PNP_LANES;        // uniform; 1 .. NSETS
+  real J[NSETS][COOP_NV], Dr[NSETS], aref[NSETS];
+  _Pragma("unroll") for (int s = 0; s < NSETS; s++) {
     _Pragma("unroll") for (int j = 0; j < COOP_NV; j++) J[s][j] = 0;
     Dr[s] = 0; aref[s] = 0;
     if (s < nsets) {
@@ -133,8 +149,9 @@ MCG_DEV void coop_solve(ModelPtr Pm, LdsPtr lds0, int e, LdsPtr ws) {
       const int b = LDS_CON + c * CON_STRIDE;
       real lev[3], n[3], t1[3], t2[3];
       _Pragma("unroll") for (int k = 0; k < 3; k++) { lev[k] = ME.ld(b + k) - Cb.pos[k]; n[k] = ME.ld(b + 3 + k); t1[k] = ME.ld(b + 6 + k); t2[k] = ME.ld(b + 9 + k); }
-      const real Dc = ME.ld(b + 13), kterm = ME.ld(b + 14);
-      const int type = sel(is_con, (int)ME.ld(b + 15), 0);
+      const real Dc = ME.ld(b + 13), kterm = ME.ld(b + 14), ftype = ME.ld(b + 15);
+      MCG_FENCE();                                                                 // the row's loads are issued together
+      const int type = sel(is_con, (int)ftype, 0);
       const bool padc = type == PAIR_PADR_CUBE || type == PAIR_PADL_CUBE, finc = type >= PAIR_FINR_CUBE;
       const bool link = type >= PAIR_TABLE_LINK0 && !finc, tabp = (type == PAIR_TABLE_PADR || type == PAIR_TABLE_PADL);
       const bool has_cube = pair_has_cube(type);
@@ -176,6 +193,8 @@ MCG_DEV void coop_solve(ModelPtr Pm, LdsPtr lds0, int e, LdsPtr ws) {
     }
   }
 
+  MCG_TICK_PIN(Dr, NSETS); MCG_TICK_PIN(aref, NSETS);
+  COOP_TICK(ST_CO_ROWS);
   // ---- H0 and g0, lane i < 18 holds row i (lanes 18.. shadow row 17 and are never read)
   const int i = sel(L < COOP_NV, L, COOP_NV - 1);
   real H0[COOP_NV], g0;
@@ -184,14 +203,17 @@ MCG_DEV void coop_solve(ModelPtr Pm, LdsPtr lds0, int e, LdsPtr ws) {
     static_for<NB>([&](auto I) { constexpr int k = I; mE = sel(i == k, coop_row_mask(PAT_E, k), mE); mM = sel(i == k, coop_row_mask(PAT_M, k), mM); });
     const bool rob = i < NB;
     const int ir = sel(rob, i, 0);
+    real he[NB], hm[NB];                         // all loads first (the column's slots share one LDS bank: every one of them is slow)
     static_for<NB>([&](auto Jj) { constexpr int j = Jj;
       // entry (i, j): below the diagonal in row i (lane-varying pattern bit), above it in row j (static row, lane-varying column)
+      const int slot = sel(ir >= j, ir * (ir + 1) / 2 + j, j * (j + 1) / 2 + ir);
+      he[j] = ME.ld(LDS_HEQ + slot); hm[j] = ME.ld(LDS_M + slot); });
+    MCG_FENCE();
+    static_for<NB>([&](auto Jj) { constexpr int j = Jj;
       const bool low = ir >= j;
-      const int slot = sel(low, ir * (ir + 1) / 2 + j, j * (j + 1) / 2 + ir);
       const bool nzE = sel(low, ((mE >> j) & 1u) != 0u, ((coop_row_mask(PAT_E, j) >> ir) & 1u) != 0u);
       const bool nzM = sel(low, ((mM >> j) & 1u) != 0u, ((coop_row_mask(PAT_M, j) >> ir) & 1u) != 0u);
-      const real he = ME.ld(LDS_HEQ + slot), hm = ME.ld(LDS_M + slot);
-      H0[j] = sel(rob, sel(nzE, he, 0.0) + sel(nzM, hm, 0.0), 0.0); });
+      H0[j] = sel(rob, sel(nzE, he[j], 0.0) + sel(nzM, hm[j], 0.0), 0.0); });
     static_for<6>([&](auto Kk) { constexpr int k = Kk; H0[NB + k] = sel(i == NB + k, CS.Md[k], 0.0); });
     const real gr = ME.ld(PUB_G0 + ir);
     real gcv = 0;
@@ -199,146 +221,180 @@ MCG_DEV void coop_solve(ModelPtr Pm, LdsPtr lds0, int e, LdsPtr ws) {
     g0 = sel(rob, gr, gcv);
   }
 
-  // ---- the iterate: uniform copy a[] (every lane) and al (lane i holds a_i)
-  real a[COOP_NV];
-  _Pragma("unroll") for (int j = 0; j < NB; j++) a[j] = ME.ld(PUB_WARM + j);
-  _Pragma("unroll") for (int k = 0; k < 6; k++) a[NB + k] = Cb.warm[k];
-  real al = 0;
-  static_for<COOP_NV>([&](auto I) { constexpr int k = I; al = sel(i == k, a[k], al); });
+  MCG_TICK_PIN(H0, COOP_NV);
+  COOP_TICK(ST_CO_H0);
+  // ---- the iterate lives one number per lane (lane i holds a_i); a uniform copy of a vector is made where one is needed, by v_readlane
+  real al = ME.ld(sel(i < NB, PUB_WARM + i, XCH_CB + 13 + (i - NB)));
+  // Assembly layout: all 32 lanes work on the 16 x 18 upper block of the increment, lane (ia, hb) on row ia, columns 9 hb .. 9 hb + 8;
+  // rows 16 and 17 come from the symmetry (columns 16, 17 of the hb = 1 lanes) and their 2 x 2 corner from the broadcast values every
+  // hb = 1 lane holds anyway.  One active row costs a lane 7 LDS reads and 18 flops (the row layout: 21 and 40).
+  const int ia = L & 15, hb = L >> 4, cb = 9 * hb;
+  struct WinRow { real own, D, Da, jb[9]; };
+  auto load_row = [&](int t, WinRow& w) {
+    const int o = t * COOP_WSTRIDE;
+    w.own = ws[o + ia]; w.D = ws[o + 18]; w.Da = ws[o + 19];
+    _Pragma("unroll") for (int c = 0; c < 9; c++) w.jb[c] = ws[o + cb + c];
+  };
+  struct AsmAcc { real Ah[9], ag, c66, c76, c77, g6, g7; };
+  auto add_row = [&](const WinRow& w, AsmAcc& A) {
+    const real cD = w.D * w.own;
+    _Pragma("unroll") for (int c = 0; c < 9; c++) A.Ah[c] = fma(cD, w.jb[c], A.Ah[c]);
+    A.ag = fma(w.Da, w.own, A.ag);
+    const real d6 = w.D * w.jb[7], d7 = w.D * w.jb[8];              // (hb = 1: columns 16 and 17)
+    A.c66 = fma(d6, w.jb[7], A.c66); A.c76 = fma(d7, w.jb[7], A.c76); A.c77 = fma(d7, w.jb[8], A.c77);
+    A.g6 = fma(w.Da, w.jb[7], A.g6); A.g7 = fma(w.Da, w.jb[8], A.g7);
+  };
 
   for (int it = 0; it < 50; it++) {
-    MCG_COUNT(CN_COUPLED_IT);
-    // (a) residuals and the active set at a
-    real r0[COOP_SETS]; unsigned act[COOP_SETS];
-    _Pragma("unroll") for (int s = 0; s < COOP_SETS; s++) {
-      r0[s] = 0; act[s] = 0;
-      if (s < nsets) {
-        real acc = -aref[s];
-        _Pragma("unroll") for (int j = 0; j < COOP_NV; j++) acc = fma(J[s][j], a[j], acc);
-        r0[s] = acc;
-        act[s] = (unsigned)__ballot(Dr[s] > 0 && acc < 0);
-      }
-    }
-    // (b) H = H0 + sum_active D J J^T, g = g0 + sum_active D aref J: the active rows pass through a 16-row window in LDS
-    real H[COOP_NV], g = g0;
-    _Pragma("unroll") for (int j = 0; j < COOP_NV; j++) H[j] = H0[j];
-    _Pragma("unroll") for (int s = 0; s < COOP_SETS; s++) {
-      if (s < nsets && act[s] != 0u) {
+    COOP_COUNT(1, 1);
+    // (a) residuals and the active set at a; H0 a on the way (the line search's smooth gradient)
+    real r0[NSETS], h0a = 0; unsigned act[NSETS];
+    _Pragma("unroll") for (int s = 0; s < NSETS; s++) r0[s] = -aref[s];
+    static_for<COOP_NV>([&](auto Jj) { constexpr int j = Jj;
+      const real aj = coop_rdlane(al, j);
+      _Pragma("unroll") for (int s = 0; s < NSETS; s++) r0[s] = fma(J[s][j], aj, r0[s]);
+      h0a = fma(H0[j], aj, h0a); });
+    _Pragma("unroll") for (int s = 0; s < NSETS; s++) act[s] = (unsigned)__ballot(Dr[s] > 0 && r0[s] < 0);
+    MCG_TICK_PIN(r0, NSETS);
+    COOP_TICK(ST_CO_RESID);
+    COOP_COUNT(3, __popc(act[0]) + (NSETS > 1 ? __popc(act[1 % NSETS]) : 0) + (NSETS > 2 ? __popc(act[2 % NSETS]) : 0));
+    // (b) H = H0 + sum_active D J J^T, g = g0 + sum_active D aref J: the active rows pass through a 16-row window in LDS, read two
+    // rows at a time (all loads of a pair are issued before the first use: one LDS round trip per pair, not one per load)
+    AsmAcc A;
+    _Pragma("unroll") for (int c = 0; c < 9; c++) A.Ah[c] = 0;
+    A.ag = A.c66 = A.c76 = A.c77 = A.g6 = A.g7 = 0;
+    _Pragma("unroll") for (int s = 0; s < NSETS; s++) {
+      if (act[s] != 0u) {
         const int nact = __popc(act[s]);
         const int pos = __popc(act[s] & ((1u << L) - 1u));
         const bool mine = ((act[s] >> L) & 1u) != 0u;
         for (int w0 = 0; w0 < nact; w0 += COOP_WIN) {
+          const int nw = sel(nact - w0 < COOP_WIN, nact - w0, COOP_WIN);
           coop_lds_sync();                                        // the window's previous readers are done
           if (mine && pos >= w0 && pos < w0 + COOP_WIN) {
             const int o = (pos - w0) * COOP_WSTRIDE;
             _Pragma("unroll") for (int j = 0; j < COOP_NV; j++) ws[o + j] = J[s][j];
             ws[o + 18] = Dr[s]; ws[o + 19] = Dr[s] * aref[s];
           }
+          if ((nw & 1) && L < COOP_WSTRIDE) ws[nw * COOP_WSTRIDE + L] = 0.0;      // odd count: a zero row completes the last pair
           coop_lds_sync();
-          const int nw = sel(nact - w0 < COOP_WIN, nact - w0, COOP_WIN);
-          for (int t = 0; t < nw; t++) {
-            const int o = t * COOP_WSTRIDE;
-            const real ji = ws[o + i];
-            const real cD = ws[o + 18] * ji;
-            g = fma(ws[o + 19], ji, g);
-            _Pragma("unroll") for (int j = 0; j < COOP_NV; j++) H[j] = fma(cD, ws[o + j], H[j]);
+          for (int t = 0; t < nw; t += 2) {
+            WinRow wa, wb;
+            load_row(t, wa); load_row(t + 1, wb);
+            MCG_FENCE();
+            add_row(wa, A); add_row(wb, A);
+            MCG_FENCE();
           }
         }
       }
     }
-    // (c) gradient at a (lane i: (H a - g)_i), before the factorisation overwrites H
-    real grad = -g;
-    _Pragma("unroll") for (int j = 0; j < COOP_NV; j++) grad = fma(H[j], a[j], grad);
-    // (d) H = L D L^T in place: lane i ends with L[i][k] in H[k] (k < i); the pivot column travels by v_readlane
-    real dinv_l = 1.0;                              // lane i: 1 / D_i
+    // the increment, scattered as a full 18 x 18 matrix (and an 18-vector behind it), gathered row by row: lane i holds row i of H
+    coop_lds_sync();
+    _Pragma("unroll") for (int c = 0; c < 9; c++) ws[ia * COOP_NV + cb + c] = A.Ah[c];
+    if (hb == 1) { ws[16 * COOP_NV + ia] = A.Ah[7]; ws[17 * COOP_NV + ia] = A.Ah[8]; }
+    else ws[COOP_NV * COOP_NV + ia] = A.ag;
+    if (L == 16) {
+      ws[16 * COOP_NV + 16] = A.c66; ws[16 * COOP_NV + 17] = A.c76; ws[17 * COOP_NV + 16] = A.c76; ws[17 * COOP_NV + 17] = A.c77;
+      ws[COOP_NV * COOP_NV + 16] = A.g6; ws[COOP_NV * COOP_NV + 17] = A.g7;
+    }
+    coop_lds_sync();
+    real H[COOP_NV], g;
+    _Pragma("unroll") for (int j = 0; j < COOP_NV; j++) H[j] = ws[i * COOP_NV + j];
+    g = ws[COOP_NV * COOP_NV + i];
+    MCG_FENCE();
+    _Pragma("unroll") for (int j = 0; j < COOP_NV; j++) H[j] += H0[j];
+    g += g0;
+    MCG_TICK_PIN(H, COOP_NV);
+    COOP_TICK(ST_CO_ASM);
+    // (c) H = L D L^T.  Lane i ends with the UNSCALED column entries H[i][k] = L[i][k] D_k in H[k] and the scaled L[i][k] in Lr[k]
+    // (k < i; zero elsewhere, so the substitutions below need no masks); the pivot column travels by v_readlane, 1 / D_k stays uniform
+    real Lr[COOP_NV], dinv[COOP_NV];
     static_for<COOP_NV>([&](auto Kk) { constexpr int k = Kk;
       const real dk = coop_rdlane(H[k], k);
-      const real inv = rcp_nr(dk);
-      dinv_l = sel(i == k, inv, dinv_l);
-      const real lk = H[k] * inv;
+      dinv[k] = rcp_nr(dk);
+      const real lk = H[k] * dinv[k];
       static_for<COOP_NV - 1 - k>([&](auto Jj) { constexpr int j = k + 1 + Jj;
-        const real sj = coop_rdlane(H[k], j);                      // H[j][k] before scaling = L[j][k] D_k
+        const real sj = coop_rdlane(H[k], j);                      // H[j][k] = L[j][k] D_k
         H[j] = fma(-lk, sj, H[j]); });
-      H[k] = lk; });
-    // (e) x = H^-1 g.  Forward substitution in row layout; L^T through one LDS transpose for the backward pass.
-    real acc = g, y_l = 0;
+      Lr[k] = sel(i > k, lk, 0.0); });
+    MCG_TICK_PIN(Lr, COOP_NV);
+    COOP_TICK(ST_CO_FACTOR);
+    // (d) x = H^-1 g.  Forward: y = L^-1 g in row layout (lane k's accumulator is final when its turn comes and is not touched
+    // afterwards: Lr[k] is zero there).  Backward on the unscaled columns, D_j x_j = y_j - sum_{j' > j} (L[j'][j] D_j) x_j', which
+    // lane j gets through one LDS transpose.  The candidate's row residuals are accumulated as its entries appear.
+    real acc = g;
     static_for<COOP_NV>([&](auto Kk) { constexpr int k = Kk;
       const real yk = coop_rdlane(acc, k);
-      y_l = sel(i == k, acc, y_l);
-      acc = fma(-sel(i > k, H[k], 0.0), yk, acc); });
+      acc = fma(-Lr[k], yk, acc); });
     coop_lds_sync();
-    if (L < COOP_NV) { _Pragma("unroll") for (int k = 0; k < COOP_NV; k++) ws[L * COOP_NV + k] = H[k]; }
+    if (L < COOP_NV) { _Pragma("unroll") for (int k = 0; k < COOP_NV; k++) ws[L * COOP_NV + k] = sel(L > k, H[k], 0.0); }
     coop_lds_sync();
-    real U[COOP_NV];                                 // U[j] = L[j][i]: column i of L
+    real U[COOP_NV];                                 // U[j] = H[j][i] (unscaled) for j > i, zero otherwise
     _Pragma("unroll") for (int j = 0; j < COOP_NV; j++) U[j] = ws[j * COOP_NV + i];
-    real bacc = y_l * dinv_l;
-    real x[COOP_NV];
-    static_for<COOP_NV>([&](auto Kk) { constexpr int j = COOP_NV - 1 - Kk;
-      x[j] = coop_rdlane(bacc, j);
-      bacc = fma(-sel(i < j, U[j], 0.0), x[j], bacc); });
+    MCG_FENCE();
+    real rx[NSETS];
+    _Pragma("unroll") for (int s = 0; s < NSETS; s++) rx[s] = -aref[s];
     real xl = 0;
-    static_for<COOP_NV>([&](auto I) { constexpr int k = I; xl = sel(i == k, x[k], xl); });
-    // (f) does the candidate keep the assumed active set?
-    real p[COOP_NV];
-    _Pragma("unroll") for (int j = 0; j < COOP_NV; j++) p[j] = x[j] - a[j];
-    real dr_[COOP_SETS];
+    static_for<COOP_NV>([&](auto Kk) { constexpr int j = COOP_NV - 1 - Kk;
+      const real xj = coop_rdlane(acc, j) * dinv[j];
+      acc = fma(-U[j], xj, acc);
+      xl = sel(i == j, xj, xl);
+      _Pragma("unroll") for (int s = 0; s < NSETS; s++) rx[s] = fma(J[s][j], xj, rx[s]); });
+    MCG_TICK_PIN(rx, NSETS);
+    COOP_TICK(ST_CO_SOLVE);
+    // (e) does the candidate keep the assumed active set?
     bool same = true;
-    _Pragma("unroll") for (int s = 0; s < COOP_SETS; s++) {
-      dr_[s] = 0;
-      if (s < nsets) {
-        real dd = 0;
-        _Pragma("unroll") for (int j = 0; j < COOP_NV; j++) dd = fma(J[s][j], p[j], dd);
-        dr_[s] = dd;
-        const unsigned nw = (unsigned)__ballot(Dr[s] > 0 && (r0[s] + dd) < 0);
-        same = same && (nw == act[s]);
-      }
-    }
+    _Pragma("unroll") for (int s = 0; s < NSETS; s++) same = same && ((unsigned)__ballot(Dr[s] > 0 && rx[s] < 0) == act[s]);
+    COOP_TICK(ST_CO_CHECK);
     if (same || it < MCG_COOP_FULL_STEPS) {           // uniform.  A consistent candidate is the minimiser; the first iterations step to x anyway
-      _Pragma("unroll") for (int j = 0; j < COOP_NV; j++) a[j] = x[j];
       al = xl;
       if (same) break;
       continue;
     }
-    // (g) exact line search from a along p: phi'(alpha) = s0 + alpha quad_s + sum_rows D min(0, r0 + alpha dr) dr, piecewise linear, increasing
-    MCG_COUNT(CN_COUPLED_LS);
+    // (f) exact line search from a along p = x - a: phi'(alpha) = s0 + alpha quad + sum_rows D min(0, r0 + alpha dr) dr, piecewise linear and
+    // increasing; s0 = (H0 a - g0) . p and quad = p^T H0 p are the smooth part's
+    COOP_COUNT(2, 1);
     const real pl = xl - al;
-    const real q = -coop_sum32(sel(L < COOP_NV, grad * pl, 0.0));          // p^T H p
-    real t1s = 0, t2s = 0;
-    _Pragma("unroll") for (int s = 0; s < COOP_SETS; s++) {
-      const bool on = s < nsets && ((act[s] >> L) & 1u) != 0u;
-      t1s += sel(on, Dr[s] * r0[s] * dr_[s], 0.0); t2s += sel(on, Dr[s] * dr_[s] * dr_[s], 0.0);
-    }
-    const real s0 = -q - coop_sum32(t1s), quad = q - coop_sum32(t2s);
+    real h0p = 0;
+    static_for<COOP_NV>([&](auto Jj) { constexpr int j = Jj; h0p = fma(H0[j], coop_rdlane(pl, j), h0p); });
+    const bool own = L < COOP_NV;
+    const real s0 = coop_sum32(sel(own, (h0a - g0) * pl, 0.0)), quad = coop_sum32(sel(own, h0p * pl, 0.0));
+    real dr_[NSETS];
+    _Pragma("unroll") for (int s = 0; s < NSETS; s++) dr_[s] = rx[s] - r0[s];
     auto dphi = [&](real alp, real& slope) {
+      COOP_COUNT(4, 1);
       real f = 0, sl = 0;
-      _Pragma("unroll") for (int s = 0; s < COOP_SETS; s++) {
-        const real rr = r0[s] + alp * dr_[s];
-        const bool on = s < nsets && Dr[s] > 0 && rr < 0;
-        f += sel(on, Dr[s] * rr * dr_[s], 0.0); sl += sel(on, Dr[s] * dr_[s] * dr_[s], 0.0);
+      _Pragma("unroll") for (int s = 0; s < NSETS; s++) {
+        const real rr = fma(alp, dr_[s], r0[s]);
+        const bool on = Dr[s] > 0 && rr < 0;
+        const real dd = Dr[s] * dr_[s];
+        f += sel(on, dd * rr, 0.0); sl += sel(on, dd * dr_[s], 0.0);
       }
       slope = quad + coop_sum32(sl);
-      return s0 + alp * quad + coop_sum32(f);
+      return fma(alp, quad, s0) + coop_sum32(f);
     };
     real lo = 0, hi = 2, sl;
     const bool beyond = dphi(hi, sl) < 0;
     real alp = 1.0;
-    for (int b = 0; b < 16; b++) {
+    for (int b = 0; b < 8 && !beyond; b++) {                                   // (uniform)
       const real f = dphi(alp, sl);
       const bool neg = f < 0;
       lo = sel(neg, alp, lo); hi = sel(neg, hi, alp);
       const real nwt = alp - f / sl;
       const real nx = sel(nwt > lo && nwt < hi, nwt, 0.5 * (lo + hi));
-      const bool moved = fabs(nx - alp) > 1e-15 * fmax(1.0, fabs(alp));      // on the root's own linear piece Newton stays put
-      alp = nx;
-      if (!moved || beyond) break;                                            // uniform
+      const bool moved = fabs(nx - alp) > 1e-10 * fmax(1.0, fabs(alp));      // on the root's own linear piece Newton stays put; the step
+      alp = nx;                                                               // length needs no more: the LAST iteration is a full step
+      if (!moved) break;
     }
     const real alpha = sel(beyond, 2.0, alp);
-    _Pragma("unroll") for (int j = 0; j < COOP_NV; j++) a[j] = fma(alpha, p[j], a[j]);
     al = fma(alpha, pl, al);
+    MCG_TICK_PIN(&al, 1);
+    COOP_TICK(ST_CO_LS);
   }
   // ---- hand the accelerations back: robot part where the warm start was, cube part in the cube's warm-start slots
   if (L < NB) ME.st(PUB_WARM + L, al);
   else if (L < COOP_NV) ME.st(XCH_CB + 13 + (L - NB), al);
+  COOP_TICK(ST_CO_OUT);
 }
 
 // All four waves call this between barriers S4 and S5 with the same `mask` (bit l: lane l's environment is flagged): wave w solves
@@ -350,11 +406,27 @@ __device__ __noinline__ void coop_phase(unsigned long long model_bits, unsigned 
   unsigned m = __builtin_amdgcn_readfirstlane(mask);
   const int w = __builtin_amdgcn_readfirstlane(wave);
   const LdsPtr ws = lds0 + COOP_WS_ROW * PNP_LANES + w * COOP_WS_DOUBLES;
+  CoopClocks CK;
+#ifdef MCG_STAGE_CLOCKS
+  for (int k = 0; k < ST_CO_IDLE - ST_CO_SETUP; k++) CK.t[k] = 0;
+  for (int k = 0; k < 5; k++) CK.n[k] = 0;
+#endif
   for (int k = 0; m != 0u; k++) {
     const int e = __builtin_ctz(m);
     m &= m - 1u;
-    if ((k & 3) == w) coop_solve(P, lds0, e, ws);
+    if ((k & 3) == w) {
+      const int ncon = __builtin_amdgcn_readfirstlane((int)lds0[XCH_NCON * PNP_LANES + e]);
+      if (10 + 6 * ncon <= 2 * PNP_LANES) coop_solve<2>(P, lds0, e, ws, ncon, CK);      // up to 9 contacts: 64 rows
+      else coop_solve<COOP_SETS>(P, lds0, e, ws, ncon, CK);
+    }
   }
+#ifdef MCG_STAGE_CLOCKS
+  if ((threadIdx.x & 63) == 0) {
+    for (int k = 0; k < ST_CO_IDLE - ST_CO_SETUP; k++) if (CK.t[k]) atomicAdd(&g_stage_clocks[ST_CO_SETUP + k], CK.t[k]);
+    const int slot[5] = {CN_COUPLED, CN_COUPLED_IT, CN_COUPLED_LS, CN_COOP_ROWS, CN_COOP_LSEVAL};
+    for (int k = 0; k < 5; k++) if (CK.n[k]) atomicAdd(&g_stage_clocks[ST_COUNT + slot[k]], (unsigned long long)CK.n[k]);
+  }
+#endif
 }
 
 }  // namespace mcg

@@ -374,12 +374,19 @@ struct CubeSys {
         const real ez = fabs(Rio[6]) * bx[3] + fabs(Rio[7]) * bx[4] + fabs(Rio[8]) * bx[5];
         if (!__any(cz - ez < tp[2] + th[2])) return;                      // wave-uniform: nothing of it reaches the table top's height
         real lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY}, wz[3] = {0, 0, 0};
-        for (int k = 0; k < 26; k++) {
-          real v[3]; ldc<3>(H->link_hull[pi][k], v);
-          real w[3];
-          _Pragma("unroll") for (int r = 0; r < 3; r++) w[r] = pio[r] + Rio[3*r]*v[0] + Rio[3*r+1]*v[1] + Rio[3*r+2]*v[2];
-          const bool lower = w[2] < lo[2];                                 // first occurrence of the minimum, as the oracle keeps it
-          _Pragma("unroll") for (int r = 0; r < 3; r++) { wz[r] = sel(lower, w[r], wz[r]); lo[r] = fmin(lo[r], w[r]); hi[r] = fmax(hi[r], w[r]); }
+        // four vertices per batch of scalar loads: a wave alone on its SIMD pays every s_load round trip in full, and 26 dependent
+        // ones per mesh were most of this pass under a policy that keeps the arm near the table (the last batch repeats vertex 25:
+        // a repeated vertex changes neither the extremes nor the first lowest one)
+        for (int kb = 0; kb < 26; kb += 4) {
+          real v4[4][3];
+          { ModelPtr Hb = launder(Pm);
+            _Pragma("unroll") for (int u = 0; u < 4; u++) { const int k = sel(kb + u < 26, kb + u, 25); ldc<3>(Hb->link_hull[pi][k], v4[u]); } }
+          _Pragma("unroll") for (int u = 0; u < 4; u++) {
+            real w[3];
+            _Pragma("unroll") for (int r = 0; r < 3; r++) w[r] = pio[r] + Rio[3*r]*v4[u][0] + Rio[3*r+1]*v4[u][1] + Rio[3*r+2]*v4[u][2];
+            const bool lower = w[2] < lo[2];                               // first occurrence of the minimum, as the oracle keeps it
+            _Pragma("unroll") for (int r = 0; r < 3; r++) { wz[r] = sel(lower, w[r], wz[r]); lo[r] = fmin(lo[r], w[r]); hi[r] = fmax(hi[r], w[r]); }
+          }
         }
         const int mult = (int)H->link_mult;
         const int before = CL.n;

@@ -545,6 +545,7 @@ MCG_DEV void cube_wave(const View& V, ModelPtr P, const PnpScratch MS, unsigned 
       coop_phase((unsigned long long)P, lds0, flagged_lanes(MS), 1);
       MCG_TICK2(ST_COUPLED);
       __syncthreads();                                              // S5
+      MCG_TICK2(ST_CO_IDLE);
       _Pragma("unroll") for (int k = 0; k < 6; k++) CS.a_c[k] = sel(flag, MS.ld(XCH_CB + 13 + k), CS.a_c[k]);
       CS.finish(qlag7); Cb = CS.Cb;
     }
@@ -570,6 +571,7 @@ MCG_DEV void pnp_substep_robot(ModelPtr P, EnvP& E, const PnpScratch MS, unsigne
     coop_phase((unsigned long long)P, lds0, mask, 0);
     MCG_TICK(ST_COUPLED);
     __syncthreads();                                                // S5
+    MCG_TICK(ST_CO_IDLE);
     // Euler step of the flagged lanes with the coupled acceleration (M a carries the contact forces); the others keep theirs
     real a[NB], rhs[NB];
     static_for<NB>([&](auto I) { constexpr int k = I; a[k] = sel(flag, MS.ld(PUB_WARM + k), nx.warm[k]); });

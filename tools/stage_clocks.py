@@ -21,14 +21,18 @@ NAMES = ["load", "controller", "sincos", "rne", "actuation", "crb->M", "rows: we
          "cube wave: waiting for q (S1)", "cube wave: collision", "cube wave: solve + finish", "cube wave: waiting at S2",
          "robot wave: waiting at S2",
          "assemble phase: entry loads", "assemble phase: G <- H_eq, Cm <- 0", "assemble phase: twist columns, relative twists",
-         "assemble phase: contact loop", "assemble phase: mapping to dofs", "assemble phase: stores"]
+         "assemble phase: contact loop", "assemble phase: mapping to dofs", "assemble phase: stores",
+         "coop: env data, twist columns", "coop: rows", "coop: H0, g0", "coop: residuals, active set", "coop: assembly (LDS window)",
+         "coop: gradient + LDL", "coop: solves + transpose", "coop: consistency check", "coop: line search", "coop: hand back", "coop: idle at S5"]
 COUNTS = ["robot sub-steps", "robot Newton iterations", "robot line searches", "cube Newton iterations", "cube line searches",
-          "coupled solves", "coupled Newton iterations", "coupled line searches", "wave-max contacts (per collision pass)"]
+          "coupled solves", "coupled Newton iterations", "coupled line searches", "wave-max contacts (per collision pass)",
+          "coop active rows (sum over iterations)", "coop line-search evaluations"]
 fresh = "--fresh-actions" in sys.argv
 grasp = "--grasp" in sys.argv           # PickAndPlace joint with every env holding the cube (scripted grasp state)
 L = _abi.load()
 n = 8192
-for obj, ctrl, k in (((True, "joint", 20),) if grasp else ((False, "joint", 200), (False, "IK", 50), (True, "joint", 100), (True, "IK", 20))):
+pnpik = "--pnp-ik" in sys.argv         # PickAndPlace, IK controller, random policy only
+for obj, ctrl, k in (((True, "joint", 20),) if grasp else ((True, "IK", 20),) if pnpik else ((False, "joint", 200), (False, "IK", 50), (True, "joint", 100), (True, "IK", 20))):
     envs = MyCobotVecEnv(n, has_object=obj, controller_type=ctrl, reward_type="dense", max_episode_steps=10 ** 9 if grasp else 50)
     envs.reset(seed=0)
     a = torch.rand(n, envs.action_dim, device="cuda") * 2 - 1
