@@ -32,8 +32,9 @@ namespace mcg {
 // ---- exchange slots of the four-wave kernel (all per-lane columns).
 // Clip-polygon slots (only the collision pass uses them, before barrier S2): flags and the cube's hand-over.
 constexpr int XCH_FLAG = LDS_POLY, XCH_T0 = LDS_POLY + 1, XCH_T1 = LDS_POLY + 2, XCH_NCON = LDS_POLY + 3;
-constexpr int XCH_CB = LDS_POLY + 4, XCH_QL7 = LDS_POLY + 23, XCH_DR = LDS_POLY + 30;      // cube: pos 3, quat 4, vel 6, warm 6; lagged pose 7; DR scales 2
-static_assert(XCH_DR + 2 <= LDS_POLY + 64, "exchange area exceeds the clip-polygon slots");
+constexpr int XCH_CB = LDS_POLY + 4, XCH_QL7 = LDS_POLY + 23, XCH_DR = LDS_POLY + 30, COOP_CTR_SLOT = LDS_POLY + 32;      // cube: pos 3, quat 4, vel 6, warm 6; lagged pose 7; DR scales 2
+static_assert(COOP_CTR_SLOT + 1 <= LDS_POLY + 64, "exchange area exceeds the clip-polygon slots");
+// COOP_CTR_SLOT: lane 0's column of it is the workgroup's hand-out counter of the cooperative phase (an unsigned, in the slot's first word)
 // Line-search row area (LDS_ROW .. LDS_ROW + 144 slot rows of PNP_LANES doubles):
 //   [0, 24)    q(t), qd(t) for the other waves: written at the end of a sub-step, read right after S1, dead after S2 (the cube wave's
 //              own solve then uses the area; prepare() does NOT touch it -- it runs between S1 and S2, while the M and RNE waves read)
@@ -45,7 +46,7 @@ constexpr int PUB_G0 = LDS_ROW + 24, PUB_SD = PUB_G0 + NB, PUB_AREF = PUB_SD + 1
 constexpr int COOP_WS_ROW = LDS_ROW + 80, COOP_WS_DOUBLES = 512;
 static_assert(PUB_QD + NB == COOP_WS_ROW, "publish area");
 static_assert(COOP_WS_ROW * PNP_LANES + 4 * COOP_WS_DOUBLES <= (LDS_ROW + MAXCON * 12) * PNP_LANES, "cooperative workspace exceeds the row area");
-constexpr int COOP_NV = 18, COOP_WIN = 16, COOP_WSTRIDE = 20;          // window: 16 active rows x (J[18], D, D*aref)
+constexpr int COOP_NV = 18, COOP_WIN = 16, COOP_WSTRIDE = 20;          // window: 16 active rows x (D, D aref, J[18])
 static_assert(COOP_WIN * COOP_WSTRIDE <= COOP_WS_DOUBLES && COOP_NV * COOP_NV + COOP_NV <= COOP_WS_DOUBLES, "window / matrix buffer");
 constexpr int COOP_ROWS = 10 + 6 * MAXCON, COOP_SETS = (COOP_ROWS + PNP_LANES - 1) / PNP_LANES;      // limits first, then the contacts
 #ifndef MCG_COOP_FULL_STEPS
@@ -68,6 +69,9 @@ MCG_DEV real coop_sum32(real v) {      // sum over the 32 active lanes, the same
   v += coop_dpp<0x141>(v);             // row_half_mirror
   v += coop_dpp<0x140>(v);             // row_mirror: every lane of a 16-lane row holds the row's sum
   return coop_rdlane(v, 0) + coop_rdlane(v, 16);
+}
+template <int K> MCG_DEV real coop_bcast16(real v) {      // lane K of each 16-lane DPP row to all lanes of that row: one v_mov_b64_dpp
+  return __builtin_amdgcn_update_dpp(v, v, 0x150 + K, 0xF, 0xF, false);      // (old = v: every lane is written, nothing to preset)
 }
 MCG_DEV void coop_lds_sync() {         // LDS traffic between lanes of one wave: order the compiler (the hardware keeps a wave's LDS ops in order)
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -229,20 +233,26 @@ MCG_DEV void coop_solve(ModelPtr Pm, LdsPtr lds0, int e, LdsPtr ws, int ncon, Co
   // rows 16 and 17 come from the symmetry (columns 16, 17 of the hb = 1 lanes) and their 2 x 2 corner from the broadcast values every
   // hb = 1 lane holds anyway.  One active row costs a lane 7 LDS reads and 18 flops (the row layout: 21 and 40).
   const int ia = L & 15, hb = L >> 4, cb = 9 * hb;
-  struct WinRow { real own, D, Da, jb[9]; };
+  // A window row is [D, D aref, J_0 .. J_17].  A lane reads TWO numbers of it -- its own entry J_t[ia] and one of the eleven its half-row
+  // needs (D, D aref, J_t[9 hb .. 9 hb + 8], lane l of the 16-lane DPP row holds the l-th) -- and the eleven reach every lane of the
+  // half by v_mov_b64_dpp row_newbcast: the four waves of the workgroup share one LDS pipe, the VALU is each wave's own.
+  const int lseg = L & 15, iseg = lseg + ((hb == 1 && lseg >= 2) ? 9 : 0);
+  struct WinRow { real own, seg; };
   auto load_row = [&](int t, WinRow& w) {
     const int o = t * COOP_WSTRIDE;
-    w.own = ws[o + ia]; w.D = ws[o + 18]; w.Da = ws[o + 19];
-    _Pragma("unroll") for (int c = 0; c < 9; c++) w.jb[c] = ws[o + cb + c];
+    w.own = ws[o + 2 + ia]; w.seg = ws[o + iseg];
   };
   struct AsmAcc { real Ah[9], ag, c66, c76, c77, g6, g7; };
   auto add_row = [&](const WinRow& w, AsmAcc& A) {
-    const real cD = w.D * w.own;
-    _Pragma("unroll") for (int c = 0; c < 9; c++) A.Ah[c] = fma(cD, w.jb[c], A.Ah[c]);
-    A.ag = fma(w.Da, w.own, A.ag);
-    const real d6 = w.D * w.jb[7], d7 = w.D * w.jb[8];              // (hb = 1: columns 16 and 17)
-    A.c66 = fma(d6, w.jb[7], A.c66); A.c76 = fma(d7, w.jb[7], A.c76); A.c77 = fma(d7, w.jb[8], A.c77);
-    A.g6 = fma(w.Da, w.jb[7], A.g6); A.g7 = fma(w.Da, w.jb[8], A.g7);
+    const real D = coop_bcast16<0>(w.seg), Da = coop_bcast16<1>(w.seg);
+    real jb[9];
+    static_for<9>([&](auto Cc) { constexpr int c = Cc; jb[c] = coop_bcast16<2 + c>(w.seg); });
+    const real cD = D * w.own;
+    _Pragma("unroll") for (int c = 0; c < 9; c++) A.Ah[c] = fma(cD, jb[c], A.Ah[c]);
+    A.ag = fma(Da, w.own, A.ag);
+    const real d6 = D * jb[7], d7 = D * jb[8];                      // (hb = 1: columns 16 and 17)
+    A.c66 = fma(d6, jb[7], A.c66); A.c76 = fma(d7, jb[7], A.c76); A.c77 = fma(d7, jb[8], A.c77);
+    A.g6 = fma(Da, jb[7], A.g6); A.g7 = fma(Da, jb[8], A.g7);
   };
 
   for (int it = 0; it < 50; it++) {
@@ -273,17 +283,21 @@ MCG_DEV void coop_solve(ModelPtr Pm, LdsPtr lds0, int e, LdsPtr ws, int ncon, Co
           coop_lds_sync();                                        // the window's previous readers are done
           if (mine && pos >= w0 && pos < w0 + COOP_WIN) {
             const int o = (pos - w0) * COOP_WSTRIDE;
-            _Pragma("unroll") for (int j = 0; j < COOP_NV; j++) ws[o + j] = J[s][j];
-            ws[o + 18] = Dr[s]; ws[o + 19] = Dr[s] * aref[s];
+            ws[o] = Dr[s]; ws[o + 1] = Dr[s] * aref[s];
+            _Pragma("unroll") for (int j = 0; j < COOP_NV; j++) ws[o + 2 + j] = J[s][j];
           }
           if ((nw & 1) && L < COOP_WSTRIDE) ws[nw * COOP_WSTRIDE + L] = 0.0;      // odd count: a zero row completes the last pair
           coop_lds_sync();
+          WinRow wa, wb;                                          // two rows per turn, the next pair's loads in flight meanwhile
+          load_row(0, wa); load_row(1, wb);
           for (int t = 0; t < nw; t += 2) {
-            WinRow wa, wb;
-            load_row(t, wa); load_row(t + 1, wb);
+            const int tn = sel(t + 2 < nw, t + 2, t);               // (the last turn re-reads its own pair)
+            WinRow na, nb;
+            load_row(tn, na); load_row(tn + 1, nb);
             MCG_FENCE();
             add_row(wa, A); add_row(wb, A);
             MCG_FENCE();
+            wa = na; wb = nb;
           }
         }
       }
@@ -403,7 +417,7 @@ __device__ __noinline__ void coop_phase(unsigned long long model_bits, unsigned 
   const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)model_bits), hi = __builtin_amdgcn_readfirstlane((unsigned)(model_bits >> 32));
   const ModelPtr P = (ModelPtr)(((unsigned long long)hi << 32) | lo);
   const LdsPtr lds0 = (LdsPtr)(uintptr_t)__builtin_amdgcn_readfirstlane(lds_base);
-  unsigned m = __builtin_amdgcn_readfirstlane(mask);
+  const unsigned m = __builtin_amdgcn_readfirstlane(mask);
   const int w = __builtin_amdgcn_readfirstlane(wave);
   const LdsPtr ws = lds0 + COOP_WS_ROW * PNP_LANES + w * COOP_WS_DOUBLES;
   CoopClocks CK;
@@ -411,14 +425,23 @@ __device__ __noinline__ void coop_phase(unsigned long long model_bits, unsigned 
   for (int k = 0; k < ST_CO_IDLE - ST_CO_SETUP; k++) CK.t[k] = 0;
   for (int k = 0; k < 5; k++) CK.n[k] = 0;
 #endif
-  for (int k = 0; m != 0u; k++) {
-    const int e = __builtin_ctz(m);
-    m &= m - 1u;
-    if ((k & 3) == w) {
-      const int ncon = __builtin_amdgcn_readfirstlane((int)lds0[XCH_NCON * PNP_LANES + e]);
-      if (10 + 6 * ncon <= 2 * PNP_LANES) coop_solve<2>(P, lds0, e, ws, ncon, CK);      // up to 9 contacts: 64 rows
-      else coop_solve<COOP_SETS>(P, lds0, e, ws, ncon, CK);
-    }
+  // The flagged environments are handed out one at a time from a counter in LDS (solves differ by a factor of ten in their Newton
+  // iteration counts: a fixed split leaves three waves waiting for the unluckiest).  The counter starts at zero: the robot wave
+  // clears it before barrier S4, and it is only touched between S4 and S5.
+  typedef __attribute__((address_space(3))) unsigned* LdsCtr;
+  const LdsCtr ctr = (LdsCtr)(lds0 + COOP_CTR_SLOT * PNP_LANES);
+  const int total = __popc(m);
+  for (;;) {
+    unsigned k = 0;
+    if ((threadIdx.x & 63) == 0) k = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    k = __builtin_amdgcn_readfirstlane(k);
+    if ((int)k >= total) break;
+    unsigned mm = m;
+    for (unsigned q = 0; q < k; q++) mm &= mm - 1u;          // the k-th flagged lane
+    const int e = __builtin_ctz(mm);
+    const int ncon = __builtin_amdgcn_readfirstlane((int)lds0[XCH_NCON * PNP_LANES + e]);
+    if (10 + 6 * ncon <= 2 * PNP_LANES) coop_solve<2>(P, lds0, e, ws, ncon, CK);      // up to 9 contacts: 64 rows
+    else coop_solve<COOP_SETS>(P, lds0, e, ws, ncon, CK);
   }
 #ifdef MCG_STAGE_CLOCKS
   if ((threadIdx.x & 63) == 0) {

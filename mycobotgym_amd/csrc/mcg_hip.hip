@@ -563,6 +563,7 @@ MCG_DEV void pnp_substep_robot(ModelPtr P, EnvP& E, const PnpScratch MS, unsigne
   PubHook hook{MS};
   robot_substep<PnpScratch, PubHook, WLD, SplitPnp, false>(P, E.R, E.qlag6, MS, &hook, &W, &nx);     // S1, S2 inside
   MCG_TICK(ST_POST);
+  if ((threadIdx.x & 63) == 0) *(__attribute__((address_space(3))) unsigned*)(uintptr_t)(lds0 + COOP_CTR_SLOT * PNP_LANES * 8) = 0u;      // the cooperative phase's hand-out counter
   __syncthreads();                                                  // S4
   MCG_TICK(ST_W1_WAIT);
   const bool flag = MS.ld(XCH_FLAG) != 0.0;
