@@ -30,22 +30,26 @@
 namespace mcg {
 
 // ---- exchange slots of the four-wave kernel (all per-lane columns).
-// Clip-polygon slots (only the collision pass uses them, before barrier S2): flags and the cube's hand-over.
+// Clip-polygon area, first 32 slots (the collision pass clips there, before barrier S2; afterwards:) flags and the cube's hand-over.
+// XCH_FLAG: 0 = no contact reaches the robot | 1 = only static geoms touch the robot (pad / arm mesh on the table or the ground): robot
+// and cube still decouple | 2 = the cube touches the robot (pad / finger link): one coupled 18-dof problem.
 constexpr int XCH_FLAG = LDS_POLY, XCH_T0 = LDS_POLY + 1, XCH_T1 = LDS_POLY + 2, XCH_NCON = LDS_POLY + 3;
-constexpr int XCH_CB = LDS_POLY + 4, XCH_QL7 = LDS_POLY + 23, XCH_DR = LDS_POLY + 30, COOP_CTR_SLOT = LDS_POLY + 32;      // cube: pos 3, quat 4, vel 6, warm 6; lagged pose 7; DR scales 2
-static_assert(COOP_CTR_SLOT + 1 <= LDS_POLY + 64, "exchange area exceeds the clip-polygon slots");
-// COOP_CTR_SLOT: lane 0's column of it is the workgroup's hand-out counter of the cooperative phase (an unsigned, in the slot's first word)
+constexpr int XCH_CB = LDS_POLY + 4, XCH_QL7 = LDS_POLY + 23, XCH_DR = LDS_POLY + 30;      // cube: pos 3, quat 4, vel 6, warm 6; lagged pose 7; DR scales 2
+static_assert(XCH_DR + 2 <= LDS_POLY + 32, "exchange area exceeds the clip-polygon slots");
+// ... second 32 slots, which no pass writes: q(t), qd(t) of the robot for the other waves -- written at the end of a sub-step, read after
+// S1 by the M, RNE and cube waves and between S4 and S5 by the cooperative solves -- and the workgroup's hand-out counter of that phase
+// (an unsigned in the first word of lane 0's slot).
+constexpr int XCH_Q = LDS_POLY + 32, XCH_QD = XCH_Q + NB, COOP_CTR_SLOT = XCH_QD + NB;
+static_assert(COOP_CTR_SLOT + 1 <= LDS_POLY + 64, "exchange area");
 // Line-search row area (LDS_ROW .. LDS_ROW + 144 slot rows of PNP_LANES doubles):
-//   [0, 24)    q(t), qd(t) for the other waves: written at the end of a sub-step, read right after S1, dead after S2 (the cube wave's
-//              own solve then uses the area; prepare() does NOT touch it -- it runs between S1 and S2, while the M and RNE waves read)
-//   [24, 80)   columns of the FLAGGED lanes only: inputs of their coupled solve, parked by the robot wave after S2.  (The cube wave's
-//              solve skips flagged lanes and leaves their columns alone.)
-//   [80, 144)  cooperative workspace, 512 doubles per wave, used between barriers S4 and S5 only (every lane-parallel solve is over)
-constexpr int XCH_Q = LDS_ROW, XCH_QD = LDS_ROW + NB;
-constexpr int PUB_G0 = LDS_ROW + 24, PUB_SD = PUB_G0 + NB, PUB_AREF = PUB_SD + 10, PUB_WARM = PUB_AREF + 10, PUB_QD = PUB_WARM + NB;
-constexpr int COOP_WS_ROW = LDS_ROW + 80, COOP_WS_DOUBLES = 512;
-static_assert(PUB_QD + NB == COOP_WS_ROW, "publish area");
-static_assert(COOP_WS_ROW * PNP_LANES + 4 * COOP_WS_DOUBLES <= (LDS_ROW + MAXCON * 12) * PNP_LANES, "cooperative workspace exceeds the row area");
+//   [0, 96)    the cube wave's own solves (12 slots per contact, list positions 0..7: a lane whose cube contacts sit higher is flagged 2);
+//              between barriers S4 and S5, when every lane-parallel solve is over: cooperative workspace, 768 doubles per wave
+//   [96, 140)  columns of the FLAGGED lanes only: inputs of their cooperative solve, parked by the robot wave after S2
+constexpr int PUB_G0 = LDS_ROW + 96, PUB_SD = PUB_G0 + NB, PUB_AREF = PUB_SD + 10, PUB_WARM = PUB_AREF + 10;
+constexpr int COOP_WS_ROW = LDS_ROW, COOP_WS_DOUBLES = 768;
+static_assert(PUB_WARM + NB <= LDS_ROW + MAXCON * 12, "publish area");
+static_assert(4 * COOP_WS_DOUBLES <= 96 * PNP_LANES, "cooperative workspace exceeds the first 96 rows of the row area");
+static_assert(ALONE_MAX_LIST * 12 <= 96, "a flagged-1 lane's own solve must stay below the parked inputs");
 constexpr int COOP_NV = 18, COOP_WIN = 16, COOP_WSTRIDE = 20;          // window: 16 active rows x (D, D aref, J[18])
 static_assert(COOP_WIN * COOP_WSTRIDE <= COOP_WS_DOUBLES && COOP_NV * COOP_NV + COOP_NV <= COOP_WS_DOUBLES, "window / matrix buffer");
 constexpr int COOP_ROWS = 10 + 6 * MAXCON, COOP_SETS = (COOP_ROWS + PNP_LANES - 1) / PNP_LANES;      // limits first, then the contacts
@@ -62,6 +66,10 @@ template <int CTRL> MCG_DEV real coop_dpp(real v) {
   const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, false);
   const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, false);
   return __hiloint2double(hi, lo);
+}
+MCG_DEV real coop_sum16(real v) {      // sum over each 16-lane DPP row, in every lane of the row
+  v += coop_dpp<0xB1>(v); v += coop_dpp<0x4E>(v); v += coop_dpp<0x141>(v); v += coop_dpp<0x140>(v);
+  return v;
 }
 MCG_DEV real coop_sum32(real v) {      // sum over the 32 active lanes, the same (uniform) number in every lane
   v += coop_dpp<0xB1>(v);              // quad_perm [1,0,3,2]
@@ -82,7 +90,7 @@ MCG_DEV void coop_lds_sync() {         // LDS traffic between lanes of one wave:
 // Stage clocks of the cooperative solve (-DMCG_STAGE_CLOCKS): accumulated in registers, added to the global table once per coop_phase
 // (one atomic per tick from a thousand waves would itself be the largest stage).
 #ifdef MCG_STAGE_CLOCKS
-struct CoopClocks { unsigned long long last, t[ST_CO_IDLE - ST_CO_SETUP]; unsigned n[5]; };      // n: solves, iterations, line searches, active rows, evaluations
+struct CoopClocks { unsigned long long last, t[ST_CO_IDLE - ST_CO_SETUP]; unsigned n[8]; };      // n: solves, iterations, line searches, active rows, evaluations, solves of >= 8 iterations, solves that hit the cap, 12-dof solves
 #define COOP_COUNT(k, v) do { CK.n[k] += (unsigned)(v); } while (0)
 #define COOP_TICK(k) do { const unsigned long long t_ = __builtin_readcyclecounter(); CK.t[(k) - ST_CO_SETUP] += t_ - CK.last; CK.last = t_; } while (0)
 #else
@@ -128,7 +136,7 @@ MCG_DEV void coop_solve(ModelPtr Pm, LdsPtr lds0, int e, LdsPtr ws, int ncon, Co
     _Pragma("unroll") for (int k = 0; k < 3; k++) { tc[j][k] = sel(ok, v[k], 0.0); tc[j][3 + k] = sel(ok, ax[k], 0.0); }
   }
   real qd[NB], vc[6];
-  _Pragma("unroll") for (int j = 0; j < NB; j++) qd[j] = ME.ld(PUB_QD + j);
+  _Pragma("unroll") for (int j = 0; j < NB; j++) qd[j] = ME.ld(XCH_QD + j);
   _Pragma("unroll") for (int k = 0; k < 6; k++) vc[k] = Cb.vel[k];
 
   COOP_TICK(ST_CO_SETUP);
@@ -257,6 +265,8 @@ MCG_DEV void coop_solve(ModelPtr Pm, LdsPtr lds0, int e, LdsPtr ws, int ncon, Co
 
   for (int it = 0; it < 50; it++) {
     COOP_COUNT(1, 1);
+    if (it == 8) COOP_COUNT(5, 1);
+    if (it == 49) COOP_COUNT(6, 1);
     // (a) residuals and the active set at a; H0 a on the way (the line search's smooth gradient)
     real r0[NSETS], h0a = 0; unsigned act[NSETS];
     _Pragma("unroll") for (int s = 0; s < NSETS; s++) r0[s] = -aref[s];
@@ -411,6 +421,266 @@ MCG_DEV void coop_solve(ModelPtr Pm, LdsPtr lds0, int e, LdsPtr ws, int ncon, Co
   COOP_TICK(ST_CO_OUT);
 }
 
+// ---- robot-only variant (flag 1).  The environment's robot-reaching contacts are all against static geoms (table / ground - pad or arm
+// mesh): cube and robot decouple, the cube stays with the cube wave's lane-parallel solve, and the robot's 12 dofs are solved here with
+// the rows that have a robot part.  12 matrix rows fit one 16-lane DPP row: lane i and lane 16 + i both hold row i (the same arithmetic on
+// the same numbers), so EVERY broadcast of the factorisation and of the substitutions is a v_mov_b64_dpp row_newbcast within the row --
+// no v_readlane, no SGPR round trip.  Same iteration as coop_solve.
+constexpr int C12_WSTRIDE = 14;        // window row: D, D aref, J[12]
+template <int NSETS>
+MCG_DEV void coop_solve12(ModelPtr Pm, LdsPtr lds0, int e, LdsPtr ws, int ncon, CoopClocks& CK) {
+  constexpr int NV = NB;
+  const int L = threadIdx.x & (PNP_LANES - 1);
+  const PnpScratch ME(lds0 + e);
+  COOP_COUNT(0, 1); COOP_COUNT(7, 1);
+#ifdef MCG_STAGE_CLOCKS
+  CK.last = __builtin_readcyclecounter();
+#endif
+  // pair numbers of the static geom - robot contacts, as CubeSys::derive forms them
+  real mu_tp[3], mu_tl[3], B_tp, B_tl;
+  {
+    ModelPtr Q = launder(Pm);
+    const real dr1 = ME.ld(XCH_DR + 1);
+    const real ft = Q->geom_friction0[0], fp = Q->geom_friction0[1] * dr1;
+    mu_tp[0] = mu_tp[1] = fmax(ft, fp); mu_tp[2] = Q->contact_par[PAIR_TABLE_PADR][12]; B_tp = Q->contact_par[PAIR_TABLE_PADR][1];
+    mu_tl[0] = mu_tl[1] = Q->contact_par[PAIR_TABLE_LINK0][10]; mu_tl[2] = 0; B_tl = Q->contact_par[PAIR_TABLE_LINK0][1];
+  }
+  bool side_any[2] = {false, false};
+  for (int c = 0; c < ncon; c++) {
+    const int type = (int)ME.ld(LDS_CON + c * CON_STRIDE + 15);
+    side_any[0] = side_any[0] || type == PAIR_TABLE_PADR; side_any[1] = side_any[1] || type == PAIR_TABLE_PADL;
+  }
+  real tc[10][6];                      // twist columns about the world origin
+  _Pragma("unroll") for (int j = 0; j < 10; j++) {
+    real ax[3], d[3], v[3];
+    _Pragma("unroll") for (int k = 0; k < 3; k++) { ax[k] = ME.ld(LDS_WJ + j * 6 + k); d[k] = ME.ld(LDS_WJ + j * 6 + 3 + k); }
+    cross(d, ax, v);
+    const bool ok = (j < 6) || side_any[(j - 6) >> 1];
+    _Pragma("unroll") for (int k = 0; k < 3; k++) { tc[j][k] = sel(ok, v[k], 0.0); tc[j][3 + k] = sel(ok, ax[k], 0.0); }
+  }
+  real qd[10];
+  _Pragma("unroll") for (int j = 0; j < 10; j++) qd[j] = ME.ld(XCH_QD + j);
+  COOP_TICK(ST_CO_SETUP);
+  // ---- rows (numbering as in coop_solve; the cube's own contacts get no row)
+  real J[NSETS][NV], Dr[NSETS], aref[NSETS];
+  _Pragma("unroll") for (int s = 0; s < NSETS; s++) {
+    const int r = PNP_LANES * s + L;
+    const bool is_lim = r < 10;
+    const int jl = sel(is_lim, r, 0);
+    const real sD = ME.ld(PUB_SD + jl), al_ = ME.ld(PUB_AREF + jl);
+    const real sgn = sel(sD > 0, 1.0, sel(sD < 0, -1.0, 0.0));
+    const int rc = sel(is_lim, 0, r - 10);
+    const int c = sel(rc / 6 < MAXCON, rc / 6, MAXCON - 1), p = rc % 6;
+    const bool is_con = !is_lim && (rc / 6 < ncon);
+    const int b = LDS_CON + c * CON_STRIDE;
+    real pos[3], n[3], t1[3], t2[3];
+    _Pragma("unroll") for (int k = 0; k < 3; k++) { pos[k] = ME.ld(b + k); n[k] = ME.ld(b + 3 + k); t1[k] = ME.ld(b + 6 + k); t2[k] = ME.ld(b + 9 + k); }
+    const real Dc = ME.ld(b + 13), kterm = ME.ld(b + 14), ftype = ME.ld(b + 15);
+    MCG_FENCE();
+    const int type = sel(is_con, (int)ftype, 0);
+    const bool link = type >= PAIR_TABLE_LINK0 && type < PAIR_FINR_CUBE, tabp = (type == PAIR_TABLE_PADR || type == PAIR_TABLE_PADL);
+    const int side = sel(type == PAIR_TABLE_PADL, 1, 0);
+    const int lbody = sel(link, sel(type - PAIR_TABLE_LINK0 < 5, type - PAIR_TABLE_LINK0, 5), sel(tabp, 5, -1));
+    const int kf = p >> 1;
+    const real m = sel((p & 1), -1.0, 1.0) * sel(link, sel3(kf, mu_tl[0], mu_tl[1], mu_tl[2]), sel3(kf, mu_tp[0], mu_tp[1], mu_tp[2]));
+    const real Bc = sel(link, B_tl, B_tp);
+    const bool live = is_con && (link || tabp) && !(link && kf == 2);
+    real dlin[3], eang[3];
+    _Pragma("unroll") for (int k = 0; k < 3; k++) dlin[k] = n[k] + sel(kf == 0, m * t1[k], sel(kf == 1, m * t2[k], 0.0));
+    cross(pos, dlin, eang);
+    const real tau = sel(kf == 2, m, 0.0);
+    _Pragma("unroll") for (int k = 0; k < 3; k++) eang[k] = fma(tau, n[k], eang[k]);
+    real vel = 0;
+    _Pragma("unroll") for (int j = 0; j < 10; j++) {
+      const bool member = live && ((j < 6) ? (j <= lbody) : (tabp && ((j - 6) >> 1) == side));
+      const real dj = dlin[0] * tc[j][0] + dlin[1] * tc[j][1] + dlin[2] * tc[j][2] + eang[0] * tc[j][3] + eang[1] * tc[j][4] + eang[2] * tc[j][5];
+      J[s][j] = sel(member, dj, 0.0);                       // the robot geom is geom2 of a static pair: +
+      vel = fma(J[s][j], qd[j], vel);
+    }
+    J[s][10] = J[s][11] = 0;
+    Dr[s] = sel(live, Dc, 0.0); aref[s] = sel(live, -Bc * vel - kterm, 0.0);
+    _Pragma("unroll") for (int j = 0; j < 10; j++) J[s][j] = sel(is_lim, sel(j == jl, sgn, 0.0), J[s][j]);
+    Dr[s] = sel(is_lim, fabs(sD), Dr[s]); aref[s] = sel(is_lim, al_, aref[s]);
+  }
+  MCG_TICK_PIN(Dr, NSETS); MCG_TICK_PIN(aref, NSETS);
+  COOP_TICK(ST_CO_ROWS);
+  // ---- H0 = M + J_eq^T D J_eq and g0: lanes i and 16 + i hold row i (lanes 12..15 of a DPP row shadow row 11)
+  const int l16 = L & 15, i = sel(l16 < NV, l16, NV - 1);
+  real H0[NV], g0;
+  {
+    unsigned mE = 0, mM = 0;
+    static_for<NV>([&](auto I) { constexpr int k = I; mE = sel(i == k, coop_row_mask(PAT_E, k), mE); mM = sel(i == k, coop_row_mask(PAT_M, k), mM); });
+    real he[NV], hm[NV];
+    static_for<NV>([&](auto Jj) { constexpr int j = Jj;
+      const int slot = sel(i >= j, i * (i + 1) / 2 + j, j * (j + 1) / 2 + i);
+      he[j] = ME.ld(LDS_HEQ + slot); hm[j] = ME.ld(LDS_M + slot); });
+    g0 = ME.ld(PUB_G0 + i);
+    MCG_FENCE();
+    static_for<NV>([&](auto Jj) { constexpr int j = Jj;
+      const bool low = i >= j;
+      const bool nzE = sel(low, ((mE >> j) & 1u) != 0u, ((coop_row_mask(PAT_E, j) >> i) & 1u) != 0u);
+      const bool nzM = sel(low, ((mM >> j) & 1u) != 0u, ((coop_row_mask(PAT_M, j) >> i) & 1u) != 0u);
+      H0[j] = sel(nzE, he[j], 0.0) + sel(nzM, hm[j], 0.0); });
+  }
+  MCG_TICK_PIN(H0, NV);
+  COOP_TICK(ST_CO_H0);
+  real al = ME.ld(PUB_WARM + i);                    // the iterate: lane i (and 16 + i) holds a_i
+  // assembly layout: lane (ia, hb) = row ia, columns 6 hb .. 6 hb + 5 of the increment
+  const int ia = l16, hb = L >> 4, cb = 6 * hb;
+  const int iseg = l16 + ((hb == 1 && l16 >= 2) ? 6 : 0);
+  struct WinRow { real own, seg; };
+  auto load_row = [&](int t, WinRow& w) { const int o = t * C12_WSTRIDE; w.own = ws[o + 2 + i]; w.seg = ws[o + iseg]; };
+  struct AsmAcc { real Ah[6], ag; };
+  auto add_row = [&](const WinRow& w, AsmAcc& A) {
+    const real D = coop_bcast16<0>(w.seg), Da = coop_bcast16<1>(w.seg);
+    const real cD = D * w.own;
+    static_for<6>([&](auto Cc) { constexpr int c = Cc; A.Ah[c] = fma(cD, coop_bcast16<2 + c>(w.seg), A.Ah[c]); });
+    A.ag = fma(Da, w.own, A.ag);
+  };
+
+  for (int it = 0; it < 50; it++) {
+    COOP_COUNT(1, 1);
+    if (it == 8) COOP_COUNT(5, 1);
+    if (it == 49) COOP_COUNT(6, 1);
+    // (a) residuals and active set at a, H0 a on the way
+    real r0[NSETS], h0a = 0; unsigned act[NSETS];
+    _Pragma("unroll") for (int s = 0; s < NSETS; s++) r0[s] = -aref[s];
+    static_for<NV>([&](auto Jj) { constexpr int j = Jj;
+      const real aj = coop_bcast16<j>(al);
+      _Pragma("unroll") for (int s = 0; s < NSETS; s++) r0[s] = fma(J[s][j], aj, r0[s]);
+      h0a = fma(H0[j], aj, h0a); });
+    _Pragma("unroll") for (int s = 0; s < NSETS; s++) act[s] = (unsigned)__ballot(Dr[s] > 0 && r0[s] < 0);
+    MCG_TICK_PIN(r0, NSETS);
+    COOP_TICK(ST_CO_RESID);
+    COOP_COUNT(3, __popc(act[0]) + (NSETS > 1 ? __popc(act[1 % NSETS]) : 0) + (NSETS > 2 ? __popc(act[2 % NSETS]) : 0));
+    // (b) the increment sum_active D J J^T, D aref J through the LDS window
+    AsmAcc A;
+    _Pragma("unroll") for (int c = 0; c < 6; c++) A.Ah[c] = 0;
+    A.ag = 0;
+    _Pragma("unroll") for (int s = 0; s < NSETS; s++) {
+      if (act[s] != 0u) {
+        const int nact = __popc(act[s]);
+        const int pos = __popc(act[s] & ((1u << L) - 1u));
+        const bool mine = ((act[s] >> L) & 1u) != 0u;
+        for (int w0 = 0; w0 < nact; w0 += COOP_WIN) {
+          const int nw = sel(nact - w0 < COOP_WIN, nact - w0, COOP_WIN);
+          coop_lds_sync();
+          if (mine && pos >= w0 && pos < w0 + COOP_WIN) {
+            const int o = (pos - w0) * C12_WSTRIDE;
+            ws[o] = Dr[s]; ws[o + 1] = Dr[s] * aref[s];
+            _Pragma("unroll") for (int j = 0; j < NV; j++) ws[o + 2 + j] = J[s][j];
+          }
+          if ((nw & 1) && L < C12_WSTRIDE) ws[nw * C12_WSTRIDE + L] = 0.0;
+          coop_lds_sync();
+          WinRow wa, wb;
+          load_row(0, wa); load_row(1, wb);
+          for (int t = 0; t < nw; t += 2) {
+            const int tn = sel(t + 2 < nw, t + 2, t);
+            WinRow na, nb;
+            load_row(tn, na); load_row(tn + 1, nb);
+            MCG_FENCE();
+            add_row(wa, A); add_row(wb, A);
+            MCG_FENCE();
+            wa = na; wb = nb;
+          }
+        }
+      }
+    }
+    coop_lds_sync();
+    if (ia < NV) {
+      _Pragma("unroll") for (int c = 0; c < 6; c++) ws[ia * NV + cb + c] = A.Ah[c];
+      if (hb == 0) ws[NV * NV + ia] = A.ag;
+    }
+    coop_lds_sync();
+    real H[NV], g;
+    _Pragma("unroll") for (int j = 0; j < NV; j++) H[j] = ws[i * NV + j];
+    g = ws[NV * NV + i];
+    MCG_FENCE();
+    _Pragma("unroll") for (int j = 0; j < NV; j++) H[j] += H0[j];
+    g += g0;
+    MCG_TICK_PIN(H, NV);
+    COOP_TICK(ST_CO_ASM);
+    // (c) H = L D L^T, the pivot column by row_newbcast
+    real Lr[NV], dinv[NV];
+    static_for<NV>([&](auto Kk) { constexpr int k = Kk;
+      const real dk = coop_bcast16<k>(H[k]);
+      dinv[k] = rcp_nr(dk);
+      const real lk = H[k] * dinv[k];
+      static_for<NV - 1 - k>([&](auto Jj) { constexpr int j = k + 1 + Jj;
+        H[j] = fma(-lk, coop_bcast16<j>(H[k]), H[j]); });
+      Lr[k] = sel(i > k, lk, 0.0); });
+    MCG_TICK_PIN(Lr, NV);
+    COOP_TICK(ST_CO_FACTOR);
+    // (d) x = H^-1 g
+    real acc = g;
+    static_for<NV>([&](auto Kk) { constexpr int k = Kk; acc = fma(-Lr[k], coop_bcast16<k>(acc), acc); });
+    coop_lds_sync();
+    if (L < NV) { _Pragma("unroll") for (int k = 0; k < NV; k++) ws[L * NV + k] = sel(L > k, H[k], 0.0); }
+    coop_lds_sync();
+    real U[NV];
+    _Pragma("unroll") for (int j = 0; j < NV; j++) U[j] = ws[j * NV + i];
+    MCG_FENCE();
+    real rx[NSETS];
+    _Pragma("unroll") for (int s = 0; s < NSETS; s++) rx[s] = -aref[s];
+    real xl = 0;
+    static_for<NV>([&](auto Kk) { constexpr int j = NV - 1 - Kk;
+      const real xj = coop_bcast16<j>(acc) * dinv[j];
+      acc = fma(-U[j], xj, acc);
+      xl = sel(i == j, xj, xl);
+      _Pragma("unroll") for (int s = 0; s < NSETS; s++) rx[s] = fma(J[s][j], xj, rx[s]); });
+    MCG_TICK_PIN(rx, NSETS);
+    COOP_TICK(ST_CO_SOLVE);
+    bool same = true;
+    _Pragma("unroll") for (int s = 0; s < NSETS; s++) same = same && ((unsigned)__ballot(Dr[s] > 0 && rx[s] < 0) == act[s]);
+    COOP_TICK(ST_CO_CHECK);
+    if (same || it < MCG_COOP_FULL_STEPS) {
+      al = xl;
+      if (same) break;
+      continue;
+    }
+    // (e) exact line search (as in coop_solve; the smooth part's sums run over one DPP row)
+    COOP_COUNT(2, 1);
+    const real pl = xl - al;
+    real h0p = 0;
+    static_for<NV>([&](auto Jj) { constexpr int j = Jj; h0p = fma(H0[j], coop_bcast16<j>(pl), h0p); });
+    const bool own = l16 < NV;
+    const real s0 = coop_sum16(sel(own, (h0a - g0) * pl, 0.0)), quad = coop_sum16(sel(own, h0p * pl, 0.0));
+    real dr_[NSETS];
+    _Pragma("unroll") for (int s = 0; s < NSETS; s++) dr_[s] = rx[s] - r0[s];
+    auto dphi = [&](real alp, real& slope) {
+      COOP_COUNT(4, 1);
+      real f = 0, sl = 0;
+      _Pragma("unroll") for (int s = 0; s < NSETS; s++) {
+        const real rr = fma(alp, dr_[s], r0[s]);
+        const bool on = Dr[s] > 0 && rr < 0;
+        const real dd = Dr[s] * dr_[s];
+        f += sel(on, dd * rr, 0.0); sl += sel(on, dd * dr_[s], 0.0);
+      }
+      slope = quad + coop_sum32(sl);
+      return fma(alp, quad, s0) + coop_sum32(f);
+    };
+    real lo = 0, hi = 2, sl;
+    const bool beyond = dphi(hi, sl) < 0;
+    real alp = 1.0;
+    for (int b = 0; b < 8 && !beyond; b++) {
+      const real f = dphi(alp, sl);
+      const bool neg = f < 0;
+      lo = sel(neg, alp, lo); hi = sel(neg, hi, alp);
+      const real nwt = alp - f / sl;
+      const real nx = sel(nwt > lo && nwt < hi, nwt, 0.5 * (lo + hi));
+      const bool moved = fabs(nx - alp) > 1e-10 * fmax(1.0, fabs(alp));
+      alp = nx;
+      if (!moved) break;
+    }
+    const real alpha = sel(beyond, 2.0, alp);
+    al = fma(alpha, pl, al);
+    MCG_TICK_PIN(&al, 1);
+    COOP_TICK(ST_CO_LS);
+  }
+  if (L < NV) ME.st(PUB_WARM + L, al);
+  COOP_TICK(ST_CO_OUT);
+}
+
 // All four waves call this between barriers S4 and S5 with the same `mask` (bit l: lane l's environment is flagged): wave w solves
 // the flagged environments number w, w + 4, ...  Out of line: one copy of the code, its own register allocation.
 __device__ __noinline__ void coop_phase(unsigned long long model_bits, unsigned lds_base, unsigned mask, int wave) {
@@ -423,7 +693,7 @@ __device__ __noinline__ void coop_phase(unsigned long long model_bits, unsigned 
   CoopClocks CK;
 #ifdef MCG_STAGE_CLOCKS
   for (int k = 0; k < ST_CO_IDLE - ST_CO_SETUP; k++) CK.t[k] = 0;
-  for (int k = 0; k < 5; k++) CK.n[k] = 0;
+  for (int k = 0; k < 8; k++) CK.n[k] = 0;
 #endif
   // The flagged environments are handed out one at a time from a counter in LDS (solves differ by a factor of ten in their Newton
   // iteration counts: a fixed split leaves three waves waiting for the unluckiest).  The counter starts at zero: the robot wave
@@ -440,14 +710,17 @@ __device__ __noinline__ void coop_phase(unsigned long long model_bits, unsigned 
     for (unsigned q = 0; q < k; q++) mm &= mm - 1u;          // the k-th flagged lane
     const int e = __builtin_ctz(mm);
     const int ncon = __builtin_amdgcn_readfirstlane((int)lds0[XCH_NCON * PNP_LANES + e]);
-    if (10 + 6 * ncon <= 2 * PNP_LANES) coop_solve<2>(P, lds0, e, ws, ncon, CK);      // up to 9 contacts: 64 rows
-    else coop_solve<COOP_SETS>(P, lds0, e, ws, ncon, CK);
+    const int kind = __builtin_amdgcn_readfirstlane((int)lds0[XCH_FLAG * PNP_LANES + e]);
+    const bool two = 10 + 6 * ncon <= 2 * PNP_LANES;                                  // up to 9 contacts: 64 rows
+    if (kind == 1) { if (two) coop_solve12<2>(P, lds0, e, ws, ncon, CK); else coop_solve12<COOP_SETS>(P, lds0, e, ws, ncon, CK); }
+    else { if (two) coop_solve<2>(P, lds0, e, ws, ncon, CK); else coop_solve<COOP_SETS>(P, lds0, e, ws, ncon, CK); }
   }
 #ifdef MCG_STAGE_CLOCKS
   if ((threadIdx.x & 63) == 0) {
+    if (CK.n[0]) atomicAdd(&g_wg_stat[(blockIdx.x & 4095) * 4 + 1], (unsigned long long)CK.n[0]);
     for (int k = 0; k < ST_CO_IDLE - ST_CO_SETUP; k++) if (CK.t[k]) atomicAdd(&g_stage_clocks[ST_CO_SETUP + k], CK.t[k]);
-    const int slot[5] = {CN_COUPLED, CN_COUPLED_IT, CN_COUPLED_LS, CN_COOP_ROWS, CN_COOP_LSEVAL};
-    for (int k = 0; k < 5; k++) if (CK.n[k]) atomicAdd(&g_stage_clocks[ST_COUNT + slot[k]], (unsigned long long)CK.n[k]);
+    const int slot[8] = {CN_COUPLED, CN_COUPLED_IT, CN_COUPLED_LS, CN_COOP_ROWS, CN_COOP_LSEVAL, CN_COOP_LONG, CN_COOP_CAP, CN_COOP_12};
+    for (int k = 0; k < 8; k++) if (CK.n[k]) atomicAdd(&g_stage_clocks[ST_COUNT + slot[k]], (unsigned long long)CK.n[k]);
   }
 #endif
 }

@@ -19,7 +19,8 @@ constexpr int CON_STRIDE = 16;       // pos[3] n[3] t1[3] t2[3] dist D kterm typ
 constexpr int PNP_LANES = 32;        // envs per wave in the PickAndPlace kernels: twice the LDS per env; a wave costs the
                                      // same with 32 or 64 active lanes (measured), and 8192 envs then cover all 256 CUs
 constexpr int LDS_CON = LDS_SLOTS;
-constexpr int LDS_POLY = LDS_CON + MAXCON * CON_STRIDE;     // two clip polygons of 16 x 2
+constexpr int LDS_POLY = LDS_CON + MAXCON * CON_STRIDE;     // two clip polygons of 8 x 2 in the first 32 slots (a quadrilateral clipped by
+                                                            // four half-planes has at most 8 vertices); the other 32: exchange slots of the four-wave kernel
 constexpr int LDS_ROW = LDS_POLY + 64;                      // per pyramid row: r0, dr (line search)
 constexpr int LDS_ACT = LDS_ROW + MAXCON * 12;              // per contact: active-row bit mask (as a double)
 constexpr int LDS_WJ = LDS_ACT + MAXCON;                    // world axis + anchor of the 10 joints in the pads' chains
@@ -34,6 +35,8 @@ typedef LaneScratchT<PNP_LANES> PnpScratch;
 enum { PAIR_TABLE_CUBE = 0, PAIR_PADR_CUBE = 1, PAIR_PADL_CUBE = 2, PAIR_TABLE_PADR = 3, PAIR_TABLE_PADL = 4, PAIR_TABLE_LINK0 = 5,
        PAIR_FINR_CUBE = PAIR_TABLE_LINK0 + 8, PAIR_FINL_CUBE = PAIR_FINR_CUBE + 1,      // finger-link mesh - cube: bodies of pad-cube
        PAR_FIN_CUBE = 6 };                                                               // ... with their own row of contact_par
+constexpr int ALONE_MAX_LIST = 8;   // four-wave kernel: list positions the cube wave's own solve may use in a lane whose row-area column also holds
+                                    // the parked inputs of a cooperative robot-only solve (mcg_coop.hpp)
 constexpr int NCLS = 3;      // classes of cube contacts in the coupled solve: 0 table, 1 right finger body, 2 left.  (A fourth -- link6, for the
                              // gripper base against the cube -- was built and measured: 27 more accumulator registers slow the WHOLE
                              // coupled solve by 50 %, contacts or not: scripted grasp 11.4 -> 17.0 ms/step.  Not kept.)
@@ -184,13 +187,13 @@ MCG_DEV void box_box(ContactList<LS>& CL, bool live, const real* pa, const real*
   const real m11 = dot3(Rrc1, Ria1), m12 = dot3(Rrc1, Ria2), m21 = dot3(Rrc2, Ria1), m22 = dot3(Rrc2, Ria2);
   const real k1 = m11*hia1, k2 = m21*hia1, k3 = m12*hia2, k4 = m22*hia2;
   const real rect[2] = {pickv(hr, c1), pickv(hr, c2)};
-  // polygons in LDS: P at LDS_POLY + 2 v + {0,1}, T at LDS_POLY + 32 + 2 v + {0,1}
+  // polygons in LDS: P at LDS_POLY + 2 v + {0,1}, T at LDS_POLY + 16 + 2 v + {0,1}
   S.st(LDS_POLY + 0, cx - k1 - k3); S.st(LDS_POLY + 1, cy - k2 - k4);
   S.st(LDS_POLY + 2, cx - k1 + k3); S.st(LDS_POLY + 3, cy - k2 + k4);
   S.st(LDS_POLY + 4, cx + k1 + k3); S.st(LDS_POLY + 5, cy + k2 + k4);
   S.st(LDS_POLY + 6, cx + k1 - k3); S.st(LDS_POLY + 7, cy + k2 - k4);
   int np = sel(face, 4, 0);
-  int src = LDS_POLY, dst = LDS_POLY + 32;
+  int src = LDS_POLY, dst = LDS_POLY + 16;
   // Sutherland-Hodgman keeps a polygon that lies strictly inside all four limits as it is (same vertices, same order):
   // the usual case of the cube on the table needs no clipping pass at all.
   const bool inside = fabs(cx) + fabs(k1) + fabs(k3) < rect[0] && fabs(cy) + fabs(k2) + fabs(k4) < rect[1];
@@ -204,11 +207,11 @@ MCG_DEV void box_box(ContactList<LS>& CL, bool live, const real* pa, const real*
       const real Pd = S.ld(src + 2*v + dir), Po = S.ld(src + 2*v + 1 - dir);
       const real Nd = S.ld(src + 2*vn + dir), No = S.ld(src + 2*vn + 1 - dir);
       const bool inP = sgn * Pd < lim, inN = sgn * Nd < lim;
-      if (on && inP && nq < 15) { S.st(dst + 2*nq + dir, Pd); S.st(dst + 2*nq + 1 - dir, Po); }
-      nq += sel((on && inP && nq < 15), 1, 0);
+      if (on && inP && nq < 8) { S.st(dst + 2*nq + dir, Pd); S.st(dst + 2*nq + 1 - dir, Po); }
+      nq += sel((on && inP && nq < 8), 1, 0);
       const real tt = (sgn * lim - Pd) / (Nd - Pd);
-      if (on && (inP != inN) && nq < 15) { S.st(dst + 2*nq + dir, sgn * lim); S.st(dst + 2*nq + 1 - dir, Po + tt * (No - Po)); }
-      nq += (on && (inP != inN) && nq < 15) ? 1 : 0;
+      if (on && (inP != inN) && nq < 8) { S.st(dst + 2*nq + dir, sgn * lim); S.st(dst + 2*nq + 1 - dir, Po + tt * (No - Po)); }
+      nq += (on && (inP != inN) && nq < 8) ? 1 : 0;
     }
     np = nq;
     const int tswap = src; src = dst; dst = tswap;
@@ -272,6 +275,7 @@ struct CubeSys {
   real B_tc, B_pc, B_tp, B_tl, B_mc, mu_tc[3], mu_pc[3], mu_tp[3], mu_tl[3], mu_mc[3];
   bool side_on[2];                             // a contact between the cube and the right / left finger body (pad or finger-link mesh)
   bool tab_on, stat_on;                        // ... between the cube and a static geom; between a static geom and the robot alone
+  int cube_lo, cube_hi, c0 = 0;                // lowest / highest list position of a contact that involves the cube (hi -1: none); list offset of the cube-alone solve
   int ncon; bool any_pad, solved, touch[2];    // touch: this forward pass has a right / left pad-cube contact; any_pad: any pad contact
   real a_c[6];
 
@@ -316,9 +320,11 @@ struct CubeSys {
     scan_sides();
   }
   MCG_DEV void scan_sides() {
-    side_on[0] = side_on[1] = tab_on = stat_on = false;
+    side_on[0] = side_on[1] = tab_on = stat_on = false; cube_hi = -1; cube_lo = 0;
     for (int c = 0; __any(c < ncon); c++) {
       const int type = sel((c < ncon), (int)S.ld(LDS_CON + c * CON_STRIDE + 15), 0);
+      cube_lo = sel((c < ncon) && pair_has_cube(type) && cube_hi < 0, c, cube_lo);
+      cube_hi = sel((c < ncon) && pair_has_cube(type), c, cube_hi);
       side_on[0] = side_on[0] || pair_class(type) == 1; side_on[1] = side_on[1] || pair_class(type) == 2;
       tab_on = tab_on || ((c < ncon) && pair_has_cube(type) && pair_class(type) == 0); stat_on = stat_on || ((c < ncon) && !pair_has_cube(type));
     }
@@ -673,24 +679,49 @@ struct CubeSys {
   // line-search data.  When the mask is consistent -- the usual case -- x is the minimiser and B's forces are final.
   // zeros in the line-search rows and masks of the list positions this lane does not fill (see prepare()).  `skip`: the lane's column
   // of the row area is not this solve's to touch (four-wave kernel: the robot wave parks the coupled solve's inputs there).
-  MCG_DEV void clean_rows(bool skip = false) const {
+  MCG_DEV void clean_rows(bool skip = false, bool limited = false) const {
     for (int c = 0; __any(c < ncon); c++) {
-      if (c >= ncon && !skip) {
+      if (c >= ncon && !skip && !(limited && c >= ALONE_MAX_LIST)) {
         _Pragma("unroll") for (int k = 0; k < 12; k++) S.st(LDS_ROW + c * 12 + k, 0.0);
         S.st(LDS_ACT + c, 0.0);
       }
     }
   }
   // `skip`: this lane's env goes through the cooperative coupled solve instead; it walks the loops with an empty list and
-  // stores nothing (its result is discarded).
-  MCG_DEV void solve_alone(bool skip = false) {
+  // stores nothing (its result is discarded).  `limited`: the lane's column holds parked inputs above list position ALONE_MAX_LIST.
+  // A wave that holds static geom - robot contacts somewhere (rare; wave-uniform) runs the OFF = true instance: each lane's loops then
+  // cover only the stretch of its list that holds the cube's contacts, positions c0 .. c0 + ncon - 1 (the robot's entries in front of
+  // it -- arm meshes, pads on the ground -- would otherwise make the whole wave walk lists three times as long), and entries inside the
+  // stretch that are not the cube's get D = 0.  The rows and masks in LDS are indexed by the position within the stretch.
+  MCG_DEV void solve_alone(bool skip = false, bool limited = false) {
     const int ncon_all = ncon;
-    ncon = sel(skip, 0, ncon_all);
-    clean_rows(skip);
-    solve_alone_impl();
+    if (__any(stat_on && !skip)) {
+      c0 = sel(cube_hi >= 0, cube_lo, 0);
+      ncon = sel(skip || cube_hi < 0, 0, cube_hi - cube_lo + 1);
+      clean_rows(skip, limited);
+      solve_alone_impl<true>();
+    } else {
+      ncon = sel(skip, 0, ncon_all);
+      clean_rows(skip, limited);
+      solve_alone_impl<false>();
+    }
     ncon = ncon_all;
   }
-  MCG_DEV void solve_alone_impl() {
+  // D of list entry c as the cube-alone solve sees it: zero for the entries that are not the cube's (a pad or an arm mesh on the table /
+  // the ground: the robot's own, cooperative solve carries those).  filt: wave-uniform, some lane of the wave holds such an entry.
+  // list position of the stretch's c-th entry.  Past the lane's own stretch (a wave-mate's is longer) the lane re-reads its last entry --
+  // finite numbers, weighted by D = 0 -- rather than whatever lies behind the list (prepare() pads with zeros only up to the wave's
+  // longest LIST, and 0 x garbage is not 0)
+  template <bool OFF> MCG_DEV int li(int c) const {
+    if constexpr (OFF) { const int k = c0 + sel(c < ncon, c, ncon - 1); return sel(k > 0, k, 0); } else return c;
+  }
+  template <bool OFF> MCG_DEV real alone_D(int c) const {
+    const int b = LDS_CON + li<OFF>(c) * CON_STRIDE;
+    bool keep = c < ncon;
+    if constexpr (OFF) keep = keep && pair_has_cube((int)S.ld(b + 15));
+    return sel(keep, S.ld(b + 13), 0.0);
+  }
+  template <bool OFF> MCG_DEV void solve_alone_impl() {
     derive(model());
     const real Bc = B_tc; const real mu[3] = {mu_tc[0], mu_tc[1], mu_tc[2]};
     real a[6];
@@ -703,14 +734,17 @@ struct CubeSys {
     };
     bool conv = false;
     for (int it = 0; it < 50; it++) {
-      MCG_COUNT(CN_CUBE_IT);
+      MCG_COUNTW(CN_CUBE_IT, 1);
+#ifdef MCG_STAGE_CLOCKS
+      if ((threadIdx.x & 63) == 0) atomicAdd(&g_wg_stat[(blockIdx.x & 4095) * 4 + 2], 1ull);
+#endif
       real H[21], g[6];
       _Pragma("unroll") for (int k = 0; k < 21; k++) H[k] = 0;
       _Pragma("unroll") for (int k = 0; k < 6; k++) { H[tri(k, k)] = Md[k]; g[k] = fs[k]; }
       for (int c = 0; __any(c < ncon); c++) {                    // pass A: mask (first iteration) + assembly
-        CubeRows R; rows_cube(c, R);
-        const int b = LDS_CON + c * CON_STRIDE;
-        const real D = sel((c < ncon), S.ld(b + 13), 0.0), kterm = S.ld(b + 14);
+        CubeRows R; rows_cube(li<OFF>(c), R);
+        const int b = LDS_CON + li<OFF>(c) * CON_STRIDE;
+        const real D = alone_D<OFF>(c), kterm = S.ld(b + 14);
         const int mask = (int)S.ld(LDS_ACT + c);
         real dv[4], da[4]; dots(R, Cb.vel, dv); dots(R, a, da);
         real W00 = 0, t0 = 0, W0[3], Wd[3], t[3];
@@ -745,9 +779,10 @@ struct CubeSys {
       real p[6]; _Pragma("unroll") for (int k = 0; k < 6; k++) p[k] = x[k] - a[k];
       bool same = true;
       for (int c = 0; __any(c < ncon); c++) {                    // pass B: consistency at x, line-search data
-        CubeRows R; rows_cube(c, R);
-        const int b = LDS_CON + c * CON_STRIDE;
-        const real D = sel((c < ncon), S.ld(b + 13), 0.0), kterm = S.ld(b + 14);
+        CubeRows R; rows_cube(li<OFF>(c), R);
+        const int b = LDS_CON + li<OFF>(c) * CON_STRIDE;
+        const real D = alone_D<OFF>(c), kterm = S.ld(b + 14);
+        const bool mine = D != 0.0;                               // (an entry of this lane's list that is the cube's)
         const int mask = (int)S.ld(LDS_ACT + c);
         real dv[4], da[4], dp[4]; dots(R, Cb.vel, dv); dots(R, a, da); dots(R, p, dp);
         static_for<3>([&](auto Kk) {
@@ -756,9 +791,9 @@ struct CubeSys {
             constexpr int odd = Od; constexpr int r = 2 * k + odd;
             const real m = odd ? -mu[k] : mu[k];
             const real r0 = fma(m, da[1 + k], da[0]) - (-Bc * fma(m, dv[1 + k], dv[0]) - kterm), jp = fma(m, dp[1 + k], dp[0]);
-            if (c < ncon) { S.st(LDS_ROW + (c * 6 + r) * 2, r0); S.st(LDS_ROW + (c * 6 + r) * 2 + 1, jp); }
+            if (mine) { S.st(LDS_ROW + (c * 6 + r) * 2, r0); S.st(LDS_ROW + (c * 6 + r) * 2 + 1, jp); }
             const real rx = r0 + jp;
-            same = same && (c >= ncon || (rx < 0) == (((mask >> r) & 1) != 0));
+            same = same && (!mine || (rx < 0) == (((mask >> r) & 1) != 0));
           });
         });
       }
@@ -770,8 +805,11 @@ struct CubeSys {
       // final full step, so bisection of phi' on [0, 2] is enough (the oracle walks the breakpoints exactly).
       real lin0 = 0, quad = 0;
       _Pragma("unroll") for (int k = 0; k < 6; k++) { const real as = fs[k] / Md[k]; lin0 += Md[k] * (a[k] - as) * p[k]; quad += Md[k] * p[k] * p[k]; }
-      MCG_COUNT(CN_CUBE_LS);
-      const real alpha = bisect(lin0, quad);
+      MCG_COUNTW(CN_CUBE_LS, 1);
+#ifdef MCG_STAGE_CLOCKS
+      if ((threadIdx.x & 63) == 0) atomicAdd(&g_wg_stat[(blockIdx.x & 4095) * 4 + 3], 1ull);
+#endif
+      const real alpha = bisect<OFF>(lin0, quad, conv);
       _Pragma("unroll") for (int k = 0; k < 6; k++) a[k] = sel(conv, a[k], a[k] + alpha * p[k]);
       remask(alpha, conv);
     }
@@ -790,27 +828,35 @@ struct CubeSys {
       }
     }
   }
-  MCG_DEV real dphi_rows(real al) const {
-    real s = 0;
+  template <bool OFF> MCG_DEV void dphi_rows_alone(real al, real& s, real& slope) const {     // the rows' part of phi' and phi''
     for (int c = 0; __any(c < ncon); c++) {
-      const real D = sel((c < ncon), S.ld(LDS_CON + c * CON_STRIDE + 13), 0.0);
+      const real D = alone_D<OFF>(c);
       _Pragma("unroll") for (int r = 0; r < 6; r++) {
         const real r0 = S.ld(LDS_ROW + (c * 6 + r) * 2), dr_ = S.ld(LDS_ROW + (c * 6 + r) * 2 + 1);
         const real rr = r0 + al * dr_;
-        s += sel((rr < 0), D * rr * dr_, 0.0);
+        s += sel((rr < 0), D * rr * dr_, 0.0); slope += sel((rr < 0), D * dr_ * dr_, 0.0);
       }
     }
-    return s;
   }
-  MCG_DEV real bisect(real lin0, real quad) const {
-    real lo = 0, hi = 2;
-    const bool beyond = lin0 + 2 * quad + dphi_rows(2.0) < 0;
-    for (int b = 0; b < 24; b++) {
-      const real mid = 0.5 * (lo + hi);
-      const bool neg = lin0 + mid * quad + dphi_rows(mid) < 0;
-      lo = sel(neg, mid, lo); hi = sel(neg, hi, mid);
+  // Exact line search of the cube-alone solve: phi' is piecewise linear and increasing, so Newton on it (bracketed, bisection as the
+  // fallback) lands on the root once it is on the root's own piece -- 3 to 6 evaluations where the 24-step bisection of round 2 made
+  // 25 (a tumbling cube then held up its whole wave for ~25 us per sub-step).  `done`: lanes that do not search (wave-uniform exit).
+  template <bool OFF> MCG_DEV real bisect(real lin0, real quad, bool done) const {
+    auto dphi = [&](real al, real& slope) { real sacc = lin0 + al * quad; slope = quad; dphi_rows_alone<OFF>(al, sacc, slope); return sacc; };
+    real lo = 0, hi = 2, sl;
+    const bool beyond = dphi(hi, sl) < 0;
+    real al = 1.0;
+    for (int b = 0; b < 12; b++) {
+      const real f = dphi(al, sl);
+      const bool neg = f < 0;
+      lo = sel(neg, al, lo); hi = sel(neg, hi, al);
+      const real nw = al - f / sl;
+      const real nx = sel(nw > lo && nw < hi, nw, 0.5 * (lo + hi));
+      const bool moved = fabs(nx - al) > 1e-12 * fmax(1.0, fabs(al));
+      al = nx;
+      if (!__any(moved && !done && !beyond)) break;
     }
-    return beyond ? 2.0 : 0.5 * (lo + hi);
+    return beyond ? 2.0 : al;
   }
   MCG_DEV void remask(real alpha, bool conv) const {
     for (int c = 0; __any(c < ncon); c++) {

@@ -31,6 +31,7 @@ int fail(int code, const char* fmt, const char* a = "") { snprintf(g_err, sizeof
 struct Cfg {
   int n, has_object, controller, fetch, reward_type, frame_skip, control_steps, max_episode_steps;
   int target_in_the_air, auto_reset, nq, nv, obs_dim, act_dim, dr_enable, block_gripper;
+  int coop12;            // PickAndPlace: environments whose robot touches only static geoms get the 12-dof cooperative solve (MCG_COOP12=1; default: all 18-dof)
   int hidden;            // Reach with reward_shaping: the cube stays in the physics as a hidden free body (mycobot.py:475-481)
   double dr_mass[2], dr_fric[2], qpos0_cube[7];
   double distance_threshold, height_offset, igx[3], dt, grip_center, grip_range;
@@ -488,7 +489,7 @@ struct PubHook {
     const bool flag = S.ld(XCH_FLAG) != 0.0;                         // the cube wave wrote it before S2
     if (__any(flag)) {                                               // wave-uniform
       if (flag) {                                                    // plain LDS stores of live registers
-        static_for<NB>([&](auto I) { constexpr int k = I; S.st(PUB_G0 + k, g0[k]); S.st(PUB_WARM + k, warm[k]); S.st(PUB_QD + k, qd[k]); });
+        static_for<NB>([&](auto I) { constexpr int k = I; S.st(PUB_G0 + k, g0[k]); S.st(PUB_WARM + k, warm[k]); });      // (qd(t) is in its exchange slots)
         static_for<10>([&](auto I) { constexpr int j = I; S.st(PUB_SD + j, sgl[j] * Dl[j]); S.st(PUB_AREF + j, arefl[j]); });
       }
     }
@@ -508,7 +509,7 @@ MCG_DEV void cube_from_lds(const PnpScratch MS, Cube& Cb) {
 MCG_DEV unsigned flagged_lanes(const PnpScratch MS) { return (unsigned)__ballot(MS.ld(XCH_FLAG) != 0.0); }      // the same in all four waves
 
 // the cube wave's whole env-step
-MCG_DEV void cube_wave(const View& V, ModelPtr P, const PnpScratch MS, unsigned lds0, int i, int total) {
+MCG_DEV void cube_wave(const View& V, ModelPtr P, const PnpScratch MS, unsigned lds0, int i, int total, bool robot_only_ok) {
   Cube Cb; real dr[2], qlag7[7];
   for (int k = 0; k < 3; k++) Cb.pos[k] = V.qpos(12 + k, i);
   for (int k = 0; k < 4; k++) Cb.quat[k] = V.qpos(15 + k, i);
@@ -526,18 +527,19 @@ MCG_DEV void cube_wave(const View& V, ModelPtr P, const PnpScratch MS, unsigned 
     CS.prepare(P, q10);
     touch = CS.touch[0] && CS.touch[1];
     MCG_TICK2(ST_W2_COLLIDE);
-    const bool flag = CS.any_pad;                                   // a contact of this lane's environment reaches the robot
-    const bool coupled = __any(flag);                               // wave-uniform
-    MS.st(XCH_FLAG, flag ? 1.0 : 0.0);
+    // 0: nothing reaches the robot | 1: only static geoms do (robot and cube decouple: the cube stays here, the robot's 12 dofs go to the
+    // cooperative solve) | 2: the cube touches the robot (one coupled problem) -- or its contacts sit too high in the list to leave the
+    // parked inputs alone
+    const int kind = CS.any_pad ? ((CS.side_on[0] || CS.side_on[1] || CS.cube_hi - CS.cube_lo >= ALONE_MAX_LIST || !robot_only_ok) ? 2 : 1) : 0;
+    const bool coupled = __any(kind != 0), coupled2 = __any(kind == 2);      // wave-uniform
+    MS.st(XCH_FLAG, (real)kind);
     if (coupled) {
-      if (flag) {                                                   // hand the (normalised, not advanced) cube over
-        cube_to_lds(MS, CS.Cb);
-        MS.st(XCH_NCON, (real)CS.ncon); MS.st(XCH_DR, dr[0]); MS.st(XCH_DR + 1, dr[1]);
-      }
+      if (kind != 0) { MS.st(XCH_NCON, (real)CS.ncon); MS.st(XCH_DR, dr[0]); MS.st(XCH_DR + 1, dr[1]); }
+      if (kind == 2) cube_to_lds(MS, CS.Cb);                        // hand the (normalised, not advanced) cube over
     }
     __syncthreads();                                                // S2 (the robot side's "M and bias ready")
-    CS.solve_alone(flag);                                           // flagged lanes walk an empty list, store nothing
-    if (!coupled) { CS.finish(qlag7); Cb = CS.Cb; }
+    CS.solve_alone(kind == 2, kind == 1);                           // flag-2 lanes walk an empty list, store nothing
+    if (!coupled2) { CS.finish(qlag7); Cb = CS.Cb; }
     MCG_TICK2(ST_W2_CUBE);
     __syncthreads();                                                // S4: end of the lane-parallel part
     MCG_TICK2(ST_W2_WAIT2);
@@ -546,8 +548,10 @@ MCG_DEV void cube_wave(const View& V, ModelPtr P, const PnpScratch MS, unsigned 
       MCG_TICK2(ST_COUPLED);
       __syncthreads();                                              // S5
       MCG_TICK2(ST_CO_IDLE);
-      _Pragma("unroll") for (int k = 0; k < 6; k++) CS.a_c[k] = sel(flag, MS.ld(XCH_CB + 13 + k), CS.a_c[k]);
-      CS.finish(qlag7); Cb = CS.Cb;
+      if (coupled2) {
+        _Pragma("unroll") for (int k = 0; k < 6; k++) CS.a_c[k] = sel(kind == 2, MS.ld(XCH_CB + 13 + k), CS.a_c[k]);
+        CS.finish(qlag7); Cb = CS.Cb;
+      }
     }
   }
   cube_to_lds(MS, Cb);
@@ -618,12 +622,15 @@ __global__ __launch_bounds__(DUAL ? 256 : PNP_LANES) void step_pnp_kernel(Cfg C,
   if constexpr (DUAL) {
     if (threadIdx.x >= 64) {
       const int total = (CONTROLLER == MCG_CTRL_IK ? C.control_steps : 1) * C.frame_skip;
-      if (threadIdx.x < 128) cube_wave(V, P, MS, lds0, i, total);
+      if (threadIdx.x < 128) cube_wave(V, P, MS, lds0, i, total, C.coop12 != 0);
       else pnp_side_wave(P, MS, lds0, total, threadIdx.x >= 192);
       return;
     }
   }
   MCG_TICK_INIT();
+#ifdef MCG_STAGE_CLOCKS
+  const unsigned long long wg_t0 = __builtin_readcyclecounter();
+#endif
   EnvP E;
   load_envp(V, i, E);
   if constexpr (DUAL) static_for<NB>([&](auto I) { constexpr int k = I; MS.st(XCH_Q + k, E.R.q[k]); MS.st(XCH_QD + k, E.R.qd[k]); });   // q(0), qd(0) for the other waves
@@ -740,6 +747,9 @@ __global__ __launch_bounds__(DUAL ? 256 : PNP_LANES) void step_pnp_kernel(Cfg C,
   write_obs(O, i, D, obs, ag, E.goal);
   store_envp(V, i_tail, E);
   MCG_TICK(ST_POST);
+#ifdef MCG_STAGE_CLOCKS
+  if (threadIdx.x == 0) g_wg_stat[(blockIdx.x & 4095) * 4] += __builtin_readcyclecounter() - wg_t0;
+#endif
   MCG_TICK_FLUSH();
 }
 
@@ -868,6 +878,11 @@ int mcg_create(const mcg_config* c, const mcg_model* model, int device, mcg_env*
     e->num_cu = (hipGetDeviceProperties(&prop, device) == hipSuccess) ? prop.multiProcessorCount : 256;
     const char* ns = getenv("MCG_NO_SPLIT");
     e->no_split = ns && ns[0] == '1';
+    // Opt-in (measured): an environment whose robot touches only static geoms gets a 12-dof cooperative solve and its
+    // cube stays with the cube wave.  The solve is half the price, but the cube wave then walks those lanes' longer lists in its own
+    // lane-parallel solve: no net gain at 8192 environments under a random policy (PickAndPlace-IK 11.7 against 11.3 ms per step).
+    const char* c12 = getenv("MCG_COOP12");
+    C.coop12 = (c12 && c12[0] == '1');
   }
   e->view.n = C.n; e->view.nq = C.nq; e->view.nv = C.nv;
   size_t nd = (size_t)state_doubles(C.nq, C.nv) * C.n;
@@ -901,6 +916,12 @@ void mcg_destroy(mcg_env* e) {
 
 #ifdef MCG_STAGE_CLOCKS
 // development builds only (tools/stage_clocks.py): read and optionally clear the per-stage shader-clock totals
+extern "C" int mcg_debug_wg_stat(unsigned long long* out, int n, int clear) {
+  if (hipDeviceSynchronize() != hipSuccess) return MCG_ERR_HIP;
+  if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(mcg::g_wg_stat), sizeof(unsigned long long) * n) != hipSuccess) return MCG_ERR_HIP;
+  if (clear) { static unsigned long long z[4096 * 4]; if (hipMemcpyToSymbol(HIP_SYMBOL(mcg::g_wg_stat), z, sizeof(z)) != hipSuccess) return MCG_ERR_HIP; }
+  return MCG_OK;
+}
 extern "C" int mcg_debug_stage_clocks(unsigned long long* out, int clear) {
   if (hipDeviceSynchronize() != hipSuccess) return MCG_ERR_HIP;
   if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(mcg::g_stage_clocks), sizeof(unsigned long long) * (mcg::ST_COUNT + mcg::CN_COUNT)) != hipSuccess) return MCG_ERR_HIP;
