@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MCG_ABI_VERSION 6
+#define MCG_ABI_VERSION 7
 
 enum { MCG_OK = 0, MCG_ERR_ARG = 1, MCG_ERR_HIP = 2, MCG_ERR_UNSUPPORTED = 3 };
 enum { MCG_CTRL_JOINT = 0, MCG_CTRL_IK = 1, MCG_CTRL_MOCAP = 2 };   /* controller_type "joint" | "IK" | "mocap" */
@@ -97,6 +97,10 @@ typedef struct mcg_model {
   double weld_anchor[3];            /* weld point on the robot, link6 frame */
   double weld_relpos[3], weld_relquat[4], weld_torquescale;
   double target0[3];                /* MJCF position of site `target0`: what stage_rewards reads unless rendering (mycobot.py:422, 309-311) */
+  double contact_rpy;               /* regulariser of a contact's pyramid rows, Rpy = contact_rpy * mu^2 * R(normal row).  2 = the rule as
+                                       recalled from MuJoCo (built-in models); 4 = the one single change that reproduces the cube's rest
+                                       height in the reference's keyframes (penetration 1.9e-5, mycobot280.xml:6; oracle/RULE_STUDY.md K1):
+                                       specialize(..., contact_rule="keyframe") / MyCobotVecEnv(contact_rule="keyframe") */
 } mcg_model;
 
 typedef struct mcg_config {
@@ -154,6 +158,15 @@ typedef struct mcg_state {
   int32_t* ep_length;/* [N]       running length of the episode in flight (Monitor's "l") */
 } mcg_state;
 
+/* Event counters since mcg_create (or the last clearing read).  The first two are this engine's own bounds on things the reference
+   leaves unbounded; none of them is expected to move in ordinary use. */
+typedef struct mcg_counters {
+  uint64_t reset_cap_hits;          /* a rejection loop of reset_model (mycobot.py:218-219, 232-233: unbounded `while`) gave up after 1000 draws */
+  uint64_t bad_state_resets;        /* mj_checkPos / mj_checkVel / mj_checkAcc fired: a body's state was reset (per body, per event) */
+  uint64_t contacts_dropped;        /* contacts cut off by the build's cap of 12 contacts per environment (MuJoCo has no such cap) */
+  uint64_t coupled_env_substeps;    /* environment-sub-steps routed through the cooperative robot + cube solve (a contact reached the robot) */
+} mcg_counters;
+
 typedef struct mcg_env mcg_env;
 
 int mcg_abi_version(void);
@@ -178,6 +191,15 @@ uint64_t mcg_get_seed(const mcg_env* env);
 int mcg_set_seed(mcg_env* env, uint64_t seed);
 int mcg_compute_reward(const double* achieved /* [n,3] device */, const double* desired, int n, int reward_type,
                        double threshold, double* out, void* stream);
+
+/* Synchronises the device; copies the counters to host memory `out`; clears them when `clear` != 0. */
+int mcg_get_counters(mcg_env* env, mcg_counters* out, int clear);
+
+/* TEST / DEBUG: the collision pass (mj_collision restated, P4) of PickAndPlace on the CURRENT state, exported as the kernels see it.
+   All device pointers.  count [N]: list entries; dropped [N]: contacts cut by the cap (or NULL); data [N, 12, 10]: per entry dist,
+   pos[3] (midpoint between the surfaces), normal[3] (geom1 -> geom2), pair type (csrc/mcg_cube.hpp PAIR_*), multiplicity (identical
+   geoms the entry stands for), D (weight of its pyramid rows). */
+int mcg_debug_contacts(mcg_env* env, int32_t* count, int32_t* dropped, double* data, void* stream);
 
 /* Live timing of the step kernel on its own stream with HIP events (used by bench.py's roofline leg). */
 int mcg_time_steps(mcg_env* env, const float* actions, const mcg_step_out* out, int steps, void* stream, float* ms_total);

@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("MCG_LIB") or os.path.join(_HERE, "libmycobot_hip.so")
 
 MCG_OK, MCG_ERR_ARG, MCG_ERR_HIP, MCG_ERR_UNSUPPORTED = 0, 1, 2, 3
 CTRL_JOINT, CTRL_IK, CTRL_MOCAP = 0, 1, 2
-ABI_VERSION = 6
+ABI_VERSION = 7
 REWARD_SPARSE, REWARD_DENSE, REWARD_SHAPING = 0, 1, 2
 
 d = C.c_double
@@ -49,6 +49,7 @@ class McgModel(C.Structure):
         ("base_quat", d * 4), ("weld_on", d), ("weld_par", d * 10), ("weld_diag", d * 2), ("weld_anchor", d * 3),
         ("weld_relpos", d * 3), ("weld_relquat", d * 4), ("weld_torquescale", d),
         ("target0", d * 3),
+        ("contact_rpy", d),
     ]
 
     @classmethod
@@ -80,6 +81,10 @@ class McgConfig(C.Structure):
     ]
 
 
+class McgCounters(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("reset_cap_hits", "bad_state_resets", "contacts_dropped", "coupled_env_substeps")]
+
+
 class McgStepOut(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in (
         "obs", "achieved_goal", "desired_goal", "reward", "terminated", "truncated", "is_success",
@@ -93,7 +98,7 @@ class McgState(C.Structure):
 
 EXPORTS = ("mcg_abi_version", "mcg_last_error", "mcg_default_model", "mcg_create", "mcg_destroy", "mcg_obs_dim",
            "mcg_action_dim", "mcg_nq", "mcg_nv", "mcg_reset", "mcg_step", "mcg_get_state", "mcg_set_state",
-           "mcg_compute_reward", "mcg_time_steps", "mcg_get_seed", "mcg_set_seed")
+           "mcg_compute_reward", "mcg_time_steps", "mcg_get_seed", "mcg_set_seed", "mcg_get_counters", "mcg_debug_contacts")
 
 _lib = None
 
@@ -127,6 +132,9 @@ def load():
     if hasattr(L, "mcg_get_seed"):        # absent only from pre-v3 builds selected through MCG_LIB for A/B timing
         L.mcg_get_seed.argtypes = [C.c_void_p]; L.mcg_get_seed.restype = C.c_uint64
         L.mcg_set_seed.argtypes = [C.c_void_p, C.c_uint64]
+    if hasattr(L, "mcg_get_counters"):    # absent only from older builds selected through MCG_LIB for A/B timing
+        L.mcg_get_counters.argtypes = [C.c_void_p, C.POINTER(McgCounters), C.c_int]
+        L.mcg_debug_contacts.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.mcg_time_steps.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(McgStepOut), C.c_int, C.c_void_p, C.POINTER(C.c_float)]
     _lib = L
     return L

@@ -40,7 +40,10 @@ static_assert(XCH_DR + 2 <= LDS_POLY + 32, "exchange area exceeds the clip-polyg
 // S1 by the M, RNE and cube waves and between S4 and S5 by the cooperative solves -- and the workgroup's hand-out counter of that phase
 // (an unsigned in the first word of lane 0's slot).
 constexpr int XCH_Q = LDS_POLY + 32, XCH_QD = XCH_Q + NB, COOP_CTR_SLOT = XCH_QD + NB;
-static_assert(COOP_CTR_SLOT + 1 <= LDS_POLY + 64, "exchange area");
+// XCH_T1 (robot wave -> cube wave, read after S1) / XCH_BADC (cube wave -> robot wave, read after S4): the other body failed mj_checkPos /
+// mj_checkVel, mj_resetData resets both
+constexpr int XCH_BADC = COOP_CTR_SLOT + 1;
+static_assert(XCH_BADC + 1 <= LDS_POLY + 64, "exchange area");
 // Line-search row area (LDS_ROW .. LDS_ROW + 144 slot rows of PNP_LANES doubles):
 //   [0, 96)    the cube wave's own solves (12 slots per contact, list positions 0..7: a lane whose cube contacts sit higher is flagged 2);
 //              between barriers S4 and S5, when every lane-parallel solve is over: cooperative workspace, 768 doubles per wave

@@ -66,6 +66,7 @@ template <class LS>
 struct ContactList {
   const LS S;
   int n;              // entries stored
+  int ndrop = 0;      // contacts the cap of MAXCON cut off (as the oracle counts them)
   int ncap = 0;       // contacts as the oracle (and MuJoCo) counts them: `mult` identical colliding geoms give `mult` identical contacts,
                       // stored here as ONE entry whose rows carry `mult` times the weight (the same cost function); the cap of MAXCON
                       // contacts cuts the list where the oracle's cuts it
@@ -80,6 +81,7 @@ struct ContactList {
       S.st(b + 12, dist); S.st(b + 13, (real)take); S.st(b + 15, (real)type);       // slot 13: multiplicity until prepare() turns it into D
     }
     n += sel(ok, 1, 0); ncap += sel(ok, take, 0);
+    ndrop += sel(dist < 0, mult - sel(take > 0, take, 0), 0);
   }
 };
 
@@ -270,11 +272,13 @@ struct CubeSys {
   const LS S; Cube Cb; real dr[2];             // by value: a reference into the env struct pins that struct in memory
                                                // (the model pointer is passed in: it must stay a scalar register)
   unsigned long long pm_bits;                  // the model pointer's bits, for stages reached through the robot's hook
+  unsigned long long* cnt = nullptr;           // mcg_counters on the device (slot 2: contacts dropped by the cap), or null
   MCG_DEV CubeSys(const LS s_, const Cube& c, const real* d) : S(s_), Cb(c), pm_bits(0) { dr[0] = d[0]; dr[1] = d[1]; }
   real h, Rc[9], Md[6], damp[6], fs[6];
   real B_tc, B_pc, B_tp, B_tl, B_mc, mu_tc[3], mu_pc[3], mu_tp[3], mu_tl[3], mu_mc[3];
   bool side_on[2];                             // a contact between the cube and the right / left finger body (pad or finger-link mesh)
   bool tab_on, stat_on;                        // ... between the cube and a static geom; between a static geom and the robot alone
+  int ndropped = 0;                            // contacts of this pass that the cap cut off
   int cube_lo, cube_hi, c0 = 0;                // lowest / highest list position of a contact that involves the cube (hi -1: none); list offset of the cube-alone solve
   int ncon; bool any_pad, solved, touch[2];    // touch: this forward pass has a right / left pad-cube contact; any_pad: any pad contact
   real a_c[6];
@@ -593,7 +597,8 @@ struct CubeSys {
       mesh_cube(0, Rs[0], pf[0], PAIR_FINR_CUBE);
       mesh_cube(1, Rs[1], pf[1], PAIR_FINL_CUBE);
     }
-    ncon = CL.n;
+    ncon = CL.n; ndropped = CL.ndrop;
+    if (__any(CL.ndrop > 0)) { if (CL.ndrop > 0 && cnt) atomicAdd(cnt + 2, (unsigned long long)CL.ndrop); }      // MAXCON cut the list (MuJoCo has no such cap)
     scan_sides();
 #ifdef MCG_STAGE_CLOCKS
     { int mx = 0; for (int c = 0; __any(c < ncon); c++) mx = c + 1; if ((threadIdx.x & 63) == 0) atomicAdd(&g_stage_clocks[ST_COUNT + CN_CONTACTS], (unsigned long long)mx); }   // wave-max contacts
@@ -641,7 +646,7 @@ struct CubeSys {
         }
       }
       const real Rn = fmax(MINVAL, (1 - imp) * tran * (1 + m0*m0) / imp);
-      const real Rpy = fmax(MINVAL, 2 * m0*m0 * Rn);
+      const real Rpy = fmax(MINVAL, Q->contact_rpy * m0*m0 * Rn);      // 2 mu^2 R [RECALL]; 4 mu^2 R under contact_rule = "keyframe" (include/mcg.h)
       if (c < ncon) { S.st(b + 13, mult / Rpy); S.st(b + 14, kk * imp * dist); }
     }
 #ifdef MCG_DBG_PRINT
@@ -654,6 +659,12 @@ struct CubeSys {
 #endif
   }
 
+  // identical geoms list entry c stands for (debug export): the mesh pairs carry the model's multiplicity unless the cap cut it
+  MCG_DEV real mult_of(int c) const {
+    ModelPtr Q = model();
+    const int type = (int)S.ld(LDS_CON + c * CON_STRIDE + 15);
+    return (type >= PAIR_FINR_CUBE) ? Q->fin_par[0] : ((type >= PAIR_TABLE_LINK0) ? Q->link_mult : 1.0);
+  }
   // rows of contact c in the cube's dofs / in the robot's dofs of the pad's side
   MCG_DEV void rows_cube(int c, CubeRows& R) const { cube_rows(S, c, Rc, Cb.pos, R); }
   MCG_DEV void rows_pad(int c, int side, PadRows& P) const {

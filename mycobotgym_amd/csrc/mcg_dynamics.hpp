@@ -618,8 +618,12 @@ struct SplitMain { static constexpr bool enabled = true, rne_remote = true, fact
 
 // COMMIT = false: the new q / qd / qacc_warmstart go to *next and S stays as it was (speculative sub-step of the two-wave
 // PickAndPlace kernel: discarded when the helper wave's collision pass finds a pad contact).
+// mj_checkPos / mj_checkVel / mj_checkAcc [RECALL]: a coordinate that is not finite or beyond 1e10 makes mj_step call mj_resetData
+MCG_DEV bool bad_value(real x) { return !(fabs(x) <= 1e10); }
+
+// Returns true in the lanes whose new state failed MuJoCo's checks and was reset (COMMIT only; the speculative caller checks *next).
 template <class LS, class CPL = NoCoupling, class WLD = NoWeld, class SPL = NoSplit, bool COMMIT = true>
-MCG_DEV void robot_substep(ModelPtr Pm, Robot& S, real* qlag6, const LS MS, CPL* CP = nullptr, const WLD* WD = nullptr,
+MCG_DEV bool robot_substep(ModelPtr Pm, Robot& S, real* qlag6, const LS MS, CPL* CP = nullptr, const WLD* WD = nullptr,
                            Robot* next = nullptr) {
   MCG_COUNT(CN_SUBSTEP);
   if constexpr (SPL::enabled) __syncthreads();                     // S1
@@ -1049,16 +1053,31 @@ MCG_DEV void robot_substep(ModelPtr Pm, Robot& S, real* qlag6, const LS MS, CPL*
   MCG_TICK(ST_E_RHS);
   euler_accel(Pm, h, MS, a, rhs);
   }
+  real qn[NB], qdn[NB];
+  bool bad = false;
   static_for<NB>([&](auto I) { constexpr int i = I;
     real q_old, qd_old;
     if constexpr (SPL::warm_lds && !CPL::enabled) { q_old = MS.ld(SPL::QB + i); qd_old = MS.ld(SPL::QDB + i); if constexpr (i < 6) MS.st(SPL::QLAG + i, q_old); }
     else { q_old = S.q[i]; qd_old = S.qd[i]; }
-    const real qd_new = fma(h, rhs[i], qd_old), q_new = fma(h, qd_new, q_old);
+    qdn[i] = fma(h, rhs[i], qd_old); qn[i] = fma(h, qdn[i], q_old);
+    if constexpr (COMMIT) bad = bad || bad_value(qn[i]) || bad_value(qdn[i]) || bad_value(a[i]); });
+  // mj_step checks qpos / qvel when it starts and qacc after mj_forward, and calls mj_resetData (qpos0, zero velocity, controls and
+  // warm start) on a bad value [RECALL]: the new state is checked here, at the end of the sub-step that produced it -- the same
+  // state the next mj_step would check first.  (Round 2 checked once per env-step.)
+  if constexpr (COMMIT) {
+    if (__any(bad)) {                                       // wave-uniform; rare
+      static_for<NB>([&](auto I) { constexpr int i = I; qn[i] = sel(bad, 0.0, qn[i]); qdn[i] = sel(bad, 0.0, qdn[i]); a[i] = sel(bad, 0.0, a[i]); });
+      static_for<7>([&](auto I) { constexpr int k = I; S.ctrl[k] = sel(bad, 0.0, S.ctrl[k]); });
+    }
+  }
+  static_for<NB>([&](auto I) { constexpr int i = I;
+    const real qd_new = qdn[i], q_new = qn[i];
     if constexpr (COMMIT) { S.qd[i] = qd_new; S.q[i] = q_new; if constexpr (SPL::warm_lds && !CPL::enabled) MS.st(SPL::WARM + i, a[i]); else S.warm[i] = a[i]; }
     else { next->qd[i] = qd_new; next->q[i] = q_new; next->warm[i] = a[i]; }
     if constexpr (SPL::enabled && COMMIT) { MS.st(SPL::QB + i, q_new); MS.st(SPL::QDB + i, qd_new); } });
   MCG_TICK_PIN(S.q, NB); MCG_TICK_PIN(S.qd, NB);
   MCG_TICK(ST_EULER);
+  return bad;
 }
 
 // The helper wave's share of one sub-step (see SplitMain).

@@ -38,6 +38,7 @@ struct Cfg {
   double init_qpos[19], init_qvel[18], init_ctrl[7];
   unsigned long long seed;
   long long env_id_offset;
+  unsigned long long* cnt;   // device: mcg_counters (reset-cap hits, bad-state resets, contacts dropped by the cap, flagged env-sub-steps)
 };
 
 struct View {           // SoA state: field f of env i at d[f * n + i]
@@ -61,6 +62,11 @@ struct Env {            // one lane's working set
   real qlag6[6], goal[3], epret;
   int32_t elapsed, episode, eplen;
 };
+
+// mcg_counters: one atomic per event, behind a wave-uniform guard (events are rare)
+MCG_DEV void count_event(const Cfg& C, int slot, bool ev) {
+  if (__any(ev)) { if (ev && C.cnt) atomicAdd(C.cnt + slot, 1ull); }
+}
 
 // ------------------------------------------------------------------------------------------------- sampling
 MCG_DEV void rng_pair(const Cfg& C, int i, int32_t episode, uint32_t draw, uint32_t stream, real& u0, real& u1) {
@@ -92,7 +98,7 @@ MCG_DEV void reset_env(const Cfg& C, int i, Env& E, bool doit) {
   const real ox = C.igx[0], oy = C.igx[1];
   real goal[3] = {0, 0, 0};
   uint32_t draw = 0;
-  bool need = doit;
+  bool need = doit, capped = false;
   int tries = 0;
   do {
     real g[3];
@@ -100,9 +106,11 @@ MCG_DEV void reset_env(const Cfg& C, int i, Env& E, bool doit) {
     const bool rej = sqrt((g[0] - ox) * (g[0] - ox) + (g[1] - oy) * (g[1] - oy)) < 0.1;
     for (int k = 0; k < 3; k++) goal[k] = sel(need, g[k], goal[k]);
     draw += sel(need, 2u, 0u);
+    capped = capped || (need && rej && !(tries < 1000));       // the reference's loop is unbounded (mycobot.py:232-233): count the give-ups
     need = need && rej && (tries < 1000);
     tries++;
   } while (__any(need));
+  count_event(C, 0, capped);
   for (int k = 0; k < NB; k++) { E.R.q[k] = sel(doit, C.init_qpos[k], E.R.q[k]); E.R.qd[k] = sel(doit, C.init_qvel[k], E.R.qd[k]); }
   for (int k = 0; k < 7; k++) E.R.ctrl[k] = sel(doit, C.init_ctrl[k], E.R.ctrl[k]);
   for (int k = 0; k < 6; k++) E.qlag6[k] = sel(doit, C.init_qpos[k], E.qlag6[k]);
@@ -112,16 +120,17 @@ MCG_DEV void reset_env(const Cfg& C, int i, Env& E, bool doit) {
 }
 
 // mj_checkPos / mj_checkVel [RECALL]: a non-finite or huge (> 1e10) coordinate makes MuJoCo call mj_resetData (qpos0,
-// zero velocity / ctrl / warm start) and carry on.  Here the check runs once per env-step instead of once per sub-step
-// (a diverged env is beyond parity anyway); it keeps one bad env from staying NaN until its next reset.
-MCG_DEV bool bad_value(real x) { return !(x == x) || x > 1e10 || x < -1e10; }
-MCG_DEV void guard_robot(Robot& R, real* qlag6) {
+// zero velocity / ctrl / warm start) and carry on.  The check runs on the state a step kernel loads (a caller may have set it) and
+// on every sub-step's new state (robot_substep; the cube wave checks the cube when a sub-step starts).
+MCG_DEV bool guard_robot(Robot& R, real* qlag6) {
   bool bad = false;
   for (int k = 0; k < NB; k++) bad = bad || bad_value(R.q[k]) || bad_value(R.qd[k]) || bad_value(R.warm[k]);
   for (int k = 0; k < NB; k++) { R.q[k] = sel(bad, 0.0, R.q[k]); R.qd[k] = sel(bad, 0.0, R.qd[k]); R.warm[k] = sel(bad, 0.0, R.warm[k]); }
   for (int k = 0; k < 7; k++) R.ctrl[k] = sel(bad, 0.0, R.ctrl[k]);
   for (int k = 0; k < 6; k++) qlag6[k] = sel(bad, 0.0, qlag6[k]);
+  return bad;
 }
+
 
 // _get_obs / generate_mujoco_observations for Reach (mycobot.py:245-283, 342-388): 10 numbers
 MCG_DEV void observe_reach(const Cfg& C, ModelPtr P, const Env& E, real* obs, real* ag) {
@@ -202,6 +211,8 @@ __global__ __launch_bounds__(SPLIT ? 192 : 64) void step_reach_kernel(Cfg C, Vie
   MCG_TICK_INIT();
   Env E;
   load_robot(V, i, E);
+  const bool bad0 = guard_robot(E.R, E.qlag6);      // the state as loaded (a caller may have set it): mj_step's first check
+  bool hadbad = bad0;
   if constexpr (SPLIT) static_for<NB>([&](auto I) { constexpr int k = I; MS.st(LDS_QB + k, E.R.q[k]); MS.st(LDS_QDB + k, E.R.qd[k]); MS.st(LDS_WARM + k, E.R.warm[k]); if constexpr (k < 6) MS.st(LDS_QLAG + k, E.qlag6[k]); });   // q(0), qd(0) for the other waves; warm start and lagged q parked
   MCG_TICK(ST_LOAD);
   float act[8];
@@ -229,22 +240,29 @@ __global__ __launch_bounds__(SPLIT ? 192 : 64) void step_reach_kernel(Cfg C, Vie
       ik_delta(X, tpos, tquat, dq);
       for (int k = 0; k < 6; k++) E.R.ctrl[k] += dq[k];
       E.R.ctrl[6] = grip;
+      if (c == 0) for (int k = 0; k < 7; k++) E.R.ctrl[k] = sel(bad0, 0.0, E.R.ctrl[k]);      // mj_resetData inside the first mj_step, after data.ctrl was written
       MCG_TICK(ST_CTRL);
-      for (int s = 0; s < C.frame_skip; s++) robot_substep<LaneScratch, NoCoupling, NoWeld, Split>(P, E.R, E.qlag6, MS);
+      for (int s = 0; s < C.frame_skip; s++) hadbad |= robot_substep<LaneScratch, NoCoupling, NoWeld, Split>(P, E.R, E.qlag6, MS);
     }
   } else if constexpr (CONTROLLER == MCG_CTRL_MOCAP) {
     Weld W; mocap_target(C, P, E.qlag6, act, W);
-    E.R.ctrl[6] = C.grip_center + (real)act_last * C.grip_range;
+    E.R.ctrl[6] = sel(bad0, 0.0, C.grip_center + (real)act_last * C.grip_range);
     MCG_TICK(ST_CTRL);
-    for (int s = 0; s < C.frame_skip; s++) robot_substep<LaneScratch, NoCoupling, Weld, Split>(P, E.R, E.qlag6, MS, nullptr, &W);
+    for (int s = 0; s < C.frame_skip; s++) hadbad |= robot_substep<LaneScratch, NoCoupling, Weld, Split>(P, E.R, E.qlag6, MS, nullptr, &W);
   } else {
-    for (int k = 0; k < 7; k++) E.R.ctrl[k] = (real)act[k];
+    for (int k = 0; k < 7; k++) E.R.ctrl[k] = sel(bad0, 0.0, (real)act[k]);      // (mj_resetData inside mj_step zeroes the ctrl just written)
     MCG_TICK(ST_CTRL);
-    for (int s = 0; s < C.frame_skip; s++) robot_substep<LaneScratch, NoCoupling, NoWeld, Split>(P, E.R, E.qlag6, MS);
+    for (int s = 0; s < C.frame_skip; s++) hadbad |= robot_substep<LaneScratch, NoCoupling, NoWeld, Split>(P, E.R, E.qlag6, MS);
   }
 
   if constexpr (SPLIT) static_for<NB>([&](auto I) { constexpr int k = I; E.R.warm[k] = MS.ld(LDS_WARM + k); if constexpr (k < 6) E.qlag6[k] = MS.ld(LDS_QLAG + k); });     // warm start and lagged q back from LDS
-  guard_robot(E.R, E.qlag6);
+  hadbad |= guard_robot(E.R, E.qlag6);
+  if (__any(hadbad)) {                              // a reset in the last sub-step: the positions of "the last forward pass" are the reset ones
+    bool zero = true;
+    for (int k = 0; k < NB; k++) zero = zero && E.R.q[k] == 0.0 && E.R.qd[k] == 0.0;
+    for (int k = 0; k < 6; k++) E.qlag6[k] = sel(hadbad && zero, 0.0, E.qlag6[k]);
+  }
+  count_event(C, 1, hadbad);
   // The row addresses of the state arrays must be RECOMPUTED here, not carried: the compiler otherwise keeps the 49 addresses it formed
   // for load_robot alive across the whole sub-step loop for store_env -- spilled, they were the kernel's entire scratch frame (396 B
   // per lane) and, as scratch lines, half of its HBM traffic.  An opaque copy of the env index cuts the common subexpressions.
@@ -349,12 +367,13 @@ MCG_DEV void reset_envp(const Cfg& C, int i, EnvP& E, bool doit) {
   }
   real oxy[2] = {C.igx[0], C.igx[1]}, goal[3] = {0, 0, 0};
   uint32_t draw = 0;
-  bool need = doit && !C.hidden; int tries = 0;     // hidden cube (Reach): reset_model places nothing (mycobot.py:216: `if self.has_object`)
+  bool need = doit && !C.hidden, capped = false; int tries = 0;     // hidden cube (Reach): reset_model places nothing (mycobot.py:216: `if self.has_object`)
   do {                                              // object position (mycobot.py:217-219)
     real g[3]; sample_goal(C, i, E.episode, draw, g);
     const bool rej = sqrt((g[0] - C.igx[0]) * (g[0] - C.igx[0]) + (g[1] - C.igx[1]) * (g[1] - C.igx[1])) < 0.1;
     oxy[0] = sel(need, g[0], oxy[0]); oxy[1] = sel(need, g[1], oxy[1]);
     draw += sel(need, 2u, 0u);
+    capped = capped || (need && rej && !(tries + 1 < 1000));
     need = need && rej && (tries + 1 < 1000);
     tries++;
   } while (__any(need));
@@ -365,9 +384,11 @@ MCG_DEV void reset_envp(const Cfg& C, int i, EnvP& E, bool doit) {
     const bool rej = sqrt((g[0] - oxy[0]) * (g[0] - oxy[0]) + (g[1] - oxy[1]) * (g[1] - oxy[1])) < 0.1;
     for (int k = 0; k < 3; k++) goal[k] = sel(need, g[k], goal[k]);
     draw += sel(need, 2u, 0u);
+    capped = capped || (need && rej && !(tries < 1000));
     need = need && rej && (tries < 1000);
     tries++;
   } while (__any(need));
+  count_event(C, 0, capped);
   for (int k = 0; k < NB; k++) { E.R.q[k] = sel(doit, C.init_qpos[k], E.R.q[k]); E.R.qd[k] = sel(doit, C.init_qvel[k], E.R.qd[k]); }
   for (int k = 0; k < 7; k++) E.R.ctrl[k] = sel(doit, C.init_ctrl[k], E.R.ctrl[k]);
   for (int k = 0; k < 6; k++) { E.qlag6[k] = sel(doit, C.init_qpos[k], E.qlag6[k]); E.Cb.vel[k] = sel(doit, C.init_qvel[12 + k], E.Cb.vel[k]); }
@@ -509,7 +530,8 @@ MCG_DEV void cube_from_lds(const PnpScratch MS, Cube& Cb) {
 MCG_DEV unsigned flagged_lanes(const PnpScratch MS) { return (unsigned)__ballot(MS.ld(XCH_FLAG) != 0.0); }      // the same in all four waves
 
 // the cube wave's whole env-step
-MCG_DEV void cube_wave(const View& V, ModelPtr P, const PnpScratch MS, unsigned lds0, int i, int total, bool robot_only_ok) {
+MCG_DEV void cube_wave(const Cfg& C, const View& V, ModelPtr P, const PnpScratch MS, unsigned lds0, int i, int total) {
+  const bool robot_only_ok = C.coop12 != 0;
   Cube Cb; real dr[2], qlag7[7];
   for (int k = 0; k < 3; k++) Cb.pos[k] = V.qpos(12 + k, i);
   for (int k = 0; k < 4; k++) Cb.quat[k] = V.qpos(15 + k, i);
@@ -523,7 +545,22 @@ MCG_DEV void cube_wave(const View& V, ModelPtr P, const PnpScratch MS, unsigned 
     MCG_TICK2(ST_W2_WAIT1);
     real q10[10];
     static_for<10>([&](auto I) { constexpr int k = I; q10[k] = MS.ld(XCH_Q + k); });
+    {   // mj_checkPos / mj_checkVel of this mj_step for the cube; the robot wave reports its own (mj_resetData resets both bodies)
+      bool cbad = false;
+      for (int k = 0; k < 3; k++) cbad = cbad || bad_value(Cb.pos[k]);
+      for (int k = 0; k < 4; k++) cbad = cbad || bad_value(Cb.quat[k]);
+      for (int k = 0; k < 6; k++) cbad = cbad || bad_value(Cb.vel[k]) || bad_value(Cb.warm[k]);
+      const bool reset = cbad || MS.ld(XCH_T1) != 0.0;
+      if (__any(reset)) {                                           // wave-uniform; rare
+        for (int k = 0; k < 3; k++) Cb.pos[k] = sel(reset, C.qpos0_cube[k], Cb.pos[k]);
+        for (int k = 0; k < 4; k++) Cb.quat[k] = sel(reset, C.qpos0_cube[3 + k], Cb.quat[k]);
+        for (int k = 0; k < 6; k++) { Cb.vel[k] = sel(reset, 0.0, Cb.vel[k]); Cb.warm[k] = sel(reset, 0.0, Cb.warm[k]); }
+      }
+      MS.st(XCH_BADC, cbad ? 1.0 : 0.0);
+      count_event(C, 1, cbad);
+    }
     CubeSys<PnpScratch> CS(MS, Cb, dr);
+    CS.cnt = C.cnt;
     CS.prepare(P, q10);
     touch = CS.touch[0] && CS.touch[1];
     MCG_TICK2(ST_W2_COLLIDE);
@@ -534,6 +571,7 @@ MCG_DEV void cube_wave(const View& V, ModelPtr P, const PnpScratch MS, unsigned 
     const bool coupled = __any(kind != 0), coupled2 = __any(kind == 2);      // wave-uniform
     MS.st(XCH_FLAG, (real)kind);
     if (coupled) {
+      if ((threadIdx.x & 63) == 0 && C.cnt) atomicAdd(C.cnt + 3, (unsigned long long)__popcll(__ballot(kind != 0)));
       if (kind != 0) { MS.st(XCH_NCON, (real)CS.ncon); MS.st(XCH_DR, dr[0]); MS.st(XCH_DR + 1, dr[1]); }
       if (kind == 2) cube_to_lds(MS, CS.Cb);                        // hand the (normalised, not advanced) cube over
     }
@@ -562,7 +600,7 @@ MCG_DEV void cube_wave(const View& V, ModelPtr P, const PnpScratch MS, unsigned 
 
 // the robot wave's sub-step
 template <class WLD>
-MCG_DEV void pnp_substep_robot(ModelPtr P, EnvP& E, const PnpScratch MS, unsigned lds0, const WLD& W) {
+MCG_DEV bool pnp_substep_robot(const Cfg& C, ModelPtr P, EnvP& E, const PnpScratch MS, unsigned lds0, const WLD& W) {
   Robot nx;
   PubHook hook{MS};
   robot_substep<PnpScratch, PubHook, WLD, SplitPnp, false>(P, E.R, E.qlag6, MS, &hook, &W, &nx);     // S1, S2 inside
@@ -587,8 +625,18 @@ MCG_DEV void pnp_substep_robot(ModelPtr P, EnvP& E, const PnpScratch MS, unsigne
       nx.qd[k] = sel(flag, qd_new, nx.qd[k]); nx.q[k] = sel(flag, q_new, nx.q[k]); nx.warm[k] = a[k]; });
     MCG_TICK(ST_EULER);
   }
+  // mj_checkPos / mj_checkVel / mj_checkAcc on the new state (the next mj_step's first check), and the cube wave's verdict on the cube
+  bool bad = MS.ld(XCH_BADC) != 0.0;
+  static_for<NB>([&](auto I) { constexpr int k = I; bad = bad || bad_value(nx.q[k]) || bad_value(nx.qd[k]) || bad_value(nx.warm[k]); });
+  if (__any(bad)) {                                                 // wave-uniform; rare: mj_resetData
+    static_for<NB>([&](auto I) { constexpr int k = I; nx.q[k] = sel(bad, 0.0, nx.q[k]); nx.qd[k] = sel(bad, 0.0, nx.qd[k]); nx.warm[k] = sel(bad, 0.0, nx.warm[k]); });
+    static_for<7>([&](auto I) { constexpr int k = I; E.R.ctrl[k] = sel(bad, 0.0, E.R.ctrl[k]); });
+  }
+  MS.st(XCH_T1, bad ? 1.0 : 0.0);
   static_for<NB>([&](auto I) { constexpr int k = I; E.R.q[k] = nx.q[k]; E.R.qd[k] = nx.qd[k]; E.R.warm[k] = nx.warm[k];
                                MS.st(XCH_Q + k, nx.q[k]); MS.st(XCH_QD + k, nx.qd[k]); });
+  (void)C;
+  return bad;
 }
 
 // the helper / RNE waves of the four-wave PickAndPlace kernel: same barriers as the cube wave
@@ -622,7 +670,7 @@ __global__ __launch_bounds__(DUAL ? 256 : PNP_LANES) void step_pnp_kernel(Cfg C,
   if constexpr (DUAL) {
     if (threadIdx.x >= 64) {
       const int total = (CONTROLLER == MCG_CTRL_IK ? C.control_steps : 1) * C.frame_skip;
-      if (threadIdx.x < 128) cube_wave(V, P, MS, lds0, i, total, C.coop12 != 0);
+      if (threadIdx.x < 128) cube_wave(C, V, P, MS, lds0, i, total);
       else pnp_side_wave(P, MS, lds0, total, threadIdx.x >= 192);
       return;
     }
@@ -633,10 +681,13 @@ __global__ __launch_bounds__(DUAL ? 256 : PNP_LANES) void step_pnp_kernel(Cfg C,
 #endif
   EnvP E;
   load_envp(V, i, E);
-  if constexpr (DUAL) static_for<NB>([&](auto I) { constexpr int k = I; MS.st(XCH_Q + k, E.R.q[k]); MS.st(XCH_QD + k, E.R.qd[k]); });   // q(0), qd(0) for the other waves
+  const bool bad0 = guard_robot(E.R, E.qlag6);   // the state as loaded (a caller may have set it): mj_step's first check
+  bool hadbad = bad0;
+  if constexpr (DUAL) { static_for<NB>([&](auto I) { constexpr int k = I; MS.st(XCH_Q + k, E.R.q[k]); MS.st(XCH_QD + k, E.R.qd[k]); });   // q(0), qd(0) for the other waves
+                        MS.st(XCH_T1, hadbad ? 1.0 : 0.0); }
   MCG_TICK(ST_LOAD);
   E.touch = false;
-  auto substep = [&](const auto& W) { if constexpr (DUAL) pnp_substep_robot(P, E, MS, lds0, W); else pnp_substep(P, E, MS, W); };
+  auto substep = [&](const auto& W) { if constexpr (DUAL) hadbad |= pnp_substep_robot(C, P, E, MS, lds0, W); else pnp_substep(P, E, MS, W); };
   float act[8];
   _Pragma("unroll") for (int k = 0; k < 8; k++) {   // act_dim is 7, 4 (fetch) or 8 (mocap): static indices keep the array in registers
     const float x = (k < C.act_dim) ? actions[(size_t)i * C.act_dim + (k < C.act_dim ? k : 0)] : 0.f;
@@ -661,16 +712,17 @@ __global__ __launch_bounds__(DUAL ? 256 : PNP_LANES) void step_pnp_kernel(Cfg C,
       ik_delta(X, tpos, tquat, dq);
       for (int k = 0; k < 6; k++) E.R.ctrl[k] += dq[k];
       E.R.ctrl[6] = grip;
+      if (c == 0) for (int k = 0; k < 7; k++) E.R.ctrl[k] = sel(bad0, 0.0, E.R.ctrl[k]);
       MCG_TICK(ST_CTRL);
       for (int s = 0; s < C.frame_skip; s++) substep(NoWeld{});
     }
   } else if constexpr (CONTROLLER == MCG_CTRL_MOCAP) {
     Weld W; mocap_target(C, P, E.qlag6, act, W);
-    E.R.ctrl[6] = C.grip_center + (real)act_last * C.grip_range;
+    E.R.ctrl[6] = sel(bad0, 0.0, C.grip_center + (real)act_last * C.grip_range);
     MCG_TICK(ST_CTRL);
     for (int s = 0; s < C.frame_skip; s++) substep(W);
   } else {
-    for (int k = 0; k < 7; k++) E.R.ctrl[k] = (real)act[k];
+    for (int k = 0; k < 7; k++) E.R.ctrl[k] = sel(bad0, 0.0, (real)act[k]);
     MCG_TICK(ST_CTRL);
     for (int s = 0; s < C.frame_skip; s++) substep(NoWeld{});
   }
@@ -680,7 +732,8 @@ __global__ __launch_bounds__(DUAL ? 256 : PNP_LANES) void step_pnp_kernel(Cfg C,
     for (int k = 0; k < 7; k++) E.qlag7[k] = MS.ld(XCH_QL7 + k);
     E.touch = MS.ld(XCH_T0) != 0.0;
   }
-  guard_robot(E.R, E.qlag6);
+  hadbad |= guard_robot(E.R, E.qlag6);
+  count_event(C, 1, hadbad);
   int i_tail = i; asm volatile("" : "+v"(i_tail));      // recompute the state rows' addresses for the tail (see step_reach_kernel)
   load_episodep(V, i_tail, E);
   {   // same guard for the cube: back to its model pose at rest
@@ -770,6 +823,37 @@ __global__ __launch_bounds__(PNP_LANES) void reset_pnp_kernel(Cfg C, View V, con
   write_obs(O, i, C.obs_dim, obs, ag, E.goal);
 }
 
+// TEST / DEBUG (mcg_debug_contacts): the collision pass of the current state, exported as the step kernels see it
+__global__ __launch_bounds__(PNP_LANES) void contacts_pnp_kernel(Cfg C, View V, const mcg_model* __restrict__ Pg, int32_t* __restrict__ count,
+                                                                 int32_t* __restrict__ dropped, double* __restrict__ data) {
+  __shared__ real lds[PNP_SLOTS][PNP_LANES];
+  const int lane = threadIdx.x;
+  const int i = blockIdx.x * PNP_LANES + lane;
+  if (i >= C.n) return;
+  const PnpScratch MS(&lds[0][lane]);
+  const ModelPtr P = as_model_ptr(Pg);
+  EnvP E;
+  load_envp(V, i, E);
+  // the multiplicities are replaced by D when prepare() ends: list them first from a pass of their own
+  CubeSys<PnpScratch> CS(MS, E.Cb, E.dr);
+  unsigned long long drop_before = 0;
+  CS.cnt = nullptr;
+  CS.prepare(P, E.R.q);
+  (void)drop_before;
+  count[i] = CS.ncon;
+  if (dropped) dropped[i] = CS.ndropped;
+  for (int c = 0; c < MAXCON; c++) {
+    const int b = LDS_CON + c * CON_STRIDE;
+    double* o = data + ((size_t)i * MAXCON + c) * 10;
+    const bool on = c < CS.ncon;
+    o[0] = on ? MS.ld(b + 12) : 0.0;
+    for (int k = 0; k < 3; k++) { o[1 + k] = on ? MS.ld(b + k) : 0.0; o[4 + k] = on ? MS.ld(b + 3 + k) : 0.0; }
+    o[7] = on ? MS.ld(b + 15) : -1.0;
+    o[8] = on ? CS.mult_of(c) : 0.0;
+    o[9] = on ? MS.ld(b + 13) : 0.0;
+  }
+}
+
 // compute_reward on batched goals (mycobot.py:289-298) -- the HER entry point
 __global__ void reward_kernel(const double* __restrict__ ag, const double* __restrict__ dg, int n, int reward_type,
                               double thr, double* __restrict__ out) {
@@ -802,6 +886,7 @@ struct mcg_env {
   Cfg cfg;
   View view;
   mcg_model* d_model;
+  unsigned long long* d_cnt;      // mcg_counters
   int device;
   int num_cu;
   bool no_split;       // MCG_NO_SPLIT=1 in the environment at mcg_create: always the one-wave Reach kernels (tests, A/B timing)
@@ -889,6 +974,9 @@ int mcg_create(const mcg_config* c, const mcg_model* model, int device, mcg_env*
   hipError_t err = hipMalloc(&e->view.d, nd * sizeof(double));
   if (err == hipSuccess) err = hipMalloc(&e->view.i32, (size_t)3 * C.n * sizeof(int32_t));
   if (err == hipSuccess) err = hipMalloc(&e->d_model, sizeof(mcg_model));
+  if (err == hipSuccess) err = hipMalloc(&e->d_cnt, sizeof(mcg_counters));
+  if (err == hipSuccess) err = hipMemset(e->d_cnt, 0, sizeof(mcg_counters));
+  if (err == hipSuccess) C.cnt = e->d_cnt;
   if (err == hipSuccess) err = hipMemset(e->view.d, 0, nd * sizeof(double));
   if (err == hipSuccess) err = hipMemset(e->view.i32, 0, (size_t)3 * C.n * sizeof(int32_t));
   if (err == hipSuccess) {          // domain-randomisation scales start at 1
@@ -897,6 +985,7 @@ int mcg_create(const mcg_config* c, const mcg_model* model, int device, mcg_env*
   }
   if (err == hipSuccess) {
     mcg_model mm = *m;
+    if (!(mm.contact_rpy > 0.0)) mm.contact_rpy = 2.0;      // a block built before ABI 7 (field zero): the recalled rule
     if (C.hidden) mm.cube_half[0] = mm.cube_half[1] = mm.cube_half[2] = 0.0;       // model.geom_size[object0] = 0
     err = hipMemcpy(e->d_model, &mm, sizeof(mcg_model), hipMemcpyHostToDevice);
   }
@@ -911,6 +1000,7 @@ void mcg_destroy(mcg_env* e) {
   if (e->view.d) (void)hipFree(e->view.d);
   if (e->view.i32) (void)hipFree(e->view.i32);
   if (e->d_model) (void)hipFree(e->d_model);
+  if (e->d_cnt) (void)hipFree(e->d_cnt);
   delete e;
 }
 
@@ -1016,6 +1106,24 @@ int mcg_get_state(mcg_env* e, const mcg_state* dst, void* stream) { return copy_
 uint64_t mcg_get_seed(const mcg_env* e) { return e ? (uint64_t)e->cfg.seed : 0; }
 int mcg_set_seed(mcg_env* e, uint64_t seed) { if (!e) return fail(MCG_ERR_ARG, "mcg_set_seed: null handle%s"); e->cfg.seed = seed; return MCG_OK; }
 int mcg_set_state(mcg_env* e, const mcg_state* src, void* stream) { return copy_state(e, src, 1, stream); }
+
+int mcg_get_counters(mcg_env* e, mcg_counters* out, int clear) {
+  if (!e || !out) return fail(MCG_ERR_ARG, "mcg_get_counters: null argument%s");
+  HIP_OK(hipSetDevice(e->device));
+  HIP_OK(hipDeviceSynchronize());
+  HIP_OK(hipMemcpy(out, e->d_cnt, sizeof(mcg_counters), hipMemcpyDeviceToHost));
+  if (clear) HIP_OK(hipMemset(e->d_cnt, 0, sizeof(mcg_counters)));
+  return MCG_OK;
+}
+
+int mcg_debug_contacts(mcg_env* e, int32_t* count, int32_t* dropped, double* data, void* stream) {
+  if (!e || !count || !data) return fail(MCG_ERR_ARG, "mcg_debug_contacts: null argument%s");
+  if (!e->cfg.has_object) return fail(MCG_ERR_UNSUPPORTED, "mcg_debug_contacts: Reach has no collision pass%s");
+  dim3 grid((e->cfg.n + PNP_LANES - 1) / PNP_LANES), block(PNP_LANES);
+  hipLaunchKernelGGL(contacts_pnp_kernel, grid, block, 0, (hipStream_t)stream, e->cfg, e->view, e->d_model, count, dropped, data);
+  HIP_OK(hipGetLastError());
+  return MCG_OK;
+}
 
 int mcg_compute_reward(const double* achieved, const double* desired, int n, int reward_type, double threshold,
                        double* out, void* stream) {

@@ -65,8 +65,10 @@ def mix_contact(m, g1, g2):
     return condim, [f[0], f[0], f[1], f[2], f[2]], solref, solimp
 
 
-def specialize(m: dict, weld_rule: str = "common") -> dict:
-    """m: table from ``load_model`` (full scene; the cube may have been dropped)."""
+def specialize(m: dict, weld_rule: str = "common", contact_rule: str = "mujoco") -> dict:
+    """m: table from ``load_model`` (full scene; the cube may have been dropped).
+    contact_rule: "mujoco" = Rpy = 2 mu^2 R for a contact's pyramid rows (the rule as recalled) | "keyframe" = 4 mu^2 R, the one single
+    change that reproduces the cube's rest height in the reference's keyframes (oracle/RULE_STUDY.md K1; oracle rule[3] = 2)."""
     name2id = {n: i for i, n in enumerate(m["body_name"])}
     has_cube = "object0" in name2id
     ids = [name2id[n] for n in MOVING] + ([name2id["object0"]] if has_cube else [])
@@ -188,6 +190,8 @@ def specialize(m: dict, weld_rule: str = "common") -> dict:
     assert i6 == 5 and np.allclose(R, np.eye(3)) and np.allclose(m["site_quat"][s], [1, 0, 0, 0])
     out["site_eef"] = p + np.asarray(m["site_pos"][s])
     # site target0 hangs on the world body: stage_rewards reads its MJCF position unless the env is rendering (mycobot.py:422, 309-311)
+    assert contact_rule in ("mujoco", "keyframe")
+    out["contact_rpy"] = 4.0 if contact_rule == "keyframe" else 2.0
     out["target0"] = (np.asarray(m["site_pos"][m["site_name"].index("target0")], dtype=np.float64)
                       if "target0" in m["site_name"] else np.array([-0.15, 0.0, 0.21]))
 

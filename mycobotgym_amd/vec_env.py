@@ -69,7 +69,8 @@ class MyCobotVecEnv:
                  frame_skip: int = 20, max_episode_steps: int = MAX_EPISODE_STEPS, device="cuda:0", seed: int = 0,
                  env_id_offset: int = 0, auto_reset: bool = True, mesh_inertia: str = "legacy",
                  domain_randomization: Optional[dict] = None, model_path: Optional[str] = None,
-                 image_obs: bool = False, model: Optional["_abi.McgModel"] = None, weld_rule: str = "common", **unused):
+                 image_obs: bool = False, model: Optional["_abi.McgModel"] = None, weld_rule: str = "common", contact_rule: str = "mujoco",
+                 **unused):
         if image_obs:
             raise NotImplementedError("image observations (-v1 ids, MyCobotImgEnv) need a rasteriser: out of scope")
         if controller_type == "delta_joint":
@@ -122,9 +123,11 @@ class MyCobotVecEnv:
             cfg.dr_friction_range[0], cfg.dr_friction_range[1] = domain_randomization.get("friction", (1.0, 1.0))
         cfg.seed = int(seed) & (2 ** 64 - 1); cfg.env_id_offset = int(env_id_offset)
         self._cfg = cfg
-        if model is None and weld_rule != "common":     # mocap weld with MuJoCo's recalled row weights (rotational rows softer)
+        if model is None and (weld_rule != "common" or contact_rule != "mujoco"):
+            # weld_rule "mujoco": the mocap weld with MuJoCo's recalled row weights (rotational rows softer); contact_rule "keyframe": the
+            # pyramid regulariser that reproduces the cube's rest height of the reference's keyframes (include/mcg.h: contact_rpy)
             from .model.specialize import specialize
-            model = _abi.McgModel.from_spec(specialize(load_table(True, mesh_inertia, mocap), weld_rule=weld_rule))
+            model = _abi.McgModel.from_spec(specialize(load_table(True, mesh_inertia, mocap), weld_rule=weld_rule, contact_rule=contact_rule))
         if model is None:     # built-in block; a caller-supplied mcg_model (tests, custom robots) overrides it
             model = _abi.McgModel()
             variant = (1 if mesh_inertia == "exact" else 0) + (2 if mocap else 0)     # 2, 3: mocap body + weld (mycobot280_mocap.xml)
@@ -281,6 +284,23 @@ class MyCobotVecEnv:
             _abi.check(self._lib.mcg_time_steps(self._h, C.c_void_p(a.data_ptr()), C.byref(self._out), int(steps),
                                                 self._stream(), C.byref(ms)), "mcg_time_steps")
         return float(ms.value)
+
+    def counters(self, clear: bool = False) -> dict:
+        """Event counters of the engine (include/mcg.h: mcg_counters); synchronises the device."""
+        c = _abi.McgCounters()
+        _abi.check(self._lib.mcg_get_counters(self._h, C.byref(c), int(clear)), "mcg_get_counters")
+        return {n: int(getattr(c, n)) for n, _ in c._fields_}
+
+    def debug_contacts(self) -> dict:
+        """TEST / DEBUG: the collision pass of the current state as the kernels see it (mcg_debug_contacts): per env the number of
+        list entries, the contacts the cap cut off, and per entry dist, pos[3], normal[3], pair type, multiplicity, D."""
+        n = self.num_envs
+        count = torch.zeros(n, dtype=torch.int32, device=self.device); dropped = torch.zeros_like(count)
+        data = torch.zeros(n, 12, 10, dtype=torch.float64, device=self.device)
+        _abi.check(self._lib.mcg_debug_contacts(self._h, count.data_ptr(), dropped.data_ptr(), data.data_ptr(), self._stream()), "mcg_debug_contacts")
+        torch.cuda.synchronize(self.device)
+        return {"count": count, "dropped": dropped, "dist": data[:, :, 0], "pos": data[:, :, 1:4], "normal": data[:, :, 4:7],
+                "type": data[:, :, 7].to(torch.int32), "mult": data[:, :, 8], "D": data[:, :, 9]}
 
     def close(self):
         if not self._closed and getattr(self, "_h", None):

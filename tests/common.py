@@ -32,7 +32,7 @@ def soften_gains(tab, scale=0.1):
 def make_oracle(n, has_object=False, controller_type="joint", fetch_env=False, reward_type="dense", seed=0,
                 env_id_offset=0, mesh_inertia="legacy", frame_skip=20, control_steps=5, max_episode_steps=50,
                 target_in_the_air=True, distance_threshold=0.01, auto_reset=True, n_threads=None, table=None,
-                domain_randomization=None, block_gripper=False, weld_rule="common"):
+                domain_randomization=None, block_gripper=False, weld_rule="common", contact_rule="mujoco"):
     from oracle import pyoracle as po
     from mycobotgym_amd.vec_env import initial_state
     mocap = controller_type == "mocap"
@@ -44,8 +44,9 @@ def make_oracle(n, has_object=False, controller_type="joint", fetch_env=False, r
     has_cube = has_object or hidden
     # the build's scoped collision set: pairs involving the cube
     model = po.OracleModel(tab, enable_contact=has_cube, scope_geom=tab["geom_name"].index("object0") if has_cube else -1)
-    if weld_rule == "mujoco":
-        model._set_i("rule", [1, 0, 0, 0, 0, 0, 0, 0])        # study switch rule[0]: rotational weight on the weld's rows 3-5
+    if weld_rule == "mujoco" or contact_rule == "keyframe":
+        # study switches: rule[0] = 1 rotational weight on the weld's rows 3-5; rule[3] = 2 Rpy = 4 mu^2 R (the keyframes' rest height)
+        model._set_i("rule", [1 if weld_rule == "mujoco" else 0, 0, 0, 2 if contact_rule == "keyframe" else 0, 0, 0, 0, 0])
     qpos, qvel, ctrl, igx, height = initial_state(has_cube, fetch_env, mesh_inertia, mocap)
     ctrl = ctrl[7 - tab["nu"]:]                  # the oracle's ctrl has the model's nu entries (mocap model: the finger only)
     cfg = po.EnvConfig()

@@ -80,6 +80,11 @@ def test_sb3_adapter_over_the_real_engine(torch_cuda, env_id):
     venv = MyCobotSB3VecEnv(make(env_id, num_envs=n, seed=9, distance_threshold=thr))
     ora = make_oracle(n, has_object=kw["has_object"], controller_type=kw["controller_type"], reward_type=kw["reward_type"], seed=9,
                       distance_threshold=thr)
+    # the oracle's own sensitivity (a second oracle from the same states perturbed by 1e-14): the yardstick of the chaotic IK env-steps
+    twin = make_oracle(n, has_object=kw["has_object"], controller_type=kw["controller_type"], reward_type=kw["reward_type"], seed=9,
+                       distance_threshold=thr) if kw["controller_type"] == "IK" else None
+    if twin is not None: twin.reset(seed=9)
+    prng = np.random.default_rng(1); twin_errs = []
     venv.seed(9)
     obs = venv.reset()
     o_obs, _, o_dg = ora.reset(seed=9)
@@ -94,8 +99,14 @@ def test_sb3_adapter_over_the_real_engine(torch_cuda, env_id):
         venv.envs.set_state(qpos=s["qpos"].T.copy(), qvel=s["qvel"].T.copy(), ctrl=s["ctrl"].T.copy(), warm=s["warm"].T.copy(),
                             qpos_lag=s["qpos_lag"].T.copy(), goal=s["goal"].T.copy(), elapsed=s["elapsed"], episode=s["episode"])
         a = rng.uniform(-1, 1, (n, venv.envs.action_dim)).astype(np.float32)
+        if twin is not None:
+            s2 = dict(s); s2["qpos"] = s["qpos"] + 1e-14 * np.sign(prng.normal(size=s["qpos"].shape)); twin.set_state(**s2)
         obs, rew, dones, infos = venv.step(a)
         o = ora.step(a)
+        if twin is not None:
+            ot = twin.step(a)
+            od = o["terminated"].astype(bool) | o["truncated"].astype(bool)
+            twin_errs.append(np.abs(ot["final_obs"][od] - o["final_obs"][od]).max(axis=1) if od.any() else np.zeros(0))
         assert rew.dtype == np.float32 and dones.dtype == bool and len(infos) == n
         o_done = o["terminated"].astype(bool) | o["truncated"].astype(bool)
         assert np.array_equal(dones, o_done)
@@ -117,7 +128,9 @@ def test_sb3_adapter_over_the_real_engine(torch_cuda, env_id):
                 assert "terminal_observation" not in infos[i] and "episode" not in infos[i]
     assert n_done >= n                                            # every env hit the TimeLimit at least once
     term_errs = np.array(term_errs)                               # terminal_observation == the oracle's final observation
-    if kw["controller_type"] == "IK": assert np.median(term_errs) < 1e-8 and np.quantile(term_errs, 0.9) < 5e-2      # 100 chaotic sub-steps, pads meeting the table
+    if kw["controller_type"] == "IK":      # 100 chaotic sub-steps, pads meeting the table: bounded by the oracle's own sensitivity, quantile by quantile
+        from tests.common import assert_within_oracle_sensitivity
+        assert_within_oracle_sensitivity([term_errs], [np.concatenate(twin_errs)], "SB3 terminal observations (IK)")
     else: assert term_errs.max() < 1e-9
     print(f"\n[{env_id}] SB3 adapter over the engine: {n_done} episodes ended in 60 steps, {n_succ} by success")
     r = venv.env_method("compute_reward", obs["achieved_goal"], obs["desired_goal"], None, indices=[0])
@@ -258,14 +271,16 @@ def test_two_processes_share_the_gpu_and_match_one(torch_cuda, task, tmp_path):
 # ----------------------------------------------------------------------------------------------------- bad-state guard
 @pytest.mark.parametrize("has_object", [False, True])
 def test_bad_state_guard(torch_cuda, has_object):
-    """mj_checkPos / mj_checkVel [RECALL]: MuJoCo resets mjData when a coordinate is NaN or beyond 1e10.  The engine checks once per
-    env-step (the oracle once per sub-step, as MuJoCo does): a poisoned env comes back finite at qpos0 with zero velocity, ctrl and
-    warm start, the others are untouched -- the deviation is confined to envs that were already lost."""
+    """mj_checkPos / mj_checkVel [RECALL]: MuJoCo resets mjData when a coordinate is NaN or beyond 1e10, at the start of the mj_step that
+    meets it.  The engine checks the state it loads and every sub-step's new state (round 2: once per env-step): a poisoned env is reset
+    to qpos0 with zero velocity, ctrl and warm start BEFORE its first sub-step and then simulated like the oracle's -- the same
+    observations and the same state after the step; the others are untouched.  (With an object: the whole mjData is reset, the cube too.)"""
     torch = torch_cuda
     from tests.common import make_pair, sync_oracle_to, step_errors
     n = 64
     envs, ora = make_pair(n, has_object=has_object, controller_type="joint", reward_type="dense", seed=8)
     envs.reset(seed=8); ora.reset(seed=8)
+    envs.counters(clear=True)
     a = np.random.default_rng(0).uniform(-1, 1, (n, 7)).astype(np.float32)
     step_errors(envs, ora, a)
     sync_oracle_to(envs, ora)
@@ -278,15 +293,15 @@ def test_bad_state_guard(torch_cuda, has_object):
     ora.set_state(**so)
     obs, rew, term, trunc, info = envs.step(torch.as_tensor(a))
     o = ora.step(a)
-    good = np.ones(n, bool); good[bad] = False
-    assert np.abs(obs["observation"].cpu().numpy()[good] - o["obs"][good]).max() < 1e-8          # neighbours: unaffected, still on the oracle
-    st = envs.get_state()
+    err = np.abs(obs["observation"].cpu().numpy() - o["obs"]).max(axis=1)
+    st, so = envs.get_state(), ora.get_state()
+    qerr = np.abs(st["qpos"].cpu().numpy().T - so["qpos"]).max(axis=1)
+    print(f"\nbad-state reset, has_object={has_object}: obs error of the three reset envs {err[bad]}, of the others {np.delete(err, bad).max():.2e}; "
+          f"qpos error of the reset envs {qerr[bad]}; counters {envs.counters()}")
+    assert err.max() < 1e-8 and qerr.max() < 1e-8            # reset envs included: 20 sub-steps from qpos0 with zero controls, as the oracle
     assert all(torch.isfinite(v.double()).all() for v in st.values())
-    assert st["qpos"][:12, bad].abs().max() == 0 and st["qvel"][:12, bad].abs().max() == 0 and st["ctrl"][:, bad].abs().max() == 0
-    assert torch.isfinite(obs["observation"]).all()
-    # the oracle (per-sub-step check) reset the same envs at their first sub-step and then simulated 20 sub-steps from qpos0
     assert all(int(ora.data(i).get("warning_badstate", (1,), np.int32)[0]) >= 1 for i in bad)
-    assert np.abs(o["obs"][bad]).max() < 1.0
+    assert envs.counters()["bad_state_resets"] >= 3
     # one step later both sides are ordinary states again
     obs, *_ = envs.step(torch.as_tensor(a))
     assert torch.isfinite(obs["observation"]).all()

@@ -173,7 +173,7 @@ def test_ik_env_step_error_is_the_oracles_own_sensitivity(torch_cuda):
     print("   hip vs oracle           :", " ".join(f"{x:.2e}" for x in qh))
     print("   oracle vs oracle + 1e-14:", " ".join(f"{x:.2e}" for x in qt))
     assert np.all(qh[:3] <= 10 * qt[:3] + 1e-13)
-    assert qh[3] <= 10 * qt[3] + 1e-13 or qh[3] < 1e-6
+    assert qh[3] <= 10 * qt[3] + 1e-13            # the worst env too: no absolute escape hatch
     assert qh[0] < 1e-10
     envs.close()
 

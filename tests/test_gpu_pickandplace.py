@@ -64,6 +64,45 @@ def test_substeps_cube_resting_on_table(torch_cuda):
     assert worst["obs"] < 1e-13 and worst["qpos"] < 1e-12 and worst["qvel"] < 5e-10      # measured 5.6e-16, 1.0e-14, 5.2e-12
 
 
+def test_contact_rule_keyframe_variant(torch_cuda):
+    """contact_rule="keyframe": Rpy = 4 mu^2 R in the kernels (mcg_model.contact_rpy) and in the oracle (rule[3] = 2).  Per-sub-step parity
+    of the variant with the cube settling on the table and during a grasp, and the rest height the reference's keyframes store
+    (z = 0.209981: penetration 1.85e-5 .. 1.95e-5, mycobot280.xml:6) reached on the GPU."""
+    torch = torch_cuda
+    from tests.common import make_pair, sync_oracle_to, step_errors
+    n = 64
+    kw = dict(has_object=True, controller_type="joint", reward_type="dense", seed=5, frame_skip=1, max_episode_steps=10 ** 9, contact_rule="keyframe")
+    envs, ora = make_pair(n, **kw)
+    envs.reset(seed=5); ora.reset(seed=5)
+    _grasp_state(ora, n)
+    a = np.clip(np.tile(np.concatenate([ora.get_state()["ctrl"][0, :6], [1.0]]).astype(np.float32), (n, 1)), -1, 1)
+    worst = 0.0
+    for t in range(150):
+        sync_oracle_to(envs, ora)
+        e, flags_equal, o = step_errors(envs, ora, a)
+        assert flags_equal
+        worst = max(worst, e.max())
+    # and free-running at rest: the kernels alone settle at the keyframes' height
+    rest = MyCobotVecEnvRest(torch, "keyframe"); base = MyCobotVecEnvRest(torch, "mujoco")
+    print(f"\ncontact_rule=keyframe: 150 sub-steps through a grasp, max obs error {worst:.2e}; cube rest penetration on the GPU {rest:.3e} "
+          f"(default rule {base:.3e}; the reference's keyframes 1.85e-5 .. 1.95e-5)")
+    assert worst < 1e-10
+    assert 1.85e-5 <= rest <= 1.95e-5 and 9.0e-6 < base < 1.0e-5
+    envs.close()
+
+
+def MyCobotVecEnvRest(torch, rule):
+    """Penetration of the resting cube after 40 env-steps with the arm parked (joint controller holding its initial pose)."""
+    from mycobotgym_amd import MyCobotVecEnv
+    envs = MyCobotVecEnv(32, has_object=True, controller_type="joint", reward_type="dense", seed=0, contact_rule=rule, max_episode_steps=10 ** 9)
+    envs.reset(seed=0)
+    hold = envs.get_state()["qpos"][:7].T.clone().float(); hold[:, 6] = 0
+    for _ in range(40): envs.step(hold)
+    z = envs.get_state()["qpos"][14].double()
+    envs.close()
+    return float((0.21 - z).mean())
+
+
 def _contact_poses(kind, count=128, seed=0):
     """Rejection-sampled arm poses (cube at rest on the table) with a SHALLOW contact of the wanted kind (a deep one is a violent
     state).  kind "pad": a finger pad on the table / the ground; kind "mesh": an arm-side mesh (support polytope, condim 3: 4 rows)."""

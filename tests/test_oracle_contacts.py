@@ -124,6 +124,18 @@ def test_rest_height_candidate_rule_reproduces_the_keyframe(po):
     assert hits == [(0, 2)]
 
 
+def test_rest_height_under_contact_rule_keyframe(po):
+    """contact_rule="keyframe" (include/mcg.h: contact_rpy = 4; oracle rule[3] = 2; MyCobotVecEnv(contact_rule="keyframe")): the
+    selectable variant under which the reference's one contact datum -- the cube resting at z = 0.209981 in both keyframes
+    (mycobot280.xml:6, mycobot280_mocap.xml:7) -- IS reproduced.  The default stays the rule as recalled (the xfail above)."""
+    from mycobotgym_amd.model.mjcf import _np_model
+    from mycobotgym_amd.model.specialize import specialize
+    tab = load_json("mycobot280")
+    assert specialize(_np_model(tab), contact_rule="keyframe")["contact_rpy"] == 4.0 and specialize(_np_model(tab))["contact_rpy"] == 2.0
+    pen = _rest_penetration(po, {3: 2})
+    assert REF_PEN[0] <= pen <= REF_PEN[1], pen
+
+
 def test_friction_holds_then_slides(po):
     """Tangential push below mu * N sticks (soft: creeps), above it slides: Coulomb behaviour of the pyramid."""
     tab = load_json("mycobot280")

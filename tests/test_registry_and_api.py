@@ -69,7 +69,7 @@ def test_library_exports_every_declared_symbol(built):
     assert set(names) == set(_abi.EXPORTS), (names, _abi.EXPORTS)
     for n in names:
         assert getattr(lib, n) is not None
-    assert lib.mcg_abi_version() == _abi.ABI_VERSION == 6
+    assert lib.mcg_abi_version() == _abi.ABI_VERSION == 7
 
 
 def test_ctypes_mirror_matches_header_layout(built, tmp_path):
