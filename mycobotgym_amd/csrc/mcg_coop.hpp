@@ -22,7 +22,7 @@
 //   * a candidate x = H^-1 g that keeps the assumed active set IS the minimiser; otherwise an exact line search on the piecewise
 //     quadratic (Newton on phi', two 32-lane DPP reductions per evaluation) and the next iteration.
 // Any contact between any two of {static geom, cube, arm body b, finger body of a side} is a row here: there are no contact classes
-// and no per-class accumulators (what kept the gripper base - cube pair out of the lane-parallel solve).
+// and no per-class accumulators (what kept the gripper base - cube pair out of round 2's lane-parallel solve: it is enabled now).
 #pragma once
 
 #include "mcg_cube.hpp"
@@ -120,7 +120,7 @@ MCG_DEV void coop_solve(ModelPtr Pm, LdsPtr lds0, int e, LdsPtr ws, int ncon, Co
   for (int k = 0; k < 4; k++) Cb.quat[k] = ME.ld(XCH_CB + 3 + k);
   for (int k = 0; k < 6; k++) { Cb.vel[k] = ME.ld(XCH_CB + 7 + k); Cb.warm[k] = ME.ld(XCH_CB + 13 + k); }
   drs[0] = ME.ld(XCH_DR); drs[1] = ME.ld(XCH_DR + 1);
-  CubeSys<PnpScratch> CS(ME, Cb, drs);
+  CubeSys<PnpScratch> CS(ME, Cb, drs);          // (for its pair numbers only)
   CS.pm_bits = (unsigned long long)Pm;
   CS.derive(Pm);
   // ---- which finger sides carry a contact (their gear / finger joint frames are posed), twist columns of the ten joints about the cube centre
@@ -171,8 +171,9 @@ MCG_DEV void coop_solve(ModelPtr Pm, LdsPtr lds0, int e, LdsPtr ws, int ncon, Co
       const bool link = type >= PAIR_TABLE_LINK0 && !finc, tabp = (type == PAIR_TABLE_PADR || type == PAIR_TABLE_PADL);
       const bool has_cube = pair_has_cube(type);
       const int side = sel((type == PAIR_PADL_CUBE || type == PAIR_TABLE_PADL || type == PAIR_FINL_CUBE), 1, 0);
-      const bool finger = padc || finc || tabp;                                    // the robot body is the finger body of `side`
-      const int lbody = sel(link, sel(type - PAIR_TABLE_LINK0 < 5, type - PAIR_TABLE_LINK0, 5), sel(finger, 5, -1));      // last arm joint in the chain
+      const bool basec = type == PAIR_BASE_CUBE;                                   // gripper base (on link6) - cube: the arm's six joints
+      const bool finger = padc || (finc && !basec) || tabp;                        // the robot body is the finger body of `side`
+      const int lbody = sel(link, sel(type - PAIR_TABLE_LINK0 < 5, type - PAIR_TABLE_LINK0, 5), sel(finger || basec, 5, -1));      // last arm joint in the chain
       const real rsign = sel(has_cube, -1.0, 1.0);                                 // robot geom is geom1 against the cube, geom2 against a static geom
       real mu[3]; real Bc;
       _Pragma("unroll") for (int k = 0; k < 3; k++)

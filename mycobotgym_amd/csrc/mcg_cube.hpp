@@ -34,12 +34,10 @@ typedef LaneScratchT<PNP_LANES> PnpScratch;
 // table or the ground: condim 3 (four pyramid rows), rows in the arm dofs up to that body only (first stage).
 enum { PAIR_TABLE_CUBE = 0, PAIR_PADR_CUBE = 1, PAIR_PADL_CUBE = 2, PAIR_TABLE_PADR = 3, PAIR_TABLE_PADL = 4, PAIR_TABLE_LINK0 = 5,
        PAIR_FINR_CUBE = PAIR_TABLE_LINK0 + 8, PAIR_FINL_CUBE = PAIR_FINR_CUBE + 1,      // finger-link mesh - cube: bodies of pad-cube
+       PAIR_BASE_CUBE = PAIR_FINL_CUBE + 1,                                              // gripper-base mesh (rides on link6) - cube
        PAR_FIN_CUBE = 6 };                                                               // ... with their own row of contact_par
 constexpr int ALONE_MAX_LIST = 8;   // four-wave kernel: list positions the cube wave's own solve may use in a lane whose row-area column also holds
                                     // the parked inputs of a cooperative robot-only solve (mcg_coop.hpp)
-constexpr int NCLS = 3;      // classes of cube contacts in the coupled solve: 0 table, 1 right finger body, 2 left.  (A fourth -- link6, for the
-                             // gripper base against the cube -- was built and measured: 27 more accumulator registers slow the WHOLE
-                             // coupled solve by 50 %, contacts or not: scripted grasp 11.4 -> 17.0 ms/step.  Not kept.)
 // the 13 canonical directions of a polytope's frame (axes, face diagonals, space diagonals): extra separating axes of the table test
 constexpr int MCG_DIR13[13][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}, {1, 1, 0}, {1, -1, 0}, {1, 0, 1}, {1, 0, -1}, {0, 1, 1}, {0, 1, -1}, {1, 1, 1}, {1, 1, -1}, {1, -1, 1}, {1, -1, -1}};
 // a contact that involves the cube (twist space in the coupled solve) / its class there: 0 table, 1 right finger body, 2 left
@@ -261,14 +259,9 @@ MCG_DEV void pyramid_row(const CubeRows& R, int r, const real* mu, real* j) {
   _Pragma("unroll") for (int d = 0; d < 6; d++) { const real jk = sel3(k, R.J1[d], R.J2[d], R.Jt[d]); j[d] = R.Jn[d] + m * jk; }
 }
 
-// Robot-side entries of a pad-cube contact's rows, dofs (arm 0..5, gear, finger) of the pad's side.  The pad is geom1,
-// the cube geom2: J = J_cube - J_pad, so these enter with a minus sign.
-struct PadRows { real Jn[8], J1[8], J2[8], Jt[8]; };
-
 // The cube and its contacts for one sub-step: prepared before the robot's Newton solve, finished after it.
 template <class LS>
 struct CubeSys {
-  static constexpr bool enabled = true, publishes = false;
   const LS S; Cube Cb; real dr[2];             // by value: a reference into the env struct pins that struct in memory
                                                // (the model pointer is passed in: it must stay a scalar register)
   unsigned long long pm_bits;                  // the model pointer's bits, for stages reached through the robot's hook
@@ -278,6 +271,7 @@ struct CubeSys {
   real B_tc, B_pc, B_tp, B_tl, B_mc, mu_tc[3], mu_pc[3], mu_tp[3], mu_tl[3], mu_mc[3];
   bool side_on[2];                             // a contact between the cube and the right / left finger body (pad or finger-link mesh)
   bool tab_on, stat_on;                        // ... between the cube and a static geom; between a static geom and the robot alone
+  bool base_on;                                // ... between the cube and the gripper base (link6)
   int ndropped = 0;                            // contacts of this pass that the cap cut off
   int cube_lo, cube_hi, c0 = 0;                // lowest / highest list position of a contact that involves the cube (hi -1: none); list offset of the cube-alone solve
   int ncon; bool any_pad, solved, touch[2];    // touch: this forward pass has a right / left pad-cube contact; any_pad: any pad contact
@@ -314,19 +308,11 @@ struct CubeSys {
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)pm_bits), hi = __builtin_amdgcn_readfirstlane((unsigned)(pm_bits >> 32));
     return (ModelPtr)(((unsigned long long)hi << 32) | lo);
   }
-  // contacts, joint frames and per-contact solver numbers are already in LDS (the caller ran prepare()): take them over
-  MCG_DEV void adopt(ModelPtr Pm, int ncon_, bool touch0, bool touch1, bool any_pad_) {
-    pm_bits = (unsigned long long)Pm;
-    derive(Pm);
-    solved = false;
-    _Pragma("unroll") for (int k = 0; k < 6; k++) a_c[k] = Cb.warm[k];
-    ncon = ncon_; touch[0] = touch0; touch[1] = touch1; any_pad = any_pad_;      // any_pad also covers table / ground - pad contacts
-    scan_sides();
-  }
   MCG_DEV void scan_sides() {
-    side_on[0] = side_on[1] = tab_on = stat_on = false; cube_hi = -1; cube_lo = 0;
+    side_on[0] = side_on[1] = tab_on = stat_on = base_on = false; cube_hi = -1; cube_lo = 0;
     for (int c = 0; __any(c < ncon); c++) {
       const int type = sel((c < ncon), (int)S.ld(LDS_CON + c * CON_STRIDE + 15), 0);
+      base_on = base_on || type == PAIR_BASE_CUBE;
       cube_lo = sel((c < ncon) && pair_has_cube(type) && cube_hi < 0, c, cube_lo);
       cube_hi = sel((c < ncon) && pair_has_cube(type), c, cube_hi);
       side_on[0] = side_on[0] || pair_class(type) == 1; side_on[1] = side_on[1] || pair_class(type) == 2;
@@ -358,6 +344,7 @@ struct CubeSys {
       pc[sd][0] = pc[sd][1] = 0.0; pc[sd][2] = 1.0; ph[sd][0] = ph[sd][1] = ph[sd][2] = 0.0; pf[sd][0] = pf[sd][1] = 0.0; pf[sd][2] = 1.0;
     }
     bool reach, padlive;
+    real R6[9], p6[3];                              // frame of link6 (the gripper base's mesh rides on it)
     {
       const TrigC T = load_trig();
       real R[9], p[3];
@@ -458,6 +445,8 @@ struct CubeSys {
         } });
       const real dxe = p[0] - Cb.pos[0], dye = p[1] - Cb.pos[1], dze = p[2] - Cb.pos[2];
       reach = dxe*dxe + dye*dye + dze*dze < 0.2 * 0.2;                  // link6 origin within 20 cm of the cube
+      _Pragma("unroll") for (int k = 0; k < 9; k++) R6[k] = R[k];
+      _Pragma("unroll") for (int k = 0; k < 3; k++) p6[k] = p[k];
       // a pad's far corner is at most 0.16 m from the link6 origin: pads can only touch the table / the ground from within 0.17 m
       real dtab = 0;
       _Pragma("unroll") for (int k = 0; k < 3; k++) { const real e = fmax(fabs(p[k] - tp[k]) - th[k], 0.0); dtab = fma(e, e, dtab); }
@@ -524,18 +513,25 @@ struct CubeSys {
     // polytope's 13 canonical axes, ONE contact along the axis of least penetration: a cube face -> at the polytope's deepest vertex;
     // a polytope axis -> at the cube's deepest corner along it.  Each entry stands for the two identical geoms the reference attaches.
     if (__any(reach)) {
+      // mi 0 / 1: right / left finger link (its own frame); mi 2: the gripper base (arm-side polytope 7, link6 frame)
       auto mesh_cube = [&](int mi, const real* Rf, const real* pfr, int type) {
         ModelPtr H = launder(Pm);
-        real fb[6]; ldc<6>(H->fin_box[mi], fb);
+        const CRealPtr hullp = mi < 2 ? &H->fin_hull[mi][0][0] : &H->link_hull[7][0][0];
+        const CRealPtr extp = mi < 2 ? &H->fin_ext[mi][0][0] : &H->link_ext[7][0][0];
+        real fb[6]; ldc<6>(mi < 2 ? H->fin_box[mi] : H->link_hull_box[7], fb);
         real cw[3];
         _Pragma("unroll") for (int k = 0; k < 3; k++) cw[k] = pfr[k] + Rf[3*k]*fb[0] + Rf[3*k+1]*fb[1] + Rf[3*k+2]*fb[2] - Cb.pos[k];
         const real rs = sqrt(fb[3]*fb[3] + fb[4]*fb[4] + fb[5]*fb[5]) + sqrt(dot3(hc, hc));
-        const bool near = reach && dot3(cw, cw) <= rs * rs;                 // bounding spheres
+        bool near = reach && dot3(cw, cw) <= rs * rs;                       // bounding spheres ...
+        {   // ... then the cube's bounding sphere against the polytope's bounding BOX, in the mesh frame (the meshes are elongated)
+          const real rc = sqrt(dot3(hc, hc));
+          _Pragma("unroll") for (int k = 0; k < 3; k++) near = near && fabs(Rf[k]*cw[0] + Rf[3 + k]*cw[1] + Rf[6 + k]*cw[2]) <= fb[3 + k] + rc;
+        }
         if (!__any(near)) return;
         real lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY}, wlo[3][3], whi[3][3];
         _Pragma("unroll") for (int a = 0; a < 3; a++) { _Pragma("unroll") for (int r = 0; r < 3; r++) wlo[a][r] = whi[a][r] = 0; }
         for (int k = 0; k < 26; k++) {
-          real v[3]; ldc<3>(H->fin_hull[mi][k], v);
+          real v[3]; ldc<3>(hullp + 3 * k, v);
           real w[3], rel[3];
           _Pragma("unroll") for (int r = 0; r < 3; r++) { w[r] = pfr[r] + Rf[3*r]*v[0] + Rf[3*r+1]*v[1] + Rf[3*r+2]*v[2]; rel[r] = w[r] - Cb.pos[r]; }
           _Pragma("unroll") for (int a = 0; a < 3; a++) {
@@ -556,7 +552,7 @@ struct CubeSys {
         }
         real nw[3] = {0, 0, 0};                                             // the normal when a polytope axis wins (cube -> mesh)
         {
-          real ext[26]; ldc<26>(&H->fin_ext[mi][0][0], ext);
+          real ext[26]; ldc<26>(extp, ext);
           static_for<13>([&](auto Kk) { constexpr int k = Kk;
             constexpr real il = 1.0 / (MCG_DIR13[k][0]*MCG_DIR13[k][0] + MCG_DIR13[k][1]*MCG_DIR13[k][1] + MCG_DIR13[k][2]*MCG_DIR13[k][2] == 1 ? 1.0 :
                                        (MCG_DIR13[k][0]*MCG_DIR13[k][0] + MCG_DIR13[k][1]*MCG_DIR13[k][1] + MCG_DIR13[k][2]*MCG_DIR13[k][2] == 2 ? 1.4142135623730951 : 1.7320508075688772));
@@ -591,9 +587,12 @@ struct CubeSys {
         }
         const real nm[3] = {-n[0], -n[1], -n[2]};                                         // the mesh is geom1: normal from the mesh to the cube
         const int before = CL.n;
-        CL.add(pos, nm, sep ? 1.0 : -depth, type, (int)H->fin_par[0]);
+        CL.add(pos, nm, sep ? 1.0 : -depth, type, mi < 2 ? (int)H->fin_par[0] : (int)H->link_mult);
         any_pad = any_pad || (CL.n > before);
       };
+#ifndef MCG_NO_BASE_CUBE
+      mesh_cube(2, R6, p6, PAIR_BASE_CUBE);          // geom order of the reference: gripper_base before the finger links
+#endif
       mesh_cube(0, Rs[0], pf[0], PAIR_FINR_CUBE);
       mesh_cube(1, Rs[1], pf[1], PAIR_FINL_CUBE);
     }
@@ -631,6 +630,7 @@ struct CubeSys {
         real par_mc[10]; ldc<10>(Q->contact_par[PAR_FIN_CUBE], par_mc);
         imp = sel(fincube, impedance(par_mc, dist), imp); kk = sel(fincube, par_mc[0], kk); m0 = sel(fincube, mu_mc[0], m0);
         tran = sel(type == PAIR_FINR_CUBE, Q->fin_par[2], sel(type == PAIR_FINL_CUBE, Q->fin_par[3], tran));
+        tran = sel(type == PAIR_BASE_CUBE, Q->link_diag[7][0] + Q->contact_diag[PAIR_TABLE_CUBE][0], tran);      // gripper_base body + cube (the table's is 0)
       }
       if (any_tp) {
         const bool tablink = type >= PAIR_TABLE_LINK0 && !fincube, tabp = tabpad && !tablink;
@@ -667,23 +667,6 @@ struct CubeSys {
   }
   // rows of contact c in the cube's dofs / in the robot's dofs of the pad's side
   MCG_DEV void rows_cube(int c, CubeRows& R) const { cube_rows(S, c, Rc, Cb.pos, R); }
-  MCG_DEV void rows_pad(int c, int side, PadRows& P) const {
-    const int b = LDS_CON + c * CON_STRIDE;
-    real pos[3], n[3], t1[3], t2[3];
-    _Pragma("unroll") for (int k = 0; k < 3; k++) { pos[k] = S.ld(b + k); n[k] = S.ld(b + 3 + k); t1[k] = S.ld(b + 6 + k); t2[k] = S.ld(b + 9 + k); }
-    _Pragma("unroll") for (int j = 0; j < 8; j++) {
-      const int slot = sel((j < 6), j, (6 + 2 * side + (j - 6)));
-      real ax[3], an[3], lev[3], v[3];
-      _Pragma("unroll") for (int k = 0; k < 3; k++) { ax[k] = S.ld(LDS_WJ + slot*6 + k); an[k] = S.ld(LDS_WJ + slot*6 + 3 + k); lev[k] = pos[k] - an[k]; }
-      cross(ax, lev, v);
-      P.Jn[j] = -dot3(n, v); P.J1[j] = -dot3(t1, v); P.J2[j] = -dot3(t2, v); P.Jt[j] = -dot3(n, ax);
-    }
-  }
-  MCG_DEV static void pyr8(const PadRows& P, int r, const real* mu, real* j) {
-    const int k = r >> 1; const real m = ((r & 1) ? -1.0 : 1.0) * (sel3(k, mu[0], mu[1], mu[2]));
-    _Pragma("unroll") for (int d = 0; d < 8; d++) { const real jk = sel3(k, P.J1[d], P.J2[d], P.Jt[d]); j[d] = P.Jn[d] + m * jk; }
-  }
-
   // ------------------------------------------------------------------------------------- cube alone (no pad contact)
   // Two passes over the contact list per Newton iteration: (A) active mask (from the warm start on the first
   // iteration) + assembly of H and g; (B) consistency of the mask at the solution x, the constraint forces at x and the
@@ -829,16 +812,6 @@ struct CubeSys {
   }
 
   // phi'(alpha) = lin0 + alpha quad + sum_rows D min(0, r0 + alpha dr) dr over the contact rows stored at LDS_ROW
-  MCG_DEV void dphi_rows(real al, real& s, real& slope) const {     // adds the contact rows' part of phi' and phi''
-    for (int c = 0; __any(c < ncon); c++) {
-      const real D = sel((c < ncon), S.ld(LDS_CON + c * CON_STRIDE + 13), 0.0);
-      _Pragma("unroll") for (int r = 0; r < 6; r++) {
-        const real r0 = S.ld(LDS_ROW + (c * 6 + r) * 2), dr_ = S.ld(LDS_ROW + (c * 6 + r) * 2 + 1);
-        const real rr = r0 + al * dr_;
-        s += sel((rr < 0), D * rr * dr_, 0.0); slope += sel((rr < 0), D * dr_ * dr_, 0.0);
-      }
-    }
-  }
   template <bool OFF> MCG_DEV void dphi_rows_alone(real al, real& s, real& slope) const {     // the rows' part of phi' and phi''
     for (int c = 0; __any(c < ncon); c++) {
       const real D = alone_D<OFF>(c);
@@ -878,612 +851,6 @@ struct CubeSys {
       }
       if (c < ncon && !conv) S.st(LDS_ACT + c, (real)mask);
     }
-  }
-
-  // --------------------------------------------------------------- coupled robot + cube Newton (a pad touches the cube)
-  // Unknowns a_r (12) and a_c (6).  Per iteration the cube block is eliminated (Schur complement), so the robot system
-  // stays a sparse 12x12 (pattern PAT_G).  Rows: joint limits, table-cube and pad-cube pyramids.
-  //
-  // Register budget rules the layout: the robot block G (78) and the coupling block Cm (10 x 6) are ACCUMULATED IN LDS, in
-  // the line-search row area (free until the consistency pass rewrites it), by read-modify-write per contact; a contact's
-  // 6 pyramid rows enter through the basis [Jn J1 J2 Jt] and a 4x4 arrow matrix W as in solve_alone.  Only the cube block
-  // Hc (21) and the right-hand sides stay in registers.  The Schur complement uses Hc = L D L^T and keeps W_i = L^-1 Cm_i
-  // in place of Cm_i: S = G - sum_d W_i[d] W_j[d] / D[d].
-  static constexpr int GA = LDS_ROW, CM = LDS_ROW + NB * (NB + 1) / 2;
-#ifndef MCG_FULL_STEPS
-#define MCG_FULL_STEPS 4
-#endif
-  static constexpr int FULL_STEPS = MCG_FULL_STEPS;
-  static_assert(NB * (NB + 1) / 2 + 60 <= MAXCON * 12, "G and Cm must fit in the line-search row area");
-  struct Coupled {                 // one contact, as the coupled solve sees it
-    CubeRows RC; PadRows RP;
-    real D, kterm, Bc, mu[3];
-    int type, side, mask; bool pad, dim3;      // dim3: condim 3 (arm mesh contacts): the torsional pair of rows does not exist
-  };
-  MCG_DEV void contact_of(int c, Coupled& K) const {
-    const int b = LDS_CON + c * CON_STRIDE;
-    K.type = sel((c < ncon), (int)S.ld(b + 15), 0);
-    K.D = sel((c < ncon), S.ld(b + 13), 0.0); K.kterm = S.ld(b + 14);
-    K.mask = sel((c < ncon), (int)S.ld(LDS_ACT + c), 0);
-    K.pad = K.type != PAIR_TABLE_CUBE;                                   // the contact has rows in the robot's dofs
-    const bool tabpad = K.type >= PAIR_TABLE_PADR;                       // ... and none in the cube's (table / ground - pad or arm mesh)
-    const bool link = K.type >= PAIR_TABLE_LINK0;
-    const int lbody = sel(link, sel(K.type - PAIR_TABLE_LINK0 < 5, K.type - PAIR_TABLE_LINK0, 5), 7);      // last arm joint that moves the mesh
-    K.dim3 = link;
-    K.mask = sel(link, K.mask & 15, K.mask);
-    K.side = sel((K.type == PAIR_PADL_CUBE || K.type == PAIR_TABLE_PADL), 1, 0);
-    rows_cube(c, K.RC);
-    rows_pad(c, K.side, K.RP);
-    _Pragma("unroll") for (int j = 0; j < 8; j++) {                      // an arm mesh on body b: joints 0..b only (no gripper dofs)
-      const bool moves = j <= lbody;
-      K.RP.Jn[j] = sel(moves, K.RP.Jn[j], 0.0); K.RP.J1[j] = sel(moves, K.RP.J1[j], 0.0);
-      K.RP.J2[j] = sel(moves, K.RP.J2[j], 0.0); K.RP.Jt[j] = sel(moves, K.RP.Jt[j], 0.0);
-    }
-    // pad-cube: the pad is geom1 (rows_pad carries that minus sign); table-pad: the pad is geom2, its rows enter with +
-    // (selects, not products with 0: the joint-frame slots of a side whose pads were not posed hold stale LDS contents)
-    _Pragma("unroll") for (int j = 0; j < 8; j++) {
-      K.RP.Jn[j] = sel(K.pad, sel(tabpad, -K.RP.Jn[j], K.RP.Jn[j]), 0.0); K.RP.J1[j] = sel(K.pad, sel(tabpad, -K.RP.J1[j], K.RP.J1[j]), 0.0);
-      K.RP.J2[j] = sel(K.pad, sel(tabpad, -K.RP.J2[j], K.RP.J2[j]), 0.0); K.RP.Jt[j] = sel(K.pad, sel(tabpad, -K.RP.Jt[j], K.RP.Jt[j]), 0.0);
-    }
-    _Pragma("unroll") for (int d = 0; d < 6; d++) {
-      K.RC.Jn[d] = sel(tabpad, 0.0, K.RC.Jn[d]); K.RC.J1[d] = sel(tabpad, 0.0, K.RC.J1[d]);
-      K.RC.J2[d] = sel(tabpad, 0.0, K.RC.J2[d]); K.RC.Jt[d] = sel(tabpad, 0.0, K.RC.Jt[d]);
-    }
-    _Pragma("unroll") for (int k = 0; k < 3; k++) K.mu[k] = sel(link, mu_tl[k], sel(tabpad, mu_tp[k], sel(K.pad, mu_pc[k], mu_tc[k])));
-    K.Bc = sel(link, B_tl, sel(tabpad, B_tp, sel(K.pad, B_pc, B_tc)));
-  }
-  // the four basis dot products of a contact with a (cube 6-vector, robot 8-vector of the contact's side)
-  MCG_DEV static void bdots(const Coupled& K, const real* vc, const real* v8, real* o) {
-    o[0] = o[1] = o[2] = o[3] = 0;
-    _Pragma("unroll") for (int d = 0; d < 6; d++) { o[0] = fma(K.RC.Jn[d], vc[d], o[0]); o[1] = fma(K.RC.J1[d], vc[d], o[1]); o[2] = fma(K.RC.J2[d], vc[d], o[2]); o[3] = fma(K.RC.Jt[d], vc[d], o[3]); }
-    _Pragma("unroll") for (int j = 0; j < 8; j++) { o[0] = fma(K.RP.Jn[j], v8[j], o[0]); o[1] = fma(K.RP.J1[j], v8[j], o[1]); o[2] = fma(K.RP.J2[j], v8[j], o[2]); o[3] = fma(K.RP.Jt[j], v8[j], o[3]); }
-  }
-  MCG_DEV static void gather8(const real* v, int side, real* o) {   // arm 0..5, then gear / finger of the side
-    _Pragma("unroll") for (int j = 0; j < 6; j++) o[j] = v[j];
-    o[6] = sel(side, v[8], v[6]); o[7] = sel(side, v[9], v[7]);
-  }
-
-  // ---- twist space (round 2).  Every contact that involves the cube -- table-cube, pad-cube -- acts on a RELATIVE TWIST of two rigid
-  // bodies: r = twist(cube) - twist(pad of the side) (or - 0 for the table), a 6-vector [v at the cube centre ; omega] in the world
-  // frame.  Its four basis rows are e = [dir ; lever x dir] (normal, two tangents) and [0 ; n] (torsion), lever = pos - cube centre:
-  // 3 cross products instead of 8 joint-by-joint rows + the cube's.  sum_rows D j j^T of all contacts of a class is accumulated as ONE
-  // 6x6 matrix A_class = sum E^T W E (and b_class = sum E^T t) in registers, and mapped to the dofs once per Newton iteration through
-  // the twist columns c_j = [(anchor_j - centre) x axis_j ; axis_j] of the pad's chain and T_c = diag(I, Rc) of the cube:
-  //    Hc += T_c^T (A_0 + A_1 + A_2) T_c,  Cm[j] -= T_c^T A_s c_j,  G[j][k] += c_k^T A_s c_j,  gr[j] -= c_j^T b_s,  gc += T_c^T b.
-  // A contact costs ~400 instructions per pass (was ~2 000 with per-entry LDS read-modify-writes of G and Cm), the mapping ~1 500 per
-  // iteration.  Contacts between a static geom and the robot alone (table / ground - pad, - arm mesh) keep the dof-space path
-  // (contact_of / add_contact below), executed only when a lane of the wave holds one at that list position.
-  struct CubeConsts { real pos[3], mu[3][3], B[3]; int ncon; };      // (filled by hoist(), below)
-  struct TwistCols { real c[10][6]; };          // arm 0..5, gear / finger right (6, 7), gear / finger left (8, 9)
-  MCG_DEV void twist_cols(TwistCols& T) const {
-    _Pragma("unroll") for (int j = 0; j < 10; j++) {
-      real ax[3], d[3], v[3];
-      _Pragma("unroll") for (int k = 0; k < 3; k++) { ax[k] = S.ld(LDS_WJ + j*6 + k); d[k] = S.ld(LDS_WJ + j*6 + 3 + k) - Cb.pos[k]; }
-      cross(d, ax, v);
-      // a side without a finger body - cube contact in this lane: its gear / finger frames may be stale LDS contents (pads not posed)
-      const bool ok = (j < 6) || side_on[(j - 6) >> 1];
-      _Pragma("unroll") for (int k = 0; k < 3; k++) { T.c[j][k] = sel(ok, v[k], 0.0); T.c[j][3 + k] = sel(ok, ax[k], 0.0); }
-    }
-  }
-  // relative twists of the three classes for cube vector vc (v ; omega body frame) and robot vector vr (12)
-  struct Twists { real r[NCLS][6]; };
-  MCG_DEV void rel_twists(const TwistCols& T, const real* vc, const real* vr, Twists& W) const {
-    real tc[6], ua[6], us[2][6];
-    _Pragma("unroll") for (int k = 0; k < 3; k++) { tc[k] = vc[k]; tc[3 + k] = Rc[3*k]*vc[3] + Rc[3*k+1]*vc[4] + Rc[3*k+2]*vc[5]; }
-    _Pragma("unroll") for (int k = 0; k < 6; k++) {
-      ua[k] = 0;
-      _Pragma("unroll") for (int j = 0; j < 6; j++) ua[k] = fma(T.c[j][k], vr[j], ua[k]);
-      us[0][k] = fma(T.c[7][k], vr[7], fma(T.c[6][k], vr[6], ua[k]));
-      us[1][k] = fma(T.c[9][k], vr[9], fma(T.c[8][k], vr[8], ua[k]));
-      W.r[0][k] = tc[k]; W.r[1][k] = tc[k] - us[0][k]; W.r[2][k] = tc[k] - us[1][k];
-    }
-  }
-  struct TwistRows { real e[3][6], n[3]; real D, kterm; int type, cls, mask; bool tw; };     // e[3] = [0 ; n]; cls: pair_class
-  MCG_DEV void twist_rows(const CubeConsts& K, int c, TwistRows& E) const {
-    const int ncon = K.ncon;
-    const int b = LDS_CON + c * CON_STRIDE;
-    real lev[3], dir[3][3];
-    _Pragma("unroll") for (int k = 0; k < 3; k++) { lev[k] = S.ld(b + k) - K.pos[k]; dir[0][k] = S.ld(b + 3 + k); dir[1][k] = S.ld(b + 6 + k); dir[2][k] = S.ld(b + 9 + k); }
-    _Pragma("unroll") for (int r = 0; r < 3; r++) { real x[3]; cross(lev, dir[r], x); _Pragma("unroll") for (int k = 0; k < 3; k++) { E.e[r][k] = dir[r][k]; E.e[r][3 + k] = x[k]; } }
-    _Pragma("unroll") for (int k = 0; k < 3; k++) E.n[k] = dir[0][k];
-    E.type = sel((c < ncon), (int)S.ld(b + 15), 0);
-    E.tw = (c < ncon) && pair_has_cube(E.type);
-    E.cls = pair_class(E.type);
-    E.D = sel(E.tw, S.ld(b + 13), 0.0); E.kterm = S.ld(b + 14);
-    E.mask = sel(E.tw, (int)S.ld(LDS_ACT + c), 0);
-  }
-  MCG_DEV static void tdots(const TwistRows& E, const real* r, real* o) {
-    _Pragma("unroll") for (int b = 0; b < 3; b++) { o[b] = 0; _Pragma("unroll") for (int k = 0; k < 6; k++) o[b] = fma(E.e[b][k], r[k], o[b]); }
-    o[3] = E.n[0]*r[3] + E.n[1]*r[4] + E.n[2]*r[5];
-  }
-  MCG_DEV static void pick_twist(const Twists& W, int cls, real* r) {
-    _Pragma("unroll") for (int k = 0; k < 6; k++) r[k] = sel(cls == 1, W.r[1][k], sel(cls == 2, W.r[2][k], W.r[0][k]));
-  }
-  // friction and velocity-term numbers of a cube contact's pair: table-cube, pad-cube, finger mesh-cube
-  // The handful of object fields the contact loops read, copied to locals ONCE per phase: through `this` (a generic pointer that may
-  // alias LDS) each of them is a flat load repeated after every LDS store, and with one wave per SIMD every such load is a fully
-  // exposed memory round trip -- the PMC view of the scripted grasp has ~3 500 VMEM reads per coupled sub-step, about the whole of its
-  // time at ~300 clocks each.  (Copying the WHOLE object was slower: section 5 of DESIGN.md.)
-  MCG_DEV CubeConsts hoist() const {
-    CubeConsts K;
-    _Pragma("unroll") for (int k = 0; k < 3; k++) { K.pos[k] = Cb.pos[k]; K.mu[0][k] = mu_tc[k]; K.mu[1][k] = mu_pc[k]; K.mu[2][k] = mu_mc[k]; }
-    K.B[0] = B_tc; K.B[1] = B_pc; K.B[2] = B_mc; K.ncon = ncon;
-    return K;
-  }
-  MCG_DEV static void cube_pair_numbers(const CubeConsts& K, int type, real* mu, real& Bc) {
-    const bool padc = type == PAIR_PADR_CUBE || type == PAIR_PADL_CUBE, finc = type >= PAIR_FINR_CUBE;
-    _Pragma("unroll") for (int k = 0; k < 3; k++) mu[k] = sel(finc, K.mu[2][k], sel(padc, K.mu[1][k], K.mu[0][k]));
-    Bc = sel(finc, K.B[2], sel(padc, K.B[1], K.B[0]));
-  }
-  static constexpr int LDS_DV = LDS_POLY + 16;     // basis . velocity of every twist-space contact, 4 per contact (the clip polygons are dead;
-                                                   // slots 0..3 of that area are the split kernels' flags, read by other waves after S2)
-  static_assert(16 + 4 * MAXCON <= 64, "velocity terms exceed the clip-polygon slots");
-
-  // Iteration structure.  A contact is walked ONCE per Newton iteration: the pass that checks the active set at the new point x also
-  // assembles the system of the set it finds there (the first FULL_STEPS iterations move to x with a full step, so the next set is
-  // known contact by contact), instead of a consistency pass followed by an assembly pass.  Pass P0 does the same for the warm start
-  // (initial masks + first assembly).  Only the fallback iterations (exact line search, from any point) keep the separate passes,
-  // because their next point is known after the search only.
-  //
-  // Register files, not instructions, set the pace here (one wave per SIMD: a dependent scratch reload is 174 clocks).  As one
-  // function the solve needs ~770 VGPRs' worth of live values and the compiler reloads ~10 % of all operands from scratch, one at a
-  // time.  So it is cut into PHASES, each a function of its own (__noinline__) with its own register allocation, that exchange
-  // state through one struct in memory (CoupledMem, in the driver's frame): assemble (contact pass + mapping), Schur + LDL + solve,
-  // line search.  Each phase loads what it needs in a batch, works in registers, and stores its results in a batch.
-  struct CoupledMem {
-    real g0[NB], Dl[10], arefl[10], sgl[10], qd[NB];      // inputs, constant during the solve
-    real ar[NB], ac[6], xr[NB], xc[6];                    // iterate and Newton candidate
-    real gr[NB], Hc[21], gc[6];                           // the register part of the Newton system (G, Cm are in LDS)
-    int actl, conv;                                       // active limit rows (bit j), lane has converged
-  };
-  enum { PASS_WARM = 0, PASS_FUSED = 1, PASS_REBUILD = 2 };
-
-  // Phase A.  System of the active set found at the pass's point: PASS_WARM the warm start (also stores every contact's velocity
-  // term), PASS_FUSED the candidate x (checks it against the assumed set, commits the step; returns true when every lane is done),
-  // PASS_REBUILD the iterate with the masks the line search left in LDS.
-  // (Measured: a phase that first copies the object into registers -- through `this` every field is a flat load, repeated after LDS
-  // stores because a generic pointer may alias LDS -- is 10 % SLOWER: the extra live registers cost more reloads than the flat loads.)
-  template <bool ADD_M>
-  __device__ __noinline__ bool coupled_assemble(CoupledMem* Mm, int mode) { return coupled_assemble_impl<ADD_M>(Mm, mode); }
-  template <bool ADD_M>
-  MCG_DEV bool coupled_assemble_impl(CoupledMem* Mm, int mode) {
-    const CubeConsts KC = hoist();
-    real pr_[NB], pc_[6];                        // the pass's point
-    const bool at_x = mode == PASS_FUSED;
-    for (int i = 0; i < NB; i++) pr_[i] = at_x ? Mm->xr[i] : Mm->ar[i];
-    _Pragma("unroll") for (int d = 0; d < 6; d++) pc_[d] = at_x ? Mm->xc[d] : Mm->ac[d];
-    const bool conv = Mm->conv != 0;
-    const int actl = Mm->actl;
-    int act = 0;
-    bool same = true;
-    {
-      real sgl[10], arefl[10];
-      _Pragma("unroll") for (int j = 0; j < 10; j++) { sgl[j] = Mm->sgl[j]; arefl[j] = Mm->arefl[j]; }
-      _Pragma("unroll") for (int j = 0; j < 10; j++) act |= ((sgl[j] != 0) && (sgl[j] * pr_[j] - arefl[j] < 0)) ? (1 << j) : 0;
-      if (mode == PASS_REBUILD) act = actl;
-      same = act == actl;
-    }
-    MCG_TICK(ST_A_ENTRY);
-    // G <- H_eq + active limit rows, parked in LDS; Cm <- 0
-    {
-      real L[NB * (NB + 1) / 2];
-      static_for<NB>([&](auto I) { constexpr int i = I;
-        static_for<i + 1>([&](auto Jj) { constexpr int j = Jj;
-          if constexpr (PAT_E.nz[i][j]) {
-            L[tri(i, j)] = S.ld(LDS_HEQ + tri(i, j));
-            if constexpr (ADD_M && PAT_M.nz[i][j]) L[tri(i, j)] += S.ld(LDS_M + tri(i, j));
-          } else if constexpr (PAT_H.nz[i][j]) L[tri(i, j)] = 0.0; }); });
-      static_for<10>([&](auto I) { constexpr int j = I; L[tri(j, j)] += ((act >> j) & 1) ? Mm->Dl[j] : 0.0; });
-      static_for<NB>([&](auto I) { constexpr int i = I; static_for<i + 1>([&](auto Jj) { constexpr int j = Jj;
-        if constexpr (PAT_H.nz[i][j]) S.st(GA + tri(i, j), L[tri(i, j)]); else if constexpr (PAT_G.nz[i][j]) S.st(GA + tri(i, j), 0.0); }); });
-      _Pragma("unroll") for (int k = 0; k < 60; k++) S.st(CM + k, 0.0);
-    }
-    MCG_TICK(ST_A_G);
-    real grs[10];                                // static contacts' part of the robot right-hand side
-    _Pragma("unroll") for (int j = 0; j < 10; j++) grs[j] = 0;
-
-    // one dof-space (static geom - robot) contact's pyramid rows with the active set `mask` into grs (registers) and G (LDS)
-    auto add_contact = [&](const Coupled& K, int mask, const real* dv, bool live) {
-      real W00 = 0, t0 = 0, W0[3], Wd[3], t[3];
-      static_for<3>([&](auto Kk) { constexpr int k = Kk; const real m = K.mu[k];
-        const real arp = -K.Bc * fma(m, dv[1 + k], dv[0]) - K.kterm, arm = -K.Bc * fma(-m, dv[1 + k], dv[0]) - K.kterm;
-        const real wp = sel(((mask >> (2 * k)) & 1) != 0, K.D, 0.0), wm = sel(((mask >> (2 * k + 1)) & 1) != 0, K.D, 0.0);
-        W00 += wp + wm; t0 = fma(wp, arp, fma(wm, arm, t0));
-        W0[k] = m * (wp - wm); Wd[k] = m * m * (wp + wm); t[k] = m * (wp * arp - wm * arm); });
-      real Ur[4][8];
-      _Pragma("unroll") for (int j = 0; j < 8; j++) {
-        Ur[0][j] = W00 * K.RP.Jn[j] + W0[0] * K.RP.J1[j] + W0[1] * K.RP.J2[j] + W0[2] * K.RP.Jt[j];
-        Ur[1][j] = W0[0] * K.RP.Jn[j] + Wd[0] * K.RP.J1[j];
-        Ur[2][j] = W0[1] * K.RP.Jn[j] + Wd[1] * K.RP.J2[j];
-        Ur[3][j] = W0[2] * K.RP.Jn[j] + Wd[2] * K.RP.Jt[j];
-      }
-      const int gear = 6 + 2 * K.side, fing = 7 + 2 * K.side;                 // dof of local 6 / 7
-      const int rowoff[2] = {gear * (gear + 1) / 2, fing * (fing + 1) / 2};
-      static_for<8>([&](auto Ii) { constexpr int i = Ii;
-        const real gl = K.RP.Jn[i] * t0 + K.RP.J1[i] * t[0] + K.RP.J2[i] * t[1] + K.RP.Jt[i] * t[2];
-        if constexpr (i < 6) grs[i] += gl;
-        else if constexpr (i == 6) { grs[6] += sel(K.side, 0.0, gl); grs[8] += sel(K.side, gl, 0.0); }
-        else { grs[7] += sel(K.side, 0.0, gl); grs[9] += sel(K.side, gl, 0.0); }
-        // robot block, lower triangle in the contact's local order (arm 0..5, gear, finger: increasing dof index).  All loads of a
-        // row first, then all stores: the addresses are per-lane, so a load behind a store could not be hoisted.
-        int kg[i + 1]; real og[i + 1];
-        static_for<i + 1>([&](auto Jj) { constexpr int j = Jj;
-          if constexpr (i < 6) kg[j] = GA + tri(i, j);
-          else kg[j] = GA + rowoff[i - 6] + (j < 6 ? j : (j == 6 ? gear : fing));
-          og[j] = S.ld(kg[j]); });
-        static_for<i + 1>([&](auto Jj) { constexpr int j = Jj;
-          const real v = K.RP.Jn[i] * Ur[0][j] + K.RP.J1[i] * Ur[1][j] + K.RP.J2[i] * Ur[2][j] + K.RP.Jt[i] * Ur[3][j];
-          S.st(kg[j], og[j] + v); }); });
-    };
-    // sign pattern of a contact's six pyramid rows at acceleration (basis dots da) given the velocity term (dv)
-    auto pattern_of = [&](const real* mu, real Bc, real kterm, bool dim3, const real* da, const real* dv) {
-      int mask = 0;
-      static_for<3>([&](auto Kk) { constexpr int k = Kk; const real m = mu[k];
-        const real arp = -Bc * fma(m, dv[1 + k], dv[0]) - kterm, arm = -Bc * fma(-m, dv[1 + k], dv[0]) - kterm;
-        mask |= (fma(m, da[1 + k], da[0]) - arp < 0 ? (1 << (2 * k)) : 0) | (fma(-m, da[1 + k], da[0]) - arm < 0 ? (1 << (2 * k + 1)) : 0); });
-      return sel(dim3, mask & 15, mask);
-    };
-
-    {
-      Twists RV, RP_;
-      {   // (the twist columns are rebuilt for each class's mapping rather than kept live across the contact loops; likewise the point)
-        TwistCols T; twist_cols(T);
-        if (mode == PASS_WARM) { real qd[NB]; for (int i = 0; i < NB; i++) qd[i] = Mm->qd[i]; rel_twists(T, Cb.vel, qd, RV); }
-        if (mode != PASS_REBUILD) rel_twists(T, pc_, pr_, RP_);
-      }
-      MCG_TICK(ST_A_TWIST);
-      // ---- static geom - robot contacts (dof space), where a lane of the wave holds one
-      if (__any(stat_on)) {
-        for (int c = 0; __any(c < KC.ncon); c++) {
-          const int type = sel((c < KC.ncon), (int)S.ld(LDS_CON + c * CON_STRIDE + 15), 0);
-          const bool st = (c < KC.ncon) && !pair_has_cube(type);
-          if (!__any(st)) continue;
-          Coupled K; contact_of(c, K);
-          K.D = sel(st, K.D, 0.0); K.mask = sel(st, K.mask, 0);
-          real v8[8], dv[4], qd[NB];
-          const real zero6[6] = {0, 0, 0, 0, 0, 0};
-          for (int i = 0; i < NB; i++) qd[i] = Mm->qd[i];
-          gather8(qd, K.side, v8); bdots(K, zero6, v8, dv);
-          int mask = K.mask;
-          if (mode != PASS_REBUILD) {
-            real p8[8], dp[4], ps[NB];
-            for (int i = 0; i < NB; i++) ps[i] = at_x ? Mm->xr[i] : Mm->ar[i];
-            gather8(ps, K.side, p8); bdots(K, zero6, p8, dp);
-            mask = pattern_of(K.mu, K.Bc, K.kterm, K.dim3, dp, dv);
-            same = same && (!st || mask == K.mask);
-            if (st && !conv) S.st(LDS_ACT + c, (real)mask);
-          }
-          add_contact(K, mask, dv, st);
-        }
-      }
-      // ---- the register part of the system starts from its smooth parts; every class of cube contacts then adds its own
-      real gr[NB], Hc[21], gc[6];
-      for (int i = 0; i < NB; i++) gr[i] = Mm->g0[i];
-      _Pragma("unroll") for (int j = 0; j < 10; j++) gr[j] += (((act >> j) & 1) ? Mm->sgl[j] * Mm->Dl[j] * Mm->arefl[j] : 0.0) + grs[j];
-      _Pragma("unroll") for (int k = 0; k < 21; k++) Hc[k] = 0;
-      _Pragma("unroll") for (int k = 0; k < 6; k++) { Hc[tri(k, k)] = Md[k]; gc[k] = fs[k]; }
-      // ---- cube contacts, ONE CLASS AT A TIME (table, right finger body, left finger body): one 6x6 accumulator live instead of three.
-      // (Register files set the pace of this solve: a fourth accumulator set slowed the whole solve by 50 %, section 5 of DESIGN.md.)
-      static_for<NCLS>([&](auto Cc) { constexpr int cls = Cc;
-        const bool mine_any = cls == 0 ? tab_on : side_on[cls == 0 ? 0 : cls - 1];
-        if (!__any(mine_any)) return;
-        real A[21], bv[6];
-        _Pragma("unroll") for (int k = 0; k < 21; k++) A[k] = 0;
-        _Pragma("unroll") for (int k = 0; k < 6; k++) bv[k] = 0;
-        for (int c = 0; __any(c < KC.ncon); c++) {
-          const int type = sel((c < KC.ncon), (int)S.ld(LDS_CON + c * CON_STRIDE + 15), 0);
-          const bool mine = (c < KC.ncon) && pair_has_cube(type) && pair_class(type) == cls;
-          if (!__any(mine)) continue;
-          TwistRows E; twist_rows(KC, c, E);
-          E.D = sel(mine, E.D, 0.0); E.mask = sel(mine, E.mask, 0);
-          real dv[4];
-          if (mode == PASS_WARM) {
-            tdots(E, RV.r[cls], dv);
-            if (mine) { _Pragma("unroll") for (int b = 0; b < 4; b++) S.st(LDS_DV + c * 4 + b, dv[b]); }
-          } else {
-            _Pragma("unroll") for (int b = 0; b < 4; b++) dv[b] = sel(mine, S.ld(LDS_DV + c * 4 + b), 0.0);      // (other lanes: stale slots)
-          }
-          real mu_[3], Bc; cube_pair_numbers(KC, E.type, mu_, Bc);
-          int mask = E.mask;
-          if (mode != PASS_REBUILD) {
-            real dp[4]; tdots(E, RP_.r[cls], dp);
-            mask = pattern_of(mu_, Bc, E.kterm, false, dp, dv);
-            same = same && (!mine || mask == E.mask);
-#ifdef MCG_DBG_PRINT
-            if (blockIdx.x == 0 && threadIdx.x == 0 && mine) printf("[pass %d] c %d type %d mask %d (was %d) dp %.4e %.4e %.4e %.4e dv %.4e %.4e %.4e %.4e\n", mode, c, E.type, mask, E.mask, dp[0], dp[1], dp[2], dp[3], dv[0], dv[1], dv[2], dv[3]);
-#endif
-            if (mine && !conv) S.st(LDS_ACT + c, (real)mask);
-          }
-          // the contact's pyramid rows with the active set `mask` into the class accumulator
-          real W00 = 0, t0 = 0, W0[3], Wd[3], t[3];
-          static_for<3>([&](auto Kk) { constexpr int k = Kk; const real m = mu_[k];
-            const real arp = -Bc * fma(m, dv[1 + k], dv[0]) - E.kterm, arm = -Bc * fma(-m, dv[1 + k], dv[0]) - E.kterm;
-            const real wp = sel(((mask >> (2 * k)) & 1) != 0, E.D, 0.0), wm = sel(((mask >> (2 * k + 1)) & 1) != 0, E.D, 0.0);
-            W00 += wp + wm; t0 = fma(wp, arp, fma(wm, arm, t0));
-            W0[k] = m * (wp - wm); Wd[k] = m * m * (wp + wm); t[k] = m * (wp * arp - wm * arm); });
-          real U[4][6];
-          _Pragma("unroll") for (int d = 0; d < 6; d++) {
-            const real e3 = d < 3 ? 0.0 : E.n[d < 3 ? 0 : d - 3];
-            U[0][d] = W00 * E.e[0][d] + W0[0] * E.e[1][d] + W0[1] * E.e[2][d] + W0[2] * e3;
-            U[1][d] = W0[0] * E.e[0][d] + Wd[0] * E.e[1][d];
-            U[2][d] = W0[1] * E.e[0][d] + Wd[1] * E.e[2][d];
-            U[3][d] = W0[2] * E.e[0][d] + Wd[2] * e3;
-            bv[d] += E.e[0][d] * t0 + E.e[1][d] * t[0] + E.e[2][d] * t[1] + e3 * t[2];
-          }
-          static_for<6>([&](auto Dd) { constexpr int d = Dd; static_for<d + 1>([&](auto Ee) { constexpr int e = Ee;
-            const real e3 = d < 3 ? 0.0 : E.n[d < 3 ? 0 : d - 3];
-            A[tri(d, e)] += E.e[0][d] * U[0][e] + E.e[1][d] * U[1][e] + E.e[2][d] * U[2][e] + e3 * U[3][e]; }); });
-        }
-        // the class into the dof-space system.  Cube block: T_c^T A T_c, T_c = diag(I, Rc): [vv, vw Rc ; . , Rc^T ww Rc]
-        {
-          static_for<3>([&](auto Dd) { constexpr int d = Dd; static_for<d + 1>([&](auto Ee) { constexpr int e = Ee; Hc[tri(d, e)] += A[tri(d, e)]; }); });
-          real X[3][3];
-          static_for<3>([&](auto Dd) { constexpr int d = Dd; static_for<3>([&](auto Ee) { constexpr int e = Ee;
-            Hc[tri(3 + d, e)] += Rc[d] * A[tri(3, e)] + Rc[3 + d] * A[tri(4, e)] + Rc[6 + d] * A[tri(5, e)]; }); });
-          static_for<3>([&](auto Kk) { constexpr int k = Kk; static_for<3>([&](auto Ee) { constexpr int e = Ee;
-            X[k][e] = A[tri(3 + k, 3)] * Rc[e] + A[tri(3 + k, 4)] * Rc[3 + e] + A[tri(3 + k, 5)] * Rc[6 + e]; }); });
-          static_for<3>([&](auto Dd) { constexpr int d = Dd; static_for<d + 1>([&](auto Ee) { constexpr int e = Ee;
-            Hc[tri(3 + d, 3 + e)] += Rc[d] * X[0][e] + Rc[3 + d] * X[1][e] + Rc[6 + d] * X[2][e]; }); });
-          _Pragma("unroll") for (int k = 0; k < 3; k++) { gc[k] += bv[k]; gc[3 + k] += Rc[k] * bv[3] + Rc[3 + k] * bv[4] + Rc[6 + k] * bv[5]; }
-        }
-        if constexpr (cls > 0) {                   // the finger body's chain: arm 0..5, gear and finger of the side
-          constexpr int sd = cls - 1;
-          TwistCols T; twist_cols(T);
-          static_for<8>([&](auto Ii) { constexpr int il = Ii; constexpr int i = il < 6 ? il : 6 + 2 * sd + (il - 6);
-            real pv[6];
-            _Pragma("unroll") for (int d = 0; d < 6; d++) { pv[d] = 0; _Pragma("unroll") for (int e = 0; e < 6; e++) pv[d] = fma(A[tri(d, e)], T.c[i][e], pv[d]); }
-            real gl = 0;
-            _Pragma("unroll") for (int d = 0; d < 6; d++) gl = fma(T.c[i][d], bv[d], gl);
-            gr[i] -= gl;
-            int kg[il + 1]; real og[il + 1], oc[6];
-            static_for<il + 1>([&](auto Kk) { constexpr int kl = Kk; constexpr int k = kl < 6 ? kl : 6 + 2 * sd + (kl - 6);
-              kg[kl] = GA + tri(i, k); og[kl] = S.ld(kg[kl]); });
-            _Pragma("unroll") for (int d = 0; d < 6; d++) oc[d] = S.ld(CM + i * 6 + d);
-            static_for<il + 1>([&](auto Kk) { constexpr int kl = Kk; constexpr int k = kl < 6 ? kl : 6 + 2 * sd + (kl - 6);
-              real v = 0;
-              _Pragma("unroll") for (int d = 0; d < 6; d++) v = fma(T.c[k][d], pv[d], v);
-              S.st(kg[kl], og[kl] + v); });
-            _Pragma("unroll") for (int d = 0; d < 3; d++) {
-              S.st(CM + i * 6 + d, oc[d] - pv[d]);
-              S.st(CM + i * 6 + 3 + d, oc[3 + d] - (Rc[d] * pv[3] + Rc[3 + d] * pv[4] + Rc[6 + d] * pv[5]));
-            } });
-        } });
-      MCG_TICK(ST_A_LOOP);
-      MCG_TICK(ST_A_MAP);
-      for (int i = 0; i < NB; i++) Mm->gr[i] = gr[i];
-      _Pragma("unroll") for (int k = 0; k < 21; k++) Mm->Hc[k] = Hc[k];
-      _Pragma("unroll") for (int k = 0; k < 6; k++) Mm->gc[k] = gc[k];
-    }
-    MCG_TICK(ST_A_STORE);
-    if (mode == PASS_WARM) { Mm->actl = act; return false; }
-    if (mode == PASS_REBUILD) return false;
-    // commit the full step: a lane that finishes takes x; the others move to x: both take x; converged lanes keep theirs
-    const bool finish = !conv && same;
-    const bool nconv = conv || finish;
-    const bool take = finish || !nconv;
-    for (int i = 0; i < NB; i++) Mm->ar[i] = sel(take, Mm->xr[i], Mm->ar[i]);
-    _Pragma("unroll") for (int d = 0; d < 6; d++) Mm->ac[d] = sel(take, Mm->xc[d], Mm->ac[d]);
-    Mm->actl = sel(nconv && !finish, actl, act);
-    Mm->conv = nconv ? 1 : 0;
-    return !__any(!nconv);
-  }
-
-  // Phase B.  Schur complement on the cube block (Hc = L D L^T, W_i = L^-1 Cm_i kept in place of Cm_i), sparse L^T D L of the robot
-  // block, both solves: (xr, xc) <- the Newton candidate of the assembled system.
-  __device__ __noinline__ void coupled_schur_solve(CoupledMem* Mm) { coupled_schur_solve_impl(Mm); }
-  MCG_DEV void coupled_schur_solve_impl(CoupledMem* Mm) {
-    real gr[NB], Hc[21], gc[6], xr[NB], xc[6];
-    for (int i = 0; i < NB; i++) gr[i] = Mm->gr[i];
-    _Pragma("unroll") for (int k = 0; k < 21; k++) Hc[k] = Mm->Hc[k];
-    _Pragma("unroll") for (int k = 0; k < 6; k++) gc[k] = Mm->gc[k];
-    real dinvc[6], yl[6];
-    spd_factor<6>(Hc, dinvc);
-    _Pragma("unroll") for (int d = 0; d < 6; d++) yl[d] = gc[d];
-    spd_forward<6>(Hc, yl);
-    real Wm[10][6];                              // W_i = L^-1 Cm_i, kept in registers for the Schur update and the back-substitution
-    static_for<10>([&](auto Ii) { constexpr int i = Ii;
-      _Pragma("unroll") for (int d = 0; d < 6; d++) Wm[i][d] = S.ld(CM + i * 6 + d); });
-    static_for<10>([&](auto Ii) { constexpr int i = Ii;
-      spd_forward<6>(Hc, Wm[i]);
-      real sdot = 0;
-      _Pragma("unroll") for (int d = 0; d < 6; d++) sdot = fma(Wm[i][d] * dinvc[d], yl[d], sdot);
-      gr[i] -= sdot; });
-    {
-      real G[NB * (NB + 1) / 2], dinv[NB];
-      static_for<NB>([&](auto I) { constexpr int i = I; static_for<i + 1>([&](auto Jj) { constexpr int j = Jj;
-        if constexpr (PAT_G.nz[i][j]) G[tri(i, j)] = S.ld(GA + tri(i, j)); }); });
-      static_for<10>([&](auto Ii) { constexpr int i = Ii;
-        real wi[6];
-        _Pragma("unroll") for (int d = 0; d < 6; d++) wi[d] = Wm[i][d] * dinvc[d];
-        static_for<i + 1>([&](auto Jj) { constexpr int j = Jj;
-          real sdot = 0;
-          _Pragma("unroll") for (int d = 0; d < 6; d++) sdot = fma(wi[d], Wm[j][d], sdot);
-          G[tri(i, j)] -= sdot; }); });
-      for (int i = 0; i < NB; i++) xr[i] = gr[i];
-      ldl_factor<PAT_G>(G, dinv);
-      ldl_solve<PAT_G>(G, dinv, xr);
-    }
-    {   // x_c = L^-T D^-1 (L^-1 g_c - sum_i W_i x_r[i])
-      real z[6];
-      _Pragma("unroll") for (int d = 0; d < 6; d++) z[d] = yl[d];
-      static_for<10>([&](auto Ii) { constexpr int i = Ii;
-        _Pragma("unroll") for (int d = 0; d < 6; d++) z[d] = fma(-Wm[i][d], xr[i], z[d]); });
-      _Pragma("unroll") for (int d = 0; d < 6; d++) z[d] *= dinvc[d];
-      spd_backward<6>(Hc, z);
-      _Pragma("unroll") for (int d = 0; d < 6; d++) xc[d] = z[d];
-    }
-    for (int i = 0; i < NB; i++) Mm->xr[i] = xr[i];
-    _Pragma("unroll") for (int d = 0; d < 6; d++) Mm->xc[d] = xc[d];
-  }
-
-  // Phase C.  Fallback iteration: consistency of the assumed set at the candidate x; lanes where it fails search the line from the
-  // iterate towards x exactly and re-mask there.  Returns true when every lane is done.
-  template <bool ADD_M>
-  __device__ __noinline__ bool coupled_linesearch(CoupledMem* Mm) { return coupled_linesearch_impl<ADD_M>(Mm); }
-  template <bool ADD_M>
-  MCG_DEV bool coupled_linesearch_impl(CoupledMem* Mm) {
-    const CubeConsts KC = hoist();
-    real ar[NB], ac[6], pr[NB], pc[6], qd[NB], sgl[10], arefl[10];
-    for (int i = 0; i < NB; i++) { ar[i] = Mm->ar[i]; pr[i] = Mm->xr[i] - ar[i]; qd[i] = Mm->qd[i]; }
-    _Pragma("unroll") for (int d = 0; d < 6; d++) { ac[d] = Mm->ac[d]; pc[d] = Mm->xc[d] - ac[d]; }
-    _Pragma("unroll") for (int j = 0; j < 10; j++) { sgl[j] = Mm->sgl[j]; arefl[j] = Mm->arefl[j]; }
-    bool conv = Mm->conv != 0;
-    const int actl = Mm->actl;
-    bool same = true;
-    _Pragma("unroll") for (int j = 0; j < 10; j++) same = same && (((sgl[j] != 0) && (sgl[j] * Mm->xr[j] - arefl[j] < 0)) == (((actl >> j) & 1) != 0));
-    // r0 / dr of every contact row (from here on the row area of LDS holds line-search rows again: G and W are dead)
-    {
-      TwistCols T; twist_cols(T);
-      Twists RA, RP; rel_twists(T, ac, ar, RA); rel_twists(T, pc, pr, RP);
-      for (int c = 0; __any(c < KC.ncon); c++) {
-        const int type = sel((c < KC.ncon), (int)S.ld(LDS_CON + c * CON_STRIDE + 15), 0);
-        const bool tw = (c < KC.ncon) && pair_has_cube(type), st = (c < KC.ncon) && !pair_has_cube(type);
-        real da[4] = {0, 0, 0, 0}, dv[4] = {0, 0, 0, 0}, dp[4] = {0, 0, 0, 0}, mu[3] = {0, 0, 0}, Bc = 0, kterm = 0; int mask = 0; bool dim3 = false;
-        if (__any(tw)) {
-          TwistRows E; twist_rows(KC, c, E);
-          real ra[6], rp[6], ta[4], tp_[4];
-          pick_twist(RA, E.cls, ra); pick_twist(RP, E.cls, rp);
-          tdots(E, ra, ta); tdots(E, rp, tp_);
-          _Pragma("unroll") for (int b = 0; b < 4; b++) { da[b] = ta[b]; dp[b] = tp_[b]; dv[b] = sel(tw, S.ld(LDS_DV + c * 4 + b), 0.0); }
-          cube_pair_numbers(KC, E.type, mu, Bc); kterm = E.kterm; mask = E.mask;
-        }
-        if (__any(st)) {
-          Coupled K; contact_of(c, K);
-          K.D = sel(st, K.D, 0.0); K.mask = sel(st, K.mask, 0);
-          real a8[8], v8[8], p8[8], sa[4], sv[4], sp[4];
-          gather8(ar, K.side, a8); gather8(qd, K.side, v8); gather8(pr, K.side, p8);
-          bdots(K, ac, a8, sa); bdots(K, Cb.vel, v8, sv); bdots(K, pc, p8, sp);
-          _Pragma("unroll") for (int b = 0; b < 4; b++) { da[b] = sel(st, sa[b], da[b]); dv[b] = sel(st, sv[b], dv[b]); dp[b] = sel(st, sp[b], dp[b]); }
-          _Pragma("unroll") for (int k = 0; k < 3; k++) mu[k] = sel(st, K.mu[k], mu[k]);
-          Bc = sel(st, K.Bc, Bc); kterm = sel(st, K.kterm, kterm); mask = sel(st, K.mask, mask); dim3 = st && K.dim3;
-        }
-        static_for<3>([&](auto Kk) { constexpr int k = Kk;
-          static_for<2>([&](auto Od) { constexpr int odd = Od; constexpr int r = 2 * k + odd;
-            const real m = odd ? -mu[k] : mu[k];
-            const bool absent = dim3 && k == 2;
-            const real r0 = sel(absent, 1.0, fma(m, da[1 + k], da[0]) - (-Bc * fma(m, dv[1 + k], dv[0]) - kterm)), jp = sel(absent, 0.0, fma(m, dp[1 + k], dp[0]));
-            if (c < KC.ncon) { S.st(LDS_ROW + (c * 6 + r) * 2, r0); S.st(LDS_ROW + (c * 6 + r) * 2 + 1, jp); }      // absent: a row that never activates
-            same = same && (c >= KC.ncon || ((r0 + jp) < 0) == (((mask >> r) & 1) != 0)); }); });
-      }
-    }
-    const bool finish = !conv && same;
-    for (int i = 0; i < NB; i++) ar[i] = sel(finish, ar[i] + pr[i], ar[i]);
-    _Pragma("unroll") for (int d = 0; d < 6; d++) ac[d] = sel(finish, ac[d] + pc[d], ac[d]);
-    conv = conv || finish;
-    if (__any(finish)) {
-      for (int i = 0; i < NB; i++) if (finish) Mm->ar[i] = Mm->xr[i];           // the candidate itself, not iterate + step (rounding)
-      _Pragma("unroll") for (int d = 0; d < 6; d++) if (finish) Mm->ac[d] = Mm->xc[d];
-    }
-    Mm->conv = conv ? 1 : 0;
-    if (!__any(!conv)) return true;
-    // line search: smooth part = robot quadratic with H0 = M + equality rows (no limits), cube diag M
-    MCG_COUNT(CN_COUPLED_LS);
-    real lin0 = 0, quad = 0;
-    real g0[NB], Dl[10];
-    for (int i = 0; i < NB; i++) g0[i] = Mm->g0[i];
-    _Pragma("unroll") for (int j = 0; j < 10; j++) Dl[j] = Mm->Dl[j];
-    {
-      real L[NB * (NB + 1) / 2];
-      static_for<NB>([&](auto I) { constexpr int i = I;
-        static_for<i + 1>([&](auto Jj) { constexpr int j = Jj;
-          if constexpr (PAT_E.nz[i][j]) {
-            L[tri(i, j)] = S.ld(LDS_HEQ + tri(i, j));
-            if constexpr (ADD_M && PAT_M.nz[i][j]) L[tri(i, j)] += S.ld(LDS_M + tri(i, j));
-          } else if constexpr (PAT_H.nz[i][j]) L[tri(i, j)] = 0.0; }); });
-      static_for<NB>([&](auto I) { constexpr int i = I; real ha = 0, hp = 0;
-        static_for<NB>([&](auto Jj) { constexpr int j = Jj;
-          if constexpr (PAT_H.nz[i > j ? i : j][i > j ? j : i]) { ha = fma(L[tri(i, j)], ar[j], ha); hp = fma(L[tri(i, j)], pr[j], hp); } });
-        lin0 += (ha - g0[i]) * pr[i]; quad += hp * pr[i]; });
-    }
-    _Pragma("unroll") for (int k = 0; k < 6; k++) { lin0 += (Md[k] * ac[k] - fs[k]) * pc[k]; quad += Md[k] * pc[k] * pc[k]; }
-    // limit rows join the piecewise part
-    real l_r0[10], l_dr[10];
-    _Pragma("unroll") for (int j = 0; j < 10; j++) { l_r0[j] = sgl[j] * ar[j] - arefl[j]; l_dr[j] = sgl[j] * pr[j]; }
-    // phi'(alpha) is piecewise linear and increasing: Newton on it (slope = quad + sum over active rows of D dr^2) lands
-    // exactly on the root once it is on the right piece; a bracket [lo, hi] with bisection as the fallback keeps it safe.
-    auto dphi = [&](real al, real& slope) {
-      real sacc = lin0 + al * quad; slope = quad;
-      dphi_rows(al, sacc, slope);
-      _Pragma("unroll") for (int j = 0; j < 10; j++) { const real rr = l_r0[j] + al * l_dr[j]; const bool on = sgl[j] != 0 && rr < 0;
-        sacc += sel(on, Dl[j] * rr * l_dr[j], 0.0); slope += sel(on, Dl[j] * l_dr[j] * l_dr[j], 0.0); }
-      return sacc;
-    };
-    real lo = 0, hi = 2, sl;
-    const bool beyond = dphi(hi, sl) < 0;
-    real al = 1.0;
-    for (int b = 0; b < 8; b++) {
-      const real f = dphi(al, sl);
-      const bool neg = f < 0;
-      lo = sel(neg, al, lo); hi = sel(neg, hi, al);
-      const real nw = al - f / sl;
-      const real nx = sel(nw > lo && nw < hi, nw, 0.5 * (lo + hi));
-      const bool moved = fabs(nx - al) > 1e-15 * fmax(1.0, fabs(al));     // on the root's own linear piece Newton stays put
-      al = nx;
-      if (!__any(moved && !conv && !beyond)) break;                         // wave-uniform exit
-    }
-    const real alpha = sel(beyond, 2.0, al);
-    int act = 0;
-    for (int i = 0; i < NB; i++) { ar[i] = ar[i] + alpha * pr[i]; if (!conv) Mm->ar[i] = ar[i]; }
-    _Pragma("unroll") for (int d = 0; d < 6; d++) { ac[d] = ac[d] + alpha * pc[d]; if (!conv) Mm->ac[d] = ac[d]; }
-    _Pragma("unroll") for (int j = 0; j < 10; j++) act |= ((sgl[j] != 0) && (sgl[j] * ar[j] - arefl[j] < 0)) ? (1 << j) : 0;
-    if (!conv) Mm->actl = act;
-    remask(alpha, conv);
-    return false;
-  }
-
-  // The driver: out of line itself, on copies of its inputs, so that the robot pipeline it is called from keeps its own registers.
-  // ADD_M: H_eq in LDS holds J^T D J only, M is added when it is read (split kernels that assemble the constraint part before M is
-  // published).
-  struct SolveIO {
-    Cube Cb; real dr[2]; unsigned long long pm_bits; int ncon; bool touch[2], any_pad;
-    real g0[NB], Dl[10], arefl[10], sgl[10], qd[NB], a[NB], a_c[6];
-  };
-  template <bool ADD_M>
-  static __device__ __noinline__ void solve_coupled_outlined(unsigned lds_column, SolveIO* io) {
-    const LS MS((LdsPtr)(uintptr_t)lds_column);
-    CubeSys CS(MS, io->Cb, io->dr);
-    CS.pm_bits = io->pm_bits;
-    CS.adopt(CS.model(), io->ncon, io->touch[0], io->touch[1], io->any_pad);
-    CS.clean_rows();
-    CoupledMem Mm;
-    for (int i = 0; i < NB; i++) { Mm.g0[i] = io->g0[i]; Mm.qd[i] = io->qd[i]; Mm.ar[i] = io->a[i]; }
-    _Pragma("unroll") for (int j = 0; j < 10; j++) { Mm.Dl[j] = io->Dl[j]; Mm.arefl[j] = io->arefl[j]; Mm.sgl[j] = io->sgl[j]; }
-    _Pragma("unroll") for (int k = 0; k < 6; k++) Mm.ac[k] = CS.a_c[k];
-    Mm.conv = 0; Mm.actl = 0;
-    MCG_COUNT(CN_COUPLED);
-    CS.template coupled_assemble<ADD_M>(&Mm, PASS_WARM);
-    MCG_TICK(ST_C_MASK);
-    bool assembled = true;
-    for (int it = 0; it < 50; it++) {
-      MCG_COUNT(CN_COUPLED_IT);
-      if (!assembled) { CS.template coupled_assemble<ADD_M>(&Mm, PASS_REBUILD); MCG_TICK(ST_C_ASSEMBLE); }
-      CS.coupled_schur_solve(&Mm);
-      MCG_TICK(ST_C_SOLVE);
-      if (it < FULL_STEPS) {
-        const bool done = CS.template coupled_assemble<ADD_M>(&Mm, PASS_FUSED);
-        MCG_TICK(ST_C_CHECK);
-        if (done) break;
-        assembled = true;
-        continue;
-      }
-      const bool done = CS.template coupled_linesearch<ADD_M>(&Mm);
-      MCG_TICK(ST_C_LS);
-      if (done) break;
-      assembled = false;
-    }
-    for (int i = 0; i < NB; i++) io->a[i] = Mm.ar[i];
-    _Pragma("unroll") for (int k = 0; k < 6; k++) io->a_c[k] = Mm.ac[k];
-  }
-  template <bool ADD_M>
-  MCG_DEV void solve_coupled_call(const real* g0, const real* Dl, const real* arefl, const real* sgl, const real* qdr, real* ar) {
-    SolveIO io;
-    io.Cb = Cb; io.dr[0] = dr[0]; io.dr[1] = dr[1]; io.pm_bits = pm_bits; io.ncon = ncon; io.touch[0] = touch[0]; io.touch[1] = touch[1]; io.any_pad = any_pad;
-    for (int i = 0; i < NB; i++) { io.g0[i] = g0[i]; io.qd[i] = qdr[i]; io.a[i] = ar[i]; }
-    _Pragma("unroll") for (int j = 0; j < 10; j++) { io.Dl[j] = Dl[j]; io.arefl[j] = arefl[j]; io.sgl[j] = sgl[j]; }
-    solve_coupled_outlined<ADD_M>((unsigned)(uintptr_t)S.base, &io);
-    for (int i = 0; i < NB; i++) ar[i] = io.a[i];
-    _Pragma("unroll") for (int k = 0; k < 6; k++) a_c[k] = io.a_c[k];
-    solved = true;
   }
 
   // ------------------------------------------------------------------------------------------------- finish

@@ -434,51 +434,7 @@ MCG_DEV void hide_object(real* obs, real* ag) {
   for (int k = 0; k < 3; k++) ag[k] = o[k];
 }
 
-// The coupled sub-step (a finger pad touches the cube: robot and cube accelerations are solved together) is rare and
-// large.  It lives out of line, on a COPY of the env, so that its code and its live ranges stay out of the hot path's
-// register allocation (inlined, it doubled the cost of the uncoupled robot pipeline) and the env struct itself never
-// has its address taken.  The collision results stay where they are (LDS); the cheap derived numbers are recomputed.
-template <class WLD> struct CoupledIO { EnvP E; WLD W; int ncon; bool touch[2], any_pad; };
-template <class WLD>
-__device__ __noinline__ void pnp_substep_coupled(unsigned long long model_bits, CoupledIO<WLD>* io, unsigned lds_column) {
-  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)model_bits), hi = __builtin_amdgcn_readfirstlane((unsigned)(model_bits >> 32));
-  const ModelPtr P = (ModelPtr)(((unsigned long long)hi << 32) | lo);
-  const PnpScratch MS((LdsPtr)(uintptr_t)lds_column);
-  EnvP E = io->E;
-  CubeSys<PnpScratch> CS(MS, E.Cb, E.dr);       // E.Cb holds the quaternion the caller's collision pass normalised
-  CS.adopt(P, io->ncon, io->touch[0], io->touch[1], io->any_pad);
-  const WLD W = io->W;
-  robot_substep<PnpScratch, CubeSys<PnpScratch>, WLD>(P, E.R, E.qlag6, MS, &CS, &W);     // its hook runs the coupled solve
-  CS.finish(E.qlag7);
-  MCG_TICK(ST_CUBE_FIN);
-  E.Cb = CS.Cb;
-  io->E = E;
-}
-
-// one mj_step of robot + cube: collision first (needs both); without pad contact the cost separates into the cube alone
-// and the robot alone (the same instantiation as Reach)
-template <class WLD>
-MCG_DEV void pnp_substep(ModelPtr P, EnvP& E, const PnpScratch MS, const WLD& W) {
-  CubeSys<PnpScratch> CS(MS, E.Cb, E.dr);
-  CS.prepare(P, E.R.q);
-  MCG_TICK(ST_COLLIDE);
-  E.touch = CS.touch[0] && CS.touch[1];        // contacts of this forward pass: what check_contact sees after the step
-  if (__any(CS.any_pad)) {                     // wave-uniform
-    CoupledIO<WLD> io; io.E = E; io.E.Cb = CS.Cb; io.W = W; io.ncon = CS.ncon; io.touch[0] = CS.touch[0]; io.touch[1] = CS.touch[1]; io.any_pad = CS.any_pad;
-    pnp_substep_coupled<WLD>((unsigned long long)P, &io, (unsigned)(uintptr_t)MS.base);
-    const bool touch = E.touch;
-    E = io.E; E.touch = touch;
-    return;
-  }
-  CS.solve_alone();                            // finish the cube first: none of its working set is live (and spilled)
-  MCG_TICK(ST_CUBE);                           // across the robot's pipeline
-  CS.finish(E.qlag7);
-  MCG_TICK(ST_CUBE_FIN);
-  E.Cb = CS.Cb;
-  robot_substep<PnpScratch, NoCoupling, WLD>(P, E.R, E.qlag6, MS, nullptr, &W);
-}
-
-// ------------------------------------------------------------------------------- four-wave PickAndPlace (DUAL)
+// ------------------------------------------------------------------------------- four-wave PickAndPlace
 // Without a contact that reaches the robot the cube's sub-step (collision, 6x6 Newton, integration) and the robot's are independent.
 // The workgroup has four waves over the same 32 environments: ROBOT (the robot pipeline, speculatively: results held back), CUBE
 // (owns the cube for the whole env-step), M (composite rigid bodies) and RNE (bias forces), as in the Reach kernel.  Barriers per
@@ -567,7 +523,7 @@ MCG_DEV void cube_wave(const Cfg& C, const View& V, ModelPtr P, const PnpScratch
     // 0: nothing reaches the robot | 1: only static geoms do (robot and cube decouple: the cube stays here, the robot's 12 dofs go to the
     // cooperative solve) | 2: the cube touches the robot (one coupled problem) -- or its contacts sit too high in the list to leave the
     // parked inputs alone
-    const int kind = CS.any_pad ? ((CS.side_on[0] || CS.side_on[1] || CS.cube_hi - CS.cube_lo >= ALONE_MAX_LIST || !robot_only_ok) ? 2 : 1) : 0;
+    const int kind = CS.any_pad ? ((CS.side_on[0] || CS.side_on[1] || CS.base_on || CS.cube_hi - CS.cube_lo >= ALONE_MAX_LIST || !robot_only_ok) ? 2 : 1) : 0;
     const bool coupled = __any(kind != 0), coupled2 = __any(kind == 2);      // wave-uniform
     MS.st(XCH_FLAG, (real)kind);
     if (coupled) {
@@ -653,19 +609,19 @@ MCG_DEV void pnp_side_wave(ModelPtr P, const PnpScratch MS, unsigned lds0, int t
   __syncthreads();                                                  // end of the env-step
 }
 
-template <int CONTROLLER, bool DUAL>
-__global__ __launch_bounds__(DUAL ? 256 : PNP_LANES) void step_pnp_kernel(Cfg C, View V, const mcg_model* __restrict__ Pg,
-                                                             const float* __restrict__ actions, mcg_step_out O) {
-  __shared__ real lds[DUAL ? PNP_SLOTS_DUAL : PNP_SLOTS][PNP_LANES];
-  const int lane = DUAL ? (threadIdx.x & 63) : threadIdx.x;
-  if (DUAL && lane >= PNP_LANES) return;         // DUAL: four waves of 32 active lanes: robot, cube, helper (M), RNE
+template <int CONTROLLER>
+__global__ __launch_bounds__(256) void step_pnp_kernel(Cfg C, View V, const mcg_model* __restrict__ Pg,
+                                                       const float* __restrict__ actions, mcg_step_out O) {
+  constexpr bool DUAL = true;                    // (the one-wave variant of rounds 1-2 went with the lane-parallel coupled solve)
+  __shared__ real lds[PNP_SLOTS_DUAL][PNP_LANES];
+  const int lane = threadIdx.x & 63;
+  if (lane >= PNP_LANES) return;                 // four waves of 32 active lanes: robot, cube, helper (M), RNE
   const PnpScratch MS(&lds[0][lane]);
   const ModelPtr P = as_model_ptr(Pg);
   const int i_raw = blockIdx.x * PNP_LANES + lane;
-  if (!DUAL && i_raw >= C.n) return;
-  // DUAL: every wave keeps its 32 lanes (the cooperative coupled solve works with all of them); in a ragged last workgroup the surplus
+  // every wave keeps its 32 lanes (the cooperative coupled solve works with all of them); in a ragged last workgroup the surplus
   // lanes shadow the last environment: same inputs, same instruction stream, the same values stored to the same places
-  const int i = (DUAL && i_raw >= C.n) ? C.n - 1 : i_raw;
+  const int i = (i_raw >= C.n) ? C.n - 1 : i_raw;
   const unsigned lds0 = (unsigned)(uintptr_t)(LdsPtr)&lds[0][0];
   if constexpr (DUAL) {
     if (threadIdx.x >= 64) {
@@ -687,7 +643,7 @@ __global__ __launch_bounds__(DUAL ? 256 : PNP_LANES) void step_pnp_kernel(Cfg C,
                         MS.st(XCH_T1, hadbad ? 1.0 : 0.0); }
   MCG_TICK(ST_LOAD);
   E.touch = false;
-  auto substep = [&](const auto& W) { if constexpr (DUAL) hadbad |= pnp_substep_robot(C, P, E, MS, lds0, W); else pnp_substep(P, E, MS, W); };
+  auto substep = [&](const auto& W) { hadbad |= pnp_substep_robot(C, P, E, MS, lds0, W); };
   float act[8];
   _Pragma("unroll") for (int k = 0; k < 8; k++) {   // act_dim is 7, 4 (fetch) or 8 (mocap): static indices keep the array in registers
     const float x = (k < C.act_dim) ? actions[(size_t)i * C.act_dim + (k < C.act_dim ? k : 0)] : 0.f;
@@ -889,7 +845,7 @@ struct mcg_env {
   unsigned long long* d_cnt;      // mcg_counters
   int device;
   int num_cu;
-  bool no_split;       // MCG_NO_SPLIT=1 in the environment at mcg_create: always the one-wave Reach kernels (tests, A/B timing)
+  bool no_split;       // MCG_NO_SPLIT=1 in the environment at mcg_create: always the one-wave REACH kernels (tests, A/B timing)
 };
 
 extern "C" {
@@ -1042,20 +998,12 @@ int mcg_reset(mcg_env* e, const uint8_t* mask, int reseed, uint64_t seed, const 
 
 static int launch_step(mcg_env* e, const float* actions, const mcg_step_out& o, hipStream_t s) {
   if (e->cfg.has_object) {
+    // four waves (robot, cube, M, RNE) over 32 environments at every grid size: the 160 KB of LDS allow one workgroup per CU either way
     dim3 grid((e->cfg.n + PNP_LANES - 1) / PNP_LANES);
-    // robot wave + cube wave (DUAL) at every grid size: the 157 KB of LDS allow one workgroup per CU either way, so the
-    // second wave always runs on a SIMD that would idle (measured: 16 384 envs 0.91 ms against 2.27 ms with one wave)
-    const bool dual = !e->no_split;
-    const dim3 block(dual ? 256 : PNP_LANES);
-#define MCG_LAUNCH_PNP(CTRL)                                                                                                   \
-  do {                                                                                                                         \
-    if (dual) hipLaunchKernelGGL((step_pnp_kernel<CTRL, true>), grid, block, 0, s, e->cfg, e->view, e->d_model, actions, o);       \
-    else hipLaunchKernelGGL((step_pnp_kernel<CTRL, false>), grid, block, 0, s, e->cfg, e->view, e->d_model, actions, o);           \
-  } while (0)
-    if (e->cfg.controller == MCG_CTRL_IK) MCG_LAUNCH_PNP(MCG_CTRL_IK);
-    else if (e->cfg.controller == MCG_CTRL_MOCAP) MCG_LAUNCH_PNP(MCG_CTRL_MOCAP);
-    else MCG_LAUNCH_PNP(MCG_CTRL_JOINT);
-#undef MCG_LAUNCH_PNP
+    const dim3 block(256);
+    if (e->cfg.controller == MCG_CTRL_IK) hipLaunchKernelGGL((step_pnp_kernel<MCG_CTRL_IK>), grid, block, 0, s, e->cfg, e->view, e->d_model, actions, o);
+    else if (e->cfg.controller == MCG_CTRL_MOCAP) hipLaunchKernelGGL((step_pnp_kernel<MCG_CTRL_MOCAP>), grid, block, 0, s, e->cfg, e->view, e->d_model, actions, o);
+    else hipLaunchKernelGGL((step_pnp_kernel<MCG_CTRL_JOINT>), grid, block, 0, s, e->cfg, e->view, e->d_model, actions, o);
     return hipGetLastError() == hipSuccess ? MCG_OK : MCG_ERR_HIP;
   }
   dim3 grid((e->cfg.n + 63) / 64);

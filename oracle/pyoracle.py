@@ -18,7 +18,7 @@ _lib = None
 
 MAXNQ, MAXNV, MAXU = 24, 24, 8
 ARM_MESHES = ("link1", "link2", "link3", "link4", "link5", "link6", "flange", "gripper_base")     # SURVEY 8f-4, first stage
-FINGER_MESHES = ("right_finger_link", "left_finger_link")                                            # second stage: against the cube
+FINGER_MESHES = ("right_finger_link", "left_finger_link", "gripper_base")                            # second stage: against the cube (round 3: the gripper base too)
 
 
 def build(force: bool = False) -> str:

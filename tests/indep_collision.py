@@ -151,6 +151,7 @@ def check_scene(sc: Scene, contacts: dict, stats: dict, what=""):
         r = check_box_pair(sc.V[f"pad{sd}"], sc.V["cube"], sc.pad[sd], sc.cube, got, f"{what} pad{sd}-cube")
         stats.setdefault("box_pairs", []).append((r["exact_depth"], r.get("along", 0.0), r["n"]))
         _measure_polytope(sc.V[f"fin{sd}"], sc.V["cube"], contacts.get((f"fin{sd}", "cube"), []), stats, f"{what} fin{sd}-cube")
+    _measure_polytope(sc.V["link7"], sc.V["cube"], contacts.get(("link7", "cube"), []), stats, f"{what} gripper_base-cube")
 
 
 def _measure_polytope(VA, VB, got, stats, what):
@@ -226,6 +227,7 @@ def kernel_contacts(count, dist, pos, normal, typ):
         t = int(typ[c]); n = np.asarray(normal[c], dtype=np.float64); p = np.asarray(pos[c], dtype=np.float64)
         if t in (1, 2): key = (f"pad{t - 1}", "cube")
         elif t in (13, 14): key = (f"fin{t - 13}", "cube")
+        elif t == 15: key = ("link7", "cube")                         # gripper base (arm-side polytope 7) - cube
         else:
             mover = "cube" if t == 0 else (f"pad{t - 3}" if t in (3, 4) else f"link{t - 5}")
             ground = np.allclose(n, [0, 0, 1]) and p[2] < 0.1          # the ground plane's contacts sit at z ~ 0, the table top's at 0.2

@@ -194,6 +194,21 @@ def test_substeps_finger_link_meshes_on_the_cube(torch_cuda):
     assert worst["obs"] < 1e-10 and worst["qpos"] < 1e-10 and worst["qvel"] < 1e-6
 
 
+def test_substeps_gripper_base_mesh_on_the_cube(torch_cuda):
+    """the gripper base's mesh (mycobot280_main.xml:171-175; it rides on link6) against the cube -- a contact between
+    the cube and the ARM, which the cooperative solve takes as one more generic row (round 2's class-wise solve could not afford it)."""
+    poses = _finger_mesh_poses(count=128, seed=4, meshes=("gripper_base",))
+    def prepare(ora):
+        s = ora.get_state()
+        s["qpos"][:] = poses; s["qpos_lag"] = s["qpos"].copy()
+        s["ctrl"][:, :6] = poses[:, :6]; s["ctrl"][:, 6] = poses[:, 6] / 0.7
+        ora.set_state(**s)
+    worst, ncon = _substep_run(torch_cuda, 128, 200, prepare=prepare, hold_pose=True)
+    print(f"\ngripper-base mesh on the cube, 200 sub-steps x 128 envs: {worst}, contact counts seen {sorted(ncon)}")
+    assert max(ncon) >= 2
+    assert worst["obs"] < 1e-10 and worst["qpos"] < 1e-10 and worst["qvel"] < 1e-6
+
+
 def test_cube_edges_parallel_to_the_table_edges(torch_cuda):
     """Regression (round 2): a cube rocking on the table by 3e-4 rad about y has its y edges parallel to the table's.  With
     |A_i x B_j| taken as sqrt(1 - C^2), rounding (C = 1 - 1e-16) made a 1e-8 `length`, and the axis built from that noise beat the

@@ -32,7 +32,8 @@ grasp = "--grasp" in sys.argv           # PickAndPlace joint with every env hold
 L = _abi.load()
 n = 8192
 pnpik = "--pnp-ik" in sys.argv         # PickAndPlace, IK controller, random policy only
-for obj, ctrl, k in (((True, "joint", 20),) if grasp else ((True, "IK", 20),) if pnpik else ((False, "joint", 200), (False, "IK", 50), (True, "joint", 100), (True, "IK", 20))):
+pnpj = "--pnp-joint" in sys.argv       # PickAndPlace, joint controller, cube resting
+for obj, ctrl, k in (((True, "joint", 20),) if grasp else ((True, "IK", 20),) if pnpik else ((True, "joint", 100),) if pnpj else ((False, "joint", 200), (False, "IK", 50), (True, "joint", 100), (True, "IK", 20))):
     envs = MyCobotVecEnv(n, has_object=obj, controller_type=ctrl, reward_type="dense", max_episode_steps=10 ** 9 if grasp else 50)
     envs.reset(seed=0)
     a = torch.rand(n, envs.action_dim, device="cuda") * 2 - 1
