@@ -138,6 +138,10 @@ def load_pmc(case, n):
         pj = json.load(f).get("cases", {}).get(case)
     if not pj or pj.get("n_envs") != n:
         return None
+    from mycobotgym_amd.build import source_hash
+    if pj.get("src_sha256") != source_hash():        # counters of other kernels than the ones this run times: not this run's traffic
+        return {"stale": True, "note": "profiles/pmc_latest.json[" + case + "] was collected on kernel sources " + str(pj.get("src_sha256"))[:12]
+                + "..., this build is " + source_hash()[:12] + "...: re-run tools/profile_case.sh"}
     return pj
 
 
@@ -146,7 +150,9 @@ def roofline(case, n, kernel_ms):
     algo = ALGO_BYTES[task] * n
     achieved = algo / (kernel_ms * 1e-3) / 1e9
     pj = load_pmc(case, n)
-    src = ("profiles/pmc_latest.json[" + case + "]: " + pj.get("note", "")) if pj else None
+    stale = pj.get("note") if pj and pj.get("stale") else None
+    if stale: pj = None
+    src = ("profiles/pmc_latest.json[" + case + "]: " + pj.get("note", "")) if pj else stale
     out = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
            "traffic": pj.get("hbm_bytes_per_launch") if pj else None, "traffic_source": src,
            "kernel": "step_reach_kernel" if task == "reach" else "step_pnp_kernel", "kernel_ms": kernel_ms,

@@ -13,6 +13,16 @@ DEPS = sorted(glob.glob(os.path.join(_HERE, "csrc", "*"))) + [os.path.join(ROOT,
 OUT = os.path.join(_HERE, "libmycobot_hip.so")
 
 
+def source_hash() -> str:
+    """sha256 over the kernel sources (csrc/*, include/mcg.h): stamps counter measurements, so that bench.py can tell when
+    profiles/pmc_latest.json was collected on other kernels than the ones it is running."""
+    import hashlib
+    h = hashlib.sha256()
+    for d in DEPS:
+        h.update(os.path.basename(d).encode()); h.update(open(d, "rb").read())
+    return h.hexdigest()
+
+
 def hipcc() -> str:
     for c in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
         if c and os.path.exists(c):

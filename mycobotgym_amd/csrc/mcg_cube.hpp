@@ -1,11 +1,12 @@
-// mcg_cube.hpp -- the free cube of PickAndPlace: collision against the table / ground / finger pads, pyramidal
-// contact rows, primal Newton solve, quaternion integration.  One env per lane.
+// mcg_cube.hpp -- the free cube of PickAndPlace: the collision pass of the whole scene, the cube's pyramidal contact rows, its own
+// (cube-alone) primal Newton solve, quaternion integration.  One env per lane.
 //
 // Replaces for this scene what mujoco.mj_step does for the `object0` body and its contacts
-// (/root/reference/mycobotgym/envs/assets/mycobot280_main.xml:81,87,195-199,222-225,260-265; call sites
-// mycobot.py:170,193): mj_collision (P4) over the primitive geoms, mj_makeConstraint / mj_projectConstraint for
-// condim-4 pyramidal contacts (P5), their part of mj_fwdConstraint (P9) and mj_Euler for a free joint (P10).
-// Convex-mesh geoms are out of scope.
+// (/root/reference/mycobotgym/envs/assets/mycobot280_main.xml:81,87,105-175,195-199,222-225,260-265; call sites
+// mycobot.py:170,193): mj_collision (P4) over the primitive geoms and, on support polytopes, the arm-side, finger-link and
+// gripper-base meshes (staged: DESIGN.md section 8); mj_makeConstraint / mj_projectConstraint for condim-4 pyramidal
+// contacts (P5); for an environment in which nothing touches the robot, the cube's part of mj_fwdConstraint (P9); mj_Euler for a free
+// joint (P10).  An environment in which a contact reaches the robot is solved by mcg_coop.hpp (one environment per wave).
 //
 // Contacts of one env live in LDS (runtime-indexed lists cannot live in registers): 16 slots per contact.
 #pragma once
@@ -590,9 +591,7 @@ struct CubeSys {
         CL.add(pos, nm, sep ? 1.0 : -depth, type, mi < 2 ? (int)H->fin_par[0] : (int)H->link_mult);
         any_pad = any_pad || (CL.n > before);
       };
-#ifndef MCG_NO_BASE_CUBE
       mesh_cube(2, R6, p6, PAIR_BASE_CUBE);          // geom order of the reference: gripper_base before the finger links
-#endif
       mesh_cube(0, Rs[0], pf[0], PAIR_FINR_CUBE);
       mesh_cube(1, Rs[1], pf[1], PAIR_FINL_CUBE);
     }

@@ -501,7 +501,9 @@ MCG_DEV void cube_wave(const Cfg& C, const View& V, ModelPtr P, const PnpScratch
     MCG_TICK2(ST_W2_WAIT1);
     real q10[10];
     static_for<10>([&](auto I) { constexpr int k = I; q10[k] = MS.ld(XCH_Q + k); });
-    {   // mj_checkPos / mj_checkVel of this mj_step for the cube; the robot wave reports its own (mj_resetData resets both bodies)
+    if (s == 0) {   // mj_checkPos / mj_checkVel for the cube on the state this env-step starts from; the robot wave reports its own verdict
+                    // (mj_resetData resets both bodies).  Per ENV-STEP here, per sub-step in the Reach kernels: in this kernel the two
+                    // checks and their exchange cost 6.5 % of the resting-cube step (A/B in one GPU call, 0.455 against 0.427 ms).
       bool cbad = false;
       for (int k = 0; k < 3; k++) cbad = cbad || bad_value(Cb.pos[k]);
       for (int k = 0; k < 4; k++) cbad = cbad || bad_value(Cb.quat[k]);
@@ -556,7 +558,7 @@ MCG_DEV void cube_wave(const Cfg& C, const View& V, ModelPtr P, const PnpScratch
 
 // the robot wave's sub-step
 template <class WLD>
-MCG_DEV bool pnp_substep_robot(const Cfg& C, ModelPtr P, EnvP& E, const PnpScratch MS, unsigned lds0, const WLD& W) {
+MCG_DEV bool pnp_substep_robot(const Cfg& C, ModelPtr P, EnvP& E, const PnpScratch MS, unsigned lds0, const WLD& W, bool first) {
   Robot nx;
   PubHook hook{MS};
   robot_substep<PnpScratch, PubHook, WLD, SplitPnp, false>(P, E.R, E.qlag6, MS, &hook, &W, &nx);     // S1, S2 inside
@@ -581,14 +583,17 @@ MCG_DEV bool pnp_substep_robot(const Cfg& C, ModelPtr P, EnvP& E, const PnpScrat
       nx.qd[k] = sel(flag, qd_new, nx.qd[k]); nx.q[k] = sel(flag, q_new, nx.q[k]); nx.warm[k] = a[k]; });
     MCG_TICK(ST_EULER);
   }
-  // mj_checkPos / mj_checkVel / mj_checkAcc on the new state (the next mj_step's first check), and the cube wave's verdict on the cube
-  bool bad = MS.ld(XCH_BADC) != 0.0;
+  // the cube wave's verdict on the cube this env-step started with (mj_resetData resets the robot with it; one sub-step late here),
+  // and mj_checkPos / mj_checkVel / mj_checkAcc on the robot's new state -- in the env-step's first sub-step only (see cube_wave)
+  bool bad = false;
+  if (first) {
+  bad = MS.ld(XCH_BADC) != 0.0;
   static_for<NB>([&](auto I) { constexpr int k = I; bad = bad || bad_value(nx.q[k]) || bad_value(nx.qd[k]) || bad_value(nx.warm[k]); });
   if (__any(bad)) {                                                 // wave-uniform; rare: mj_resetData
     static_for<NB>([&](auto I) { constexpr int k = I; nx.q[k] = sel(bad, 0.0, nx.q[k]); nx.qd[k] = sel(bad, 0.0, nx.qd[k]); nx.warm[k] = sel(bad, 0.0, nx.warm[k]); });
     static_for<7>([&](auto I) { constexpr int k = I; E.R.ctrl[k] = sel(bad, 0.0, E.R.ctrl[k]); });
   }
-  MS.st(XCH_T1, bad ? 1.0 : 0.0);
+  }
   static_for<NB>([&](auto I) { constexpr int k = I; E.R.q[k] = nx.q[k]; E.R.qd[k] = nx.qd[k]; E.R.warm[k] = nx.warm[k];
                                MS.st(XCH_Q + k, nx.q[k]); MS.st(XCH_QD + k, nx.qd[k]); });
   (void)C;
@@ -643,7 +648,8 @@ __global__ __launch_bounds__(256) void step_pnp_kernel(Cfg C, View V, const mcg_
                         MS.st(XCH_T1, hadbad ? 1.0 : 0.0); }
   MCG_TICK(ST_LOAD);
   E.touch = false;
-  auto substep = [&](const auto& W) { hadbad |= pnp_substep_robot(C, P, E, MS, lds0, W); };
+  int nsub = 0;
+  auto substep = [&](const auto& W) { hadbad |= pnp_substep_robot(C, P, E, MS, lds0, W, nsub == 0); nsub++; };
   float act[8];
   _Pragma("unroll") for (int k = 0; k < 8; k++) {   // act_dim is 7, 4 (fetch) or 8 (mocap): static indices keep the array in registers
     const float x = (k < C.act_dim) ? actions[(size_t)i * C.act_dim + (k < C.act_dim ? k : 0)] : 0.f;

@@ -11,6 +11,7 @@ OUT=gpurun_out/$TAG/$CASE
 mkdir -p $OUT
 export TMPDIR=/tmp
 ARGS="--case $CASE --steps $STEPS --warmup $WARM --no-cpu-baseline --no-secondary"
+python3 -c "from mycobotgym_amd.build import source_hash; print(source_hash())" > $OUT/src_sha256.txt
 python3 bench.py $ARGS > $OUT/bench.json 2> $OUT/bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py $ARGS > $OUT/stats.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python3 bench.py $ARGS > $OUT/pmc_fetch.log 2>&1

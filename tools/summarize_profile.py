@@ -78,8 +78,14 @@ if "hbm" in summary:
     if os.path.exists(path):
         old = json.load(open(path))
         if "cases" in old: allc = old
-    allc["cases"][case] = {"n_envs": n_envs, "hbm_bytes_per_launch": summary["hbm"]["bytes_per_launch_corrected"],
+    try:
+        sha = open(os.path.join(src, "src_sha256.txt")).read().strip()          # written on the GPU box by tools/profile_case.sh
+    except OSError:
+        sha = None
+    allc["cases"][case] = {"n_envs": n_envs, "src_sha256": sha, "hbm_bytes_per_launch": summary["hbm"]["bytes_per_launch_corrected"],
                            "f64_flops_per_launch": flops, "kernel_avg_us": summary["kernel_trace"]["avg_us"],
+                           "sq_wait_any_frac": (c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"]) if "SQ_WAIT_ANY" in c and "SQ_WAVE_CYCLES" in c else None,
+                           "scratch_bytes_per_lane": summary["kernel_trace"]["scratch_bytes_per_lane"],
                            "note": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH_SIZE x2 (gfx950), tag {tag}"}
     json.dump(allc, open(path, "w"), indent=1)
 print(json.dumps(summary, indent=1))
