@@ -155,6 +155,9 @@ def roofline(case, n, kernel_ms):
     src = ("profiles/pmc_latest.json[" + case + "]: " + pj.get("note", "")) if pj else stale
     out = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
            "traffic": pj.get("hbm_bytes_per_launch") if pj else None, "traffic_source": src,
+           "traffic_over_algorithmic": (pj["hbm_bytes_per_launch"] / algo) if pj else None,
+           "sq_wait_any_frac": pj.get("sq_wait_any_frac") if pj else None,
+           "scratch_bytes_per_lane": pj.get("scratch_bytes_per_lane") if pj else None,
            "kernel": "step_reach_kernel" if task == "reach" else "step_pnp_kernel", "kernel_ms": kernel_ms,
            "algorithmic_bytes_per_launch": algo,
            "note": "nominal roofline only: with all sub-steps fused the path moves ~1 KB per env-step and is bound by "
@@ -275,6 +278,24 @@ def main():
                 "steps": steps, "warmup": warmup, "physics_substeps_per_sec": v * sub,
                 "roofline": roofline(case, n, kernel_ms) if rank == 0 else None, "episode_stats_last_step": stats}
 
+    def api_step_cost(case, steps):
+        """The packaged Gymnasium-style step() (fresh copies of every output, info dict) against the raw launch: what a caller of
+        MyCobotVecEnv.step pays on top of the kernel."""
+        task, controller, dr, grasp = CASES[case]
+        envs = MyCobotVecEnv(n, has_object=task == "pnp", controller_type=controller, reward_type="dense", device=dev, seed=0)
+        envs.reset(seed=0)
+        g = torch.Generator(device=dev); g.manual_seed(7)
+        pool = torch.rand(16, n, envs.action_dim, device=dev, generator=g) * 2 - 1
+        out = {}
+        for name, fn in (("raw_step_async_ms", lambda a: envs.step_async(a)), ("step_copy_false_ms", lambda a: envs.step(a, copy=False)),
+                         ("step_ms", lambda a: envs.step(a))):
+            for t in range(20): fn(pool[t % 16])
+            torch.cuda.synchronize(dev); t0 = time.perf_counter()
+            for t in range(steps): fn(pool[t % 16])
+            torch.cuda.synchronize(dev); out[name] = (time.perf_counter() - t0) / steps * 1e3
+        envs.close()
+        return out
+
     main_e = entry(case, K, W, args.lockstep)
     task, controller = CASES[case][0], CASES[case][1]
     out = {
@@ -295,6 +316,7 @@ def main():
         out["lockstep"] = {k: v for k, v in entry(case, K, W, True).items() if k != "roofline"}
         out["secondary"] = [entry(c, k2 if c != "pnp-joint-grasp" else min(k2, 40), w2 if c != "pnp-joint-grasp" else 5, False)
                             for c in DEFAULT_SECONDARY]
+        out["api_step_cost"] = api_step_cost(case, 200)
     if rank == 0:
         if not args.no_cpu_baseline and world == 1 and task == "reach":
             out["cpu_baseline"] = cpu_baseline(controller)

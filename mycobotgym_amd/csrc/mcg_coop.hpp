@@ -102,6 +102,19 @@ struct CoopClocks {};
 #define COOP_COUNT(k, v) do {} while (0)
 #endif
 
+MCG_DEV void coop_flush_clocks(const CoopClocks& CK) {
+#ifdef MCG_STAGE_CLOCKS
+  if ((threadIdx.x & 63) == 0) {
+    if (CK.n[0]) atomicAdd(&g_wg_stat[(blockIdx.x & 4095) * 4 + 1], (unsigned long long)CK.n[0]);
+    for (int k = 0; k < ST_CO_IDLE - ST_CO_SETUP; k++) if (CK.t[k]) atomicAdd(&g_stage_clocks[ST_CO_SETUP + k], CK.t[k]);
+    const int slot[8] = {CN_COUPLED, CN_COUPLED_IT, CN_COUPLED_LS, CN_COOP_ROWS, CN_COOP_LSEVAL, CN_COOP_LONG, CN_COOP_CAP, CN_COOP_12};
+    for (int k = 0; k < 8; k++) if (CK.n[k]) atomicAdd(&g_stage_clocks[ST_COUNT + slot[k]], (unsigned long long)CK.n[k]);
+  }
+#else
+  (void)CK;
+#endif
+}
+
 constexpr unsigned coop_row_mask(const Pattern& P, int i) { unsigned m = 0; for (int j = 0; j <= i; j++) m |= P.nz[i][j] ? (1u << j) : 0u; return m; }
 
 // One environment's coupled solve, by the 32 active lanes of the calling wave.  lds0 = slot 0 of lane 0 of the workgroup's array,
@@ -685,23 +698,44 @@ MCG_DEV void coop_solve12(ModelPtr Pm, LdsPtr lds0, int e, LdsPtr ws, int ncon, 
   COOP_TICK(ST_CO_OUT);
 }
 
-// All four waves call this between barriers S4 and S5 with the same `mask` (bit l: lane l's environment is flagged): wave w solves
-// the flagged environments number w, w + 4, ...  Out of line: one copy of the code, its own register allocation.
-__device__ __noinline__ void coop_phase(unsigned long long model_bits, unsigned lds_base, unsigned mask, int wave) {
+// ---- the cooperative phase.  All four waves run it between barriers S4 and S5 with the same `mask` (bit l: lane l's environment is
+// flagged).  The flagged environments are handed out one at a time from a counter in LDS (solves differ by a factor of ten in their Newton
+// iteration counts: a fixed split leaves three waves waiting for the unluckiest); the robot wave clears the counter before S4.
+//
+// Where the code lives decides the kernel's HBM traffic.  An out-of-line function saves and restores every callee-saved register it
+// uses -- 218 dwords a lane for this one -- on EVERY call: with one call per wave per coupled sub-step that was 56 KB per wave-call,
+// 133 KB of scratch traffic per env-step of the scripted grasp (98x the algorithmic bytes; rocprofv3 PMC, profiles/r03v).  So the
+// common shape (18 dofs, up to 64 rows) is INLINED into the kernel's cube-wave and M / RNE-wave branches, which hold next to nothing
+// across the phase (the cube wave its cube, the others nothing), and only the robot wave -- whose live state would be spilled around
+// an inlined copy, and whose contact-free pipeline an inlined copy slowed in round 2 -- calls the out-of-line instance; the rare shapes
+// (more than nine contacts, the opt-in 12-dof routing) are out of line for everyone.  Scripted grasp: 98x -> 3.1x the algorithmic bytes.
+// (Both other placements were measured in the same GPU calls: cube wave and M / RNE waves as out-of-line per-env-step functions with
+// the phase inlined into them -- 4.8x, but the resting-cube step 0.436 -> 0.456 ms; only the cube wave out of line -- 2.9x, 0.454 ms.)
+static __device__ __noinline__ void coop_solve_rare(unsigned long long model_bits, unsigned lds_base, int e_, int wave, int ncon_, int kind_) {
   const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)model_bits), hi = __builtin_amdgcn_readfirstlane((unsigned)(model_bits >> 32));
   const ModelPtr P = (ModelPtr)(((unsigned long long)hi << 32) | lo);
   const LdsPtr lds0 = (LdsPtr)(uintptr_t)__builtin_amdgcn_readfirstlane(lds_base);
-  const unsigned m = __builtin_amdgcn_readfirstlane(mask);
-  const int w = __builtin_amdgcn_readfirstlane(wave);
+  const int e = __builtin_amdgcn_readfirstlane(e_), w = __builtin_amdgcn_readfirstlane(wave);
+  const int ncon = __builtin_amdgcn_readfirstlane(ncon_), kind = __builtin_amdgcn_readfirstlane(kind_);
   const LdsPtr ws = lds0 + COOP_WS_ROW * PNP_LANES + w * COOP_WS_DOUBLES;
   CoopClocks CK;
 #ifdef MCG_STAGE_CLOCKS
   for (int k = 0; k < ST_CO_IDLE - ST_CO_SETUP; k++) CK.t[k] = 0;
   for (int k = 0; k < 8; k++) CK.n[k] = 0;
 #endif
-  // The flagged environments are handed out one at a time from a counter in LDS (solves differ by a factor of ten in their Newton
-  // iteration counts: a fixed split leaves three waves waiting for the unluckiest).  The counter starts at zero: the robot wave
-  // clears it before barrier S4, and it is only touched between S4 and S5.
+  const bool two = 10 + 6 * ncon <= 2 * PNP_LANES;
+  if (kind == 1) { if (two) coop_solve12<2>(P, lds0, e, ws, ncon, CK); else coop_solve12<COOP_SETS>(P, lds0, e, ws, ncon, CK); }
+  else coop_solve<COOP_SETS>(P, lds0, e, ws, ncon, CK);
+  coop_flush_clocks(CK);
+}
+
+MCG_DEV void coop_phase_body(ModelPtr P, LdsPtr lds0, unsigned m, int w) {
+  const LdsPtr ws = lds0 + COOP_WS_ROW * PNP_LANES + w * COOP_WS_DOUBLES;
+  CoopClocks CK;
+#ifdef MCG_STAGE_CLOCKS
+  for (int k = 0; k < ST_CO_IDLE - ST_CO_SETUP; k++) CK.t[k] = 0;
+  for (int k = 0; k < 8; k++) CK.n[k] = 0;
+#endif
   typedef __attribute__((address_space(3))) unsigned* LdsCtr;
   const LdsCtr ctr = (LdsCtr)(lds0 + COOP_CTR_SLOT * PNP_LANES);
   const int total = __popc(m);
@@ -715,18 +749,17 @@ __device__ __noinline__ void coop_phase(unsigned long long model_bits, unsigned 
     const int e = __builtin_ctz(mm);
     const int ncon = __builtin_amdgcn_readfirstlane((int)lds0[XCH_NCON * PNP_LANES + e]);
     const int kind = __builtin_amdgcn_readfirstlane((int)lds0[XCH_FLAG * PNP_LANES + e]);
-    const bool two = 10 + 6 * ncon <= 2 * PNP_LANES;                                  // up to 9 contacts: 64 rows
-    if (kind == 1) { if (two) coop_solve12<2>(P, lds0, e, ws, ncon, CK); else coop_solve12<COOP_SETS>(P, lds0, e, ws, ncon, CK); }
-    else { if (two) coop_solve<2>(P, lds0, e, ws, ncon, CK); else coop_solve<COOP_SETS>(P, lds0, e, ws, ncon, CK); }
+    if (kind != 1 && 10 + 6 * ncon <= 2 * PNP_LANES) coop_solve<2>(P, lds0, e, ws, ncon, CK);      // up to 9 contacts: 64 rows
+    else coop_solve_rare((unsigned long long)P, (unsigned)(uintptr_t)lds0, e, w, ncon, kind);
   }
-#ifdef MCG_STAGE_CLOCKS
-  if ((threadIdx.x & 63) == 0) {
-    if (CK.n[0]) atomicAdd(&g_wg_stat[(blockIdx.x & 4095) * 4 + 1], (unsigned long long)CK.n[0]);
-    for (int k = 0; k < ST_CO_IDLE - ST_CO_SETUP; k++) if (CK.t[k]) atomicAdd(&g_stage_clocks[ST_CO_SETUP + k], CK.t[k]);
-    const int slot[8] = {CN_COUPLED, CN_COUPLED_IT, CN_COUPLED_LS, CN_COOP_ROWS, CN_COOP_LSEVAL, CN_COOP_LONG, CN_COOP_CAP, CN_COOP_12};
-    for (int k = 0; k < 8; k++) if (CK.n[k]) atomicAdd(&g_stage_clocks[ST_COUNT + slot[k]], (unsigned long long)CK.n[k]);
-  }
-#endif
+  coop_flush_clocks(CK);
+}
+
+// the robot wave's instance
+static __device__ __noinline__ void coop_phase(unsigned long long model_bits, unsigned lds_base, unsigned mask, int wave) {
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)model_bits), hi = __builtin_amdgcn_readfirstlane((unsigned)(model_bits >> 32));
+  const ModelPtr P = (ModelPtr)(((unsigned long long)hi << 32) | lo);
+  coop_phase_body(P, (LdsPtr)(uintptr_t)__builtin_amdgcn_readfirstlane(lds_base), __builtin_amdgcn_readfirstlane(mask), __builtin_amdgcn_readfirstlane(wave));
 }
 
 }  // namespace mcg

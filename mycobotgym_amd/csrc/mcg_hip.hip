@@ -486,7 +486,9 @@ MCG_DEV void cube_from_lds(const PnpScratch MS, Cube& Cb) {
 MCG_DEV unsigned flagged_lanes(const PnpScratch MS) { return (unsigned)__ballot(MS.ld(XCH_FLAG) != 0.0); }      // the same in all four waves
 
 // the cube wave's whole env-step
-MCG_DEV void cube_wave(const Cfg& C, const View& V, ModelPtr P, const PnpScratch MS, unsigned lds0, int i, int total) {
+struct CubeWaveArgs { real qpos0_cube[7]; unsigned long long* cnt; int coop12; };
+// (inlined into the kernel, the cooperative phase inlined into it: the wave's own state across the phase is the cube, 30 numbers)
+MCG_DEV void cube_wave(const CubeWaveArgs& C, const View& V, ModelPtr P, const PnpScratch MS, unsigned lds0, int i, int total) {
   const bool robot_only_ok = C.coop12 != 0;
   Cube Cb; real dr[2], qlag7[7];
   for (int k = 0; k < 3; k++) Cb.pos[k] = V.qpos(12 + k, i);
@@ -515,7 +517,7 @@ MCG_DEV void cube_wave(const Cfg& C, const View& V, ModelPtr P, const PnpScratch
         for (int k = 0; k < 6; k++) { Cb.vel[k] = sel(reset, 0.0, Cb.vel[k]); Cb.warm[k] = sel(reset, 0.0, Cb.warm[k]); }
       }
       MS.st(XCH_BADC, cbad ? 1.0 : 0.0);
-      count_event(C, 1, cbad);
+      if (__any(cbad)) { if (cbad && C.cnt) atomicAdd(C.cnt + 1, 1ull); }
     }
     CubeSys<PnpScratch> CS(MS, Cb, dr);
     CS.cnt = C.cnt;
@@ -540,7 +542,7 @@ MCG_DEV void cube_wave(const Cfg& C, const View& V, ModelPtr P, const PnpScratch
     __syncthreads();                                                // S4: end of the lane-parallel part
     MCG_TICK2(ST_W2_WAIT2);
     if (coupled) {
-      coop_phase((unsigned long long)P, lds0, flagged_lanes(MS), 1);
+      coop_phase_body(P, (LdsPtr)(uintptr_t)lds0, __builtin_amdgcn_readfirstlane(flagged_lanes(MS)), 1);
       MCG_TICK2(ST_COUPLED);
       __syncthreads();                                              // S5
       MCG_TICK2(ST_CO_IDLE);
@@ -601,13 +603,14 @@ MCG_DEV bool pnp_substep_robot(const Cfg& C, ModelPtr P, EnvP& E, const PnpScrat
 }
 
 // the helper / RNE waves of the four-wave PickAndPlace kernel: same barriers as the cube wave
+// (inlined into the kernel: these waves hold nothing across a sub-step, so the inlined cooperative phase spills nothing)
 MCG_DEV void pnp_side_wave(ModelPtr P, const PnpScratch MS, unsigned lds0, int total, bool rne) {
   for (int s = 0; s < total; s++) {
     if (rne) rne_substep<SplitPnp>(P, MS); else helper_substep<SplitPnp>(P, MS);      // S1, S2 inside
     __syncthreads();                                                // S4
     const unsigned mask = flagged_lanes(MS);
     if (mask != 0u) {
-      coop_phase((unsigned long long)P, lds0, mask, rne ? 3 : 2);
+      coop_phase_body(P, (LdsPtr)(uintptr_t)lds0, __builtin_amdgcn_readfirstlane(mask), rne ? 3 : 2);
       __syncthreads();                                              // S5
     }
   }
@@ -631,8 +634,11 @@ __global__ __launch_bounds__(256) void step_pnp_kernel(Cfg C, View V, const mcg_
   if constexpr (DUAL) {
     if (threadIdx.x >= 64) {
       const int total = (CONTROLLER == MCG_CTRL_IK ? C.control_steps : 1) * C.frame_skip;
-      if (threadIdx.x < 128) cube_wave(C, V, P, MS, lds0, i, total);
-      else pnp_side_wave(P, MS, lds0, total, threadIdx.x >= 192);
+      if (threadIdx.x < 128) {
+        CubeWaveArgs A; for (int k = 0; k < 7; k++) A.qpos0_cube[k] = C.qpos0_cube[k];
+        A.cnt = C.cnt; A.coop12 = C.coop12;
+        cube_wave(A, V, P, MS, lds0, i, total);
+      } else pnp_side_wave(P, MS, lds0, total, threadIdx.x >= 192);
       return;
     }
   }

@@ -253,6 +253,7 @@ def specialize(m: dict, weld_rule: str = "common", contact_rule: str = "mujoco")
         hull = np.zeros((8, 26, 3)); box = np.zeros((8, 6)); ldiag = np.zeros((8, 2)); mult = set()
         dir13 = np.array([(1, 0, 0), (0, 1, 0), (0, 0, 1), (1, 1, 0), (1, -1, 0), (1, 0, 1), (1, 0, -1), (0, 1, 1), (0, 1, -1), (1, 1, 1), (1, 1, -1), (1, -1, 1), (1, -1, -1)], dtype=float)      # MCG_DIR13 (csrc/mcg_cube.hpp), DIR13 (oracle/mco_collision.c)
         lext = np.zeros((8, 13, 2))
+        mesh_sigs = set()
         for p, nm in enumerate(names):
             gs = [g for g in range(m["ngeom"]) if m["geom_type"][g] == 7 and m["geom_mesh"][g] == nm
                   and m["geom_contype"][g] and m["geom_conaffinity"][g]]
@@ -270,7 +271,12 @@ def specialize(m: dict, weld_rule: str = "common", contact_rule: str = "mujoco")
             mult.add(len(gs))
             condim, fri, solref, solimp = mix_contact(m, gt, g)
             assert condim == 3
+            # ONE row of contact_par serves all eight meshes (and, for the gripper base against the cube, the finger-mesh row serves it
+            # too: csrc/mcg_cube.hpp): every mesh geom must mix to the same numbers, else the row of the last mesh would silently win
+            sig = (tuple(np.round(fri, 15)), tuple(np.round(solref, 15)), tuple(np.round(solimp, 15)), tuple(np.round(m["geom_friction"][g], 15)))
+            mesh_sigs.add(sig)
         assert len(mult) == 1
+        assert len(mesh_sigs) == 1, "the arm-side mesh geoms differ in friction / solref / solimp: one contact_par row per mesh would be needed"
         cp.append(np.concatenate([_solparams(solref, solimp, h), fri]))
         out["contact_par"] = np.array(cp)    # + row 5: table - arm mesh (condim 3)
         out["link_hull"] = hull; out["link_hull_box"] = box; out["link_diag"] = ldiag; out["link_ext"] = lext; out["link_mult"] = float(mult.pop())
