@@ -115,6 +115,12 @@ MCG_DEV void coop_flush_clocks(const CoopClocks& CK) {
 #endif
 }
 
+#ifdef MCG_COOP_DEBUG
+// development aid: the first solve of every environment of workgroup 0 leaves its first Newton system, candidate and result here
+__device__ double g_coop_dbg[32 * 512];
+__device__ int g_coop_dbg_done[32];
+#endif
+
 constexpr unsigned coop_row_mask(const Pattern& P, int i) { unsigned m = 0; for (int j = 0; j <= i; j++) m |= P.nz[i][j] ? (1u << j) : 0u; return m; }
 
 // One environment's coupled solve, by the 32 active lanes of the calling wave.  lds0 = slot 0 of lane 0 of the workgroup's array,
@@ -345,6 +351,12 @@ MCG_DEV void coop_solve(ModelPtr Pm, LdsPtr lds0, int e, LdsPtr ws, int ncon, Co
     MCG_FENCE();
     _Pragma("unroll") for (int j = 0; j < COOP_NV; j++) H[j] += H0[j];
     g += g0;
+#ifdef MCG_COOP_DEBUG
+    const bool dbg = blockIdx.x == 0 && it == 0 && g_coop_dbg_done[e] == 0;
+    if (dbg && L < COOP_NV && threadIdx.x % 64 < 32) { double* o = g_coop_dbg + e * 512;
+      for (int j = 0; j < COOP_NV; j++) o[L * COOP_NV + j] = H[j];
+      o[324 + L] = g; o[360 + L] = al; }
+#endif
     MCG_TICK_PIN(H, COOP_NV);
     COOP_TICK(ST_CO_ASM);
     // (c) H = L D L^T.  Lane i ends with the UNSCALED column entries H[i][k] = L[i][k] D_k in H[k] and the scaled L[i][k] in Lr[k]
@@ -381,12 +393,19 @@ MCG_DEV void coop_solve(ModelPtr Pm, LdsPtr lds0, int e, LdsPtr ws, int ncon, Co
       acc = fma(-U[j], xj, acc);
       xl = sel(i == j, xj, xl);
       _Pragma("unroll") for (int s = 0; s < NSETS; s++) rx[s] = fma(J[s][j], xj, rx[s]); });
+#ifdef MCG_COOP_DEBUG
+    if (dbg && L < COOP_NV && threadIdx.x % 64 < 32) g_coop_dbg[e * 512 + 342 + L] = xl;
+#endif
     MCG_TICK_PIN(rx, NSETS);
     COOP_TICK(ST_CO_SOLVE);
     // (e) does the candidate keep the assumed active set?
     bool same = true;
     _Pragma("unroll") for (int s = 0; s < NSETS; s++) same = same && ((unsigned)__ballot(Dr[s] > 0 && rx[s] < 0) == act[s]);
     COOP_TICK(ST_CO_CHECK);
+#ifdef MCG_COOP_DEBUG
+    const bool dbt = blockIdx.x == 0 && g_coop_dbg_done[e] == 0 && it < 8 && threadIdx.x % 64 == 0;
+    if (dbt) { double* o = g_coop_dbg + e * 512 + 400 + it * 8; o[0] = __popc(act[0]) + (NSETS > 1 ? __popc(act[1 % NSETS]) : 0); o[1] = same; o[2] = 0; o[3] = -1; }
+#endif
     if (same || it < MCG_COOP_FULL_STEPS) {           // uniform.  A consistent candidate is the minimiser; the first iterations step to x anyway
       al = xl;
       if (same) break;
@@ -417,319 +436,495 @@ MCG_DEV void coop_solve(ModelPtr Pm, LdsPtr lds0, int e, LdsPtr ws, int ncon, Co
     real lo = 0, hi = 2, sl;
     const bool beyond = dphi(hi, sl) < 0;
     real alp = 1.0;
+#ifdef MCG_COOP_DEBUG
+    if (dbt && it == 1) { double* o = g_coop_dbg + e * 512 + 464 + 8 * 3; o[0] = 2; o[1] = beyond; o[2] = sl; }
+#endif
     for (int b = 0; b < 8 && !beyond; b++) {                                   // (uniform)
       const real f = dphi(alp, sl);
+#ifdef MCG_COOP_DEBUG
+      if (dbt && it == 1) { double* o = g_coop_dbg + e * 512 + 464 + b * 3; o[0] = alp; o[1] = f; o[2] = sl; }
+#endif
       const bool neg = f < 0;
       lo = sel(neg, alp, lo); hi = sel(neg, hi, alp);
       const real nwt = alp - f / sl;
-      const real nx = sel(nwt > lo && nwt < hi, nwt, 0.5 * (lo + hi));
+      const real nx = sel(nwt >= lo && nwt <= hi, nwt, 0.5 * (lo + hi));      // closed: AT the root the step is zero and nwt == alp == lo or hi
       const bool moved = fabs(nx - alp) > 1e-10 * fmax(1.0, fabs(alp));      // on the root's own linear piece Newton stays put; the step
       alp = nx;                                                               // length needs no more: the LAST iteration is a full step
       if (!moved) break;
     }
     const real alpha = sel(beyond, 2.0, alp);
+#ifdef MCG_COOP_DEBUG
+    if (dbt) { double* o = g_coop_dbg + e * 512 + 400 + it * 8; o[2] = 1; o[3] = alpha; o[4] = s0; o[5] = quad; }
+#endif
     al = fma(alpha, pl, al);
     MCG_TICK_PIN(&al, 1);
     COOP_TICK(ST_CO_LS);
   }
+#ifdef MCG_COOP_DEBUG
+  if (blockIdx.x == 0 && g_coop_dbg_done[e] == 0 && threadIdx.x % 64 < 32) {
+    if (L < COOP_NV) g_coop_dbg[e * 512 + 380 + L] = al;
+    __builtin_amdgcn_s_waitcnt(0);
+    if (L == 0) g_coop_dbg_done[e] = 1;
+  }
+#endif
   // ---- hand the accelerations back: robot part where the warm start was, cube part in the cube's warm-start slots
   if (L < NB) ME.st(PUB_WARM + L, al);
   else if (L < COOP_NV) ME.st(XCH_CB + 13 + (L - NB), al);
   COOP_TICK(ST_CO_OUT);
 }
 
-// ---- robot-only variant (flag 1).  The environment's robot-reaching contacts are all against static geoms (table / ground - pad or arm
-// mesh): cube and robot decouple, the cube stays with the cube wave's lane-parallel solve, and the robot's 12 dofs are solved here with
-// the rows that have a robot part.  12 matrix rows fit one 16-lane DPP row: lane i and lane 16 + i both hold row i (the same arithmetic on
-// the same numbers), so EVERY broadcast of the factorisation and of the substitutions is a v_mov_b64_dpp row_newbcast within the row --
-// no v_readlane, no SGPR round trip.  Same iteration as coop_solve.
-constexpr int C12_WSTRIDE = 14;        // window row: D, D aref, J[12]
+// ---- TWO environments per wave (round 3, second half).  The 32-lane solve above leaves half of the wave's lanes unused and, in its
+// matrix phases, 18 of 64.  Here the cube wave and the M / RNE waves keep their upper 32 lanes alive for the cooperative phase (they are
+// masked off everywhere else) and every wave solves two flagged environments in lock-step: env A in lanes 0-31, env B in lanes 32-63,
+// the same instruction stream, per-half state.  What had to change for that:
+//   * nothing may be wave-uniform per environment: no v_readlane.  The factorisation runs in ONE 16-lane DPP row per environment on the
+//     leading 16 x 16 block, every broadcast a v_mov_b64_dpp row_newbcast; rows 16 and 17 (the cube's last two angular dofs) are carried
+//     TRANSPOSED -- lane j holds H[16][j] and H[17][j] -- and their 2 x 2 corner replicated in every lane, so their updates need only the
+//     broadcasts the block already makes.  (Both DPP rows of a half hold the same numbers: nothing to mask.)
+//   * vectors every row needs (the iterate, the candidate) go through 18 doubles of LDS instead of 18 v_readlane pairs;
+//   * 32-lane sums: four DPP steps and one v_permlane16_swap (gfx950) instead of two v_readlane.
+// And the assembly H = H0 + J~^T J~, g = g0 + J~^T aref~ (rows pre-scaled by sqrt(D): J~ = sqrt(D) J) is a matrix product: the active
+// rows of a window go to the MATRIX CORES, four rows per v_mfma_f64_16x16x4_f64 -- A = B = the window's columns 0..15 for the leading
+// block, columns 16..18 (dofs 16, 17 and aref~) for the border and the corner: three instructions per four rows and two LDS reads per
+// lane, against ~80 VALU / DPP issue slots per row before (tools/microbench/mfma_f64.hip: operand and result layout, 80-90 clocks per
+// instruction).
+typedef double coop_vd4 __attribute__((ext_vector_type(4)));
+typedef double coop_vd2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) coop_vd2* LdsPtr2;
+constexpr int CP_WS = COOP_WS_DOUBLES / 2;                    // per environment
+constexpr int CP_N = 16;                                       // the leading block
+constexpr int CP_MSTRIDE = 18, CP_VOFF = CP_N * CP_MSTRIDE, CP_COFF = CP_VOFF + 3 * CP_N, CP_AOFF = CP_COFF + 8;
+static_assert(CP_AOFF + COOP_NV <= CP_WS && (COOP_WIN - 1) * COOP_WSTRIDE + 32 <= CP_WS, "pair workspace");
+static_assert(CP_VOFF % 2 == 0 && CP_COFF % 2 == 0 && CP_AOFF % 2 == 0 && COOP_WSTRIDE % 2 == 0 && CP_MSTRIDE % 2 == 0 && CP_WS % 2 == 0, "16-byte LDS accesses");
+
+MCG_DEV real coop_sum32h(real v) {     // sum over the 32 lanes of each half of the wave, in every lane of the half
+  v = coop_sum16(v);
+  // the partner row's sum through the LDS crossbar (ds_bpermute, no memory touched)
+  const int peer = (int)(((threadIdx.x & 63) ^ 16) << 2);
+  const int lo = __builtin_amdgcn_ds_bpermute(peer, __double2loint(v)), hi = __builtin_amdgcn_ds_bpermute(peer, __double2hiint(v));
+  return v + __hiloint2double(hi, lo);
+}
+MCG_DEV coop_vd2 coop_ld2(LdsPtr p) { return *(LdsPtr2)p; }
+MCG_DEV void coop_st2(LdsPtr p, real a, real b) { coop_vd2 v = {a, b}; *(LdsPtr2)p = v; }
+
+// eA, eB: the two environments' lanes (LDS columns); haveB false: one environment left, the upper half idles on a copy of A's data
 template <int NSETS>
-MCG_DEV void coop_solve12(ModelPtr Pm, LdsPtr lds0, int e, LdsPtr ws, int ncon, CoopClocks& CK) {
-  constexpr int NV = NB;
-  const int L = threadIdx.x & (PNP_LANES - 1);
+MCG_DEV void coop_solve_pair(ModelPtr Pm, LdsPtr lds0, LdsPtr wsw, int eA, int eB, int nconA, int nconB, bool haveB, CoopClocks& CK) {
+  constexpr int NV = COOP_NV, N = CP_N;
+  const int T = threadIdx.x & 63, hl = T & 31, l16 = T & 15, drow = T >> 4;
+  const bool up = T >= 32;
+  const int e = sel(up, eB, eA), ncon = sel(up, nconB, nconA);
+  const bool have = !up || haveB;
+  const int nconmax = nconA > nconB ? nconA : nconB;             // uniform
   const PnpScratch ME(lds0 + e);
-  COOP_COUNT(0, 1); COOP_COUNT(7, 1);
+  const LdsPtr ws = wsw + sel(up, CP_WS, 0);                     // this half's workspace; env A's is wsw, env B's wsw + CP_WS
+  COOP_COUNT(0, haveB ? 2 : 1);
 #ifdef MCG_STAGE_CLOCKS
   CK.last = __builtin_readcyclecounter();
 #endif
-  // pair numbers of the static geom - robot contacts, as CubeSys::derive forms them
-  real mu_tp[3], mu_tl[3], B_tp, B_tl;
-  {
-    ModelPtr Q = launder(Pm);
-    const real dr1 = ME.ld(XCH_DR + 1);
-    const real ft = Q->geom_friction0[0], fp = Q->geom_friction0[1] * dr1;
-    mu_tp[0] = mu_tp[1] = fmax(ft, fp); mu_tp[2] = Q->contact_par[PAIR_TABLE_PADR][12]; B_tp = Q->contact_par[PAIR_TABLE_PADR][1];
-    mu_tl[0] = mu_tl[1] = Q->contact_par[PAIR_TABLE_LINK0][10]; mu_tl[2] = 0; B_tl = Q->contact_par[PAIR_TABLE_LINK0][1];
-  }
+  // ---- the environment's cube and pair numbers
+  Cube Cb; real drs[2];
+  for (int k = 0; k < 3; k++) Cb.pos[k] = ME.ld(XCH_CB + k);
+  for (int k = 0; k < 4; k++) Cb.quat[k] = ME.ld(XCH_CB + 3 + k);
+  for (int k = 0; k < 6; k++) { Cb.vel[k] = ME.ld(XCH_CB + 7 + k); Cb.warm[k] = ME.ld(XCH_CB + 13 + k); }
+  drs[0] = ME.ld(XCH_DR); drs[1] = ME.ld(XCH_DR + 1);
+  CubeSys<PnpScratch> CS(ME, Cb, drs);
+  CS.pm_bits = (unsigned long long)Pm;
+  CS.derive(Pm);
   bool side_any[2] = {false, false};
-  for (int c = 0; c < ncon; c++) {
-    const int type = (int)ME.ld(LDS_CON + c * CON_STRIDE + 15);
-    side_any[0] = side_any[0] || type == PAIR_TABLE_PADR; side_any[1] = side_any[1] || type == PAIR_TABLE_PADL;
+  for (int c = 0; c < nconmax; c++) {
+    const int type = (int)ME.ld(LDS_CON + sel(c < ncon, c, 0) * CON_STRIDE + 15);
+    const bool in = c < ncon;
+    side_any[0] = side_any[0] || (in && (type == PAIR_PADR_CUBE || type == PAIR_TABLE_PADR || type == PAIR_FINR_CUBE));
+    side_any[1] = side_any[1] || (in && (type == PAIR_PADL_CUBE || type == PAIR_TABLE_PADL || type == PAIR_FINL_CUBE));
   }
-  real tc[10][6];                      // twist columns about the world origin
+  real tc[10][6];
   _Pragma("unroll") for (int j = 0; j < 10; j++) {
     real ax[3], d[3], v[3];
-    _Pragma("unroll") for (int k = 0; k < 3; k++) { ax[k] = ME.ld(LDS_WJ + j * 6 + k); d[k] = ME.ld(LDS_WJ + j * 6 + 3 + k); }
+    _Pragma("unroll") for (int k = 0; k < 3; k++) { ax[k] = ME.ld(LDS_WJ + j * 6 + k); d[k] = ME.ld(LDS_WJ + j * 6 + 3 + k) - Cb.pos[k]; }
     cross(d, ax, v);
     const bool ok = (j < 6) || side_any[(j - 6) >> 1];
     _Pragma("unroll") for (int k = 0; k < 3; k++) { tc[j][k] = sel(ok, v[k], 0.0); tc[j][3 + k] = sel(ok, ax[k], 0.0); }
   }
-  real qd[10];
-  _Pragma("unroll") for (int j = 0; j < 10; j++) qd[j] = ME.ld(XCH_QD + j);
+  real qd[NB], vc[6];
+  _Pragma("unroll") for (int j = 0; j < NB; j++) qd[j] = ME.ld(XCH_QD + j);
+  _Pragma("unroll") for (int k = 0; k < 6; k++) vc[k] = Cb.vel[k];
   COOP_TICK(ST_CO_SETUP);
-  // ---- rows (numbering as in coop_solve; the cube's own contacts get no row)
-  real J[NSETS][NV], Dr[NSETS], aref[NSETS];
+  // ---- rows, as in coop_solve, then scaled by sqrt(D): the cost is 1/2 sum min(0, J~ a - aref~)^2 and D never appears again
+  const int nsets = (10 + 6 * nconmax + PNP_LANES - 1) / PNP_LANES;          // uniform
+  real J[NSETS][NV], aref[NSETS];
   _Pragma("unroll") for (int s = 0; s < NSETS; s++) {
-    const int r = PNP_LANES * s + L;
-    const bool is_lim = r < 10;
-    const int jl = sel(is_lim, r, 0);
-    const real sD = ME.ld(PUB_SD + jl), al_ = ME.ld(PUB_AREF + jl);
-    const real sgn = sel(sD > 0, 1.0, sel(sD < 0, -1.0, 0.0));
-    const int rc = sel(is_lim, 0, r - 10);
-    const int c = sel(rc / 6 < MAXCON, rc / 6, MAXCON - 1), p = rc % 6;
-    const bool is_con = !is_lim && (rc / 6 < ncon);
-    const int b = LDS_CON + c * CON_STRIDE;
-    real pos[3], n[3], t1[3], t2[3];
-    _Pragma("unroll") for (int k = 0; k < 3; k++) { pos[k] = ME.ld(b + k); n[k] = ME.ld(b + 3 + k); t1[k] = ME.ld(b + 6 + k); t2[k] = ME.ld(b + 9 + k); }
-    const real Dc = ME.ld(b + 13), kterm = ME.ld(b + 14), ftype = ME.ld(b + 15);
-    MCG_FENCE();
-    const int type = sel(is_con, (int)ftype, 0);
-    const bool link = type >= PAIR_TABLE_LINK0 && type < PAIR_FINR_CUBE, tabp = (type == PAIR_TABLE_PADR || type == PAIR_TABLE_PADL);
-    const int side = sel(type == PAIR_TABLE_PADL, 1, 0);
-    const int lbody = sel(link, sel(type - PAIR_TABLE_LINK0 < 5, type - PAIR_TABLE_LINK0, 5), sel(tabp, 5, -1));
-    const int kf = p >> 1;
-    const real m = sel((p & 1), -1.0, 1.0) * sel(link, sel3(kf, mu_tl[0], mu_tl[1], mu_tl[2]), sel3(kf, mu_tp[0], mu_tp[1], mu_tp[2]));
-    const real Bc = sel(link, B_tl, B_tp);
-    const bool live = is_con && (link || tabp) && !(link && kf == 2);
-    real dlin[3], eang[3];
-    _Pragma("unroll") for (int k = 0; k < 3; k++) dlin[k] = n[k] + sel(kf == 0, m * t1[k], sel(kf == 1, m * t2[k], 0.0));
-    cross(pos, dlin, eang);
-    const real tau = sel(kf == 2, m, 0.0);
-    _Pragma("unroll") for (int k = 0; k < 3; k++) eang[k] = fma(tau, n[k], eang[k]);
-    real vel = 0;
-    _Pragma("unroll") for (int j = 0; j < 10; j++) {
-      const bool member = live && ((j < 6) ? (j <= lbody) : (tabp && ((j - 6) >> 1) == side));
-      const real dj = dlin[0] * tc[j][0] + dlin[1] * tc[j][1] + dlin[2] * tc[j][2] + eang[0] * tc[j][3] + eang[1] * tc[j][4] + eang[2] * tc[j][5];
-      J[s][j] = sel(member, dj, 0.0);                       // the robot geom is geom2 of a static pair: +
-      vel = fma(J[s][j], qd[j], vel);
+    _Pragma("unroll") for (int j = 0; j < NV; j++) J[s][j] = 0;
+    aref[s] = 0;
+    if (s < nsets) {
+      const int r = PNP_LANES * s + hl;
+      const bool is_lim = r < 10;
+      const int jl = sel(is_lim, r, 0);
+      const real sD = ME.ld(PUB_SD + jl), al = ME.ld(PUB_AREF + jl);
+      const real sgn = sel(sD > 0, 1.0, sel(sD < 0, -1.0, 0.0));
+      const int rc = sel(is_lim, 0, r - 10);
+      const int c = sel(rc / 6 < MAXCON, rc / 6, MAXCON - 1), p = rc % 6;
+      const bool is_con = !is_lim && (rc / 6 < ncon);
+      const int b = LDS_CON + c * CON_STRIDE;
+      real lev[3], n[3], t1[3], t2[3];
+      _Pragma("unroll") for (int k = 0; k < 3; k++) { lev[k] = ME.ld(b + k) - Cb.pos[k]; n[k] = ME.ld(b + 3 + k); t1[k] = ME.ld(b + 6 + k); t2[k] = ME.ld(b + 9 + k); }
+      const real Dc = ME.ld(b + 13), kterm = ME.ld(b + 14), ftype = ME.ld(b + 15);
+      MCG_FENCE();
+      const int type = sel(is_con, (int)ftype, 0);
+      const bool padc = type == PAIR_PADR_CUBE || type == PAIR_PADL_CUBE, finc = type >= PAIR_FINR_CUBE;
+      const bool link = type >= PAIR_TABLE_LINK0 && !finc, tabp = (type == PAIR_TABLE_PADR || type == PAIR_TABLE_PADL);
+      const bool has_cube = pair_has_cube(type);
+      const int side = sel((type == PAIR_PADL_CUBE || type == PAIR_TABLE_PADL || type == PAIR_FINL_CUBE), 1, 0);
+      const bool basec = type == PAIR_BASE_CUBE;
+      const bool finger = padc || (finc && !basec) || tabp;
+      const int lbody = sel(link, sel(type - PAIR_TABLE_LINK0 < 5, type - PAIR_TABLE_LINK0, 5), sel(finger || basec, 5, -1));
+      const real rsign = sel(has_cube, -1.0, 1.0);
+      real mu[3]; real Bc;
+      _Pragma("unroll") for (int k = 0; k < 3; k++)
+        mu[k] = sel(link, CS.mu_tl[k], sel(tabp, CS.mu_tp[k], sel(finc, CS.mu_mc[k], sel(padc, CS.mu_pc[k], CS.mu_tc[k]))));
+      Bc = sel(link, CS.B_tl, sel(tabp, CS.B_tp, sel(finc, CS.B_mc, sel(padc, CS.B_pc, CS.B_tc))));
+      const int kf = p >> 1;
+      const real m = sel((p & 1), -1.0, 1.0) * sel3(kf, mu[0], mu[1], mu[2]);
+      const bool absent = link && kf == 2;
+      real dlin[3], eang[3];
+      _Pragma("unroll") for (int k = 0; k < 3; k++) dlin[k] = n[k] + sel(kf == 0, m * t1[k], sel(kf == 1, m * t2[k], 0.0));
+      cross(lev, dlin, eang);
+      const real tau = sel(kf == 2, m, 0.0);
+      _Pragma("unroll") for (int k = 0; k < 3; k++) eang[k] = fma(tau, n[k], eang[k]);
+      const bool live = is_con && !absent;
+      _Pragma("unroll") for (int j = 0; j < 10; j++) {
+        const bool member = live && ((j < 6) ? (j <= lbody) : (finger && ((j - 6) >> 1) == side));
+        const real dj = dlin[0] * tc[j][0] + dlin[1] * tc[j][1] + dlin[2] * tc[j][2] + eang[0] * tc[j][3] + eang[1] * tc[j][4] + eang[2] * tc[j][5];
+        J[s][j] = sel(member, rsign * dj, 0.0);
+      }
+      _Pragma("unroll") for (int k = 0; k < 3; k++) {
+        J[s][12 + k] = sel(live && has_cube, dlin[k], 0.0);
+        J[s][15 + k] = sel(live && has_cube, CS.Rc[k] * eang[0] + CS.Rc[3 + k] * eang[1] + CS.Rc[6 + k] * eang[2], 0.0);
+      }
+      real vel = 0;
+      _Pragma("unroll") for (int j = 0; j < 10; j++) vel = fma(J[s][j], qd[j], vel);
+      _Pragma("unroll") for (int k = 0; k < 6; k++) vel = fma(J[s][12 + k], vc[k], vel);
+      real D = sel(live, Dc, 0.0), ar = sel(live, -Bc * vel - kterm, 0.0);
+      _Pragma("unroll") for (int j = 0; j < 10; j++) J[s][j] = sel(is_lim, sel(j == jl, sgn, 0.0), J[s][j]);
+      D = sel(is_lim, fabs(sD), D); ar = sel(is_lim, al, ar);
+      const real sd = sel(have && D > 0, sqrt(D), 0.0);            // (an idle half has no rows)
+      _Pragma("unroll") for (int j = 0; j < NV; j++) J[s][j] *= sd;
+      aref[s] = sd * ar;
     }
-    J[s][10] = J[s][11] = 0;
-    Dr[s] = sel(live, Dc, 0.0); aref[s] = sel(live, -Bc * vel - kterm, 0.0);
-    _Pragma("unroll") for (int j = 0; j < 10; j++) J[s][j] = sel(is_lim, sel(j == jl, sgn, 0.0), J[s][j]);
-    Dr[s] = sel(is_lim, fabs(sD), Dr[s]); aref[s] = sel(is_lim, al_, aref[s]);
   }
-  MCG_TICK_PIN(Dr, NSETS); MCG_TICK_PIN(aref, NSETS);
+  MCG_TICK_PIN(aref, NSETS);
   COOP_TICK(ST_CO_ROWS);
-  // ---- H0 = M + J_eq^T D J_eq and g0: lanes i and 16 + i hold row i (lanes 12..15 of a DPP row shadow row 11)
-  const int l16 = L & 15, i = sel(l16 < NV, l16, NV - 1);
-  real H0[NV], g0;
+  // ---- H0 and g0: lane j of each DPP row holds row j < 16 of the leading block; rows 16, 17 of H0 are the cube inertia's last two
+  // diagonal entries (uniform)
+  const int i = l16;
+  real H0[N], g0;
   {
     unsigned mE = 0, mM = 0;
-    static_for<NV>([&](auto I) { constexpr int k = I; mE = sel(i == k, coop_row_mask(PAT_E, k), mE); mM = sel(i == k, coop_row_mask(PAT_M, k), mM); });
-    real he[NV], hm[NV];
-    static_for<NV>([&](auto Jj) { constexpr int j = Jj;
-      const int slot = sel(i >= j, i * (i + 1) / 2 + j, j * (j + 1) / 2 + i);
+    static_for<NB>([&](auto I) { constexpr int k = I; mE = sel(i == k, coop_row_mask(PAT_E, k), mE); mM = sel(i == k, coop_row_mask(PAT_M, k), mM); });
+    const bool rob = i < NB;
+    const int ir = sel(rob, i, 0);
+    real he[NB], hm[NB];
+    static_for<NB>([&](auto Jj) { constexpr int j = Jj;
+      const int slot = sel(ir >= j, ir * (ir + 1) / 2 + j, j * (j + 1) / 2 + ir);
       he[j] = ME.ld(LDS_HEQ + slot); hm[j] = ME.ld(LDS_M + slot); });
-    g0 = ME.ld(PUB_G0 + i);
     MCG_FENCE();
-    static_for<NV>([&](auto Jj) { constexpr int j = Jj;
-      const bool low = i >= j;
-      const bool nzE = sel(low, ((mE >> j) & 1u) != 0u, ((coop_row_mask(PAT_E, j) >> i) & 1u) != 0u);
-      const bool nzM = sel(low, ((mM >> j) & 1u) != 0u, ((coop_row_mask(PAT_M, j) >> i) & 1u) != 0u);
-      H0[j] = sel(nzE, he[j], 0.0) + sel(nzM, hm[j], 0.0); });
+    static_for<NB>([&](auto Jj) { constexpr int j = Jj;
+      const bool low = ir >= j;
+      const bool nzE = sel(low, ((mE >> j) & 1u) != 0u, ((coop_row_mask(PAT_E, j) >> ir) & 1u) != 0u);
+      const bool nzM = sel(low, ((mM >> j) & 1u) != 0u, ((coop_row_mask(PAT_M, j) >> ir) & 1u) != 0u);
+      H0[j] = sel(rob, sel(nzE, he[j], 0.0) + sel(nzM, hm[j], 0.0), 0.0); });
+    static_for<N - NB>([&](auto Kk) { constexpr int k = Kk; H0[NB + k] = sel(i == NB + k, CS.Md[k], 0.0); });
+    const real gr = ME.ld(PUB_G0 + ir);
+    real gcv = 0;
+    static_for<N - NB>([&](auto Kk) { constexpr int k = Kk; gcv = sel(i == NB + k, CS.fs[k], gcv); });
+    g0 = sel(rob, gr, gcv);
   }
-  MCG_TICK_PIN(H0, NV);
+  const real md6 = CS.Md[4], md7 = CS.Md[5], g06 = CS.fs[4], g07 = CS.fs[5];
+  MCG_TICK_PIN(H0, N);
   COOP_TICK(ST_CO_H0);
-  real al = ME.ld(PUB_WARM + i);                    // the iterate: lane i (and 16 + i) holds a_i
-  // assembly layout: lane (ia, hb) = row ia, columns 6 hb .. 6 hb + 5 of the increment
-  const int ia = l16, hb = L >> 4, cb = 6 * hb;
-  const int iseg = l16 + ((hb == 1 && l16 >= 2) ? 6 : 0);
-  struct WinRow { real own, seg; };
-  auto load_row = [&](int t, WinRow& w) { const int o = t * C12_WSTRIDE; w.own = ws[o + 2 + i]; w.seg = ws[o + iseg]; };
-  struct AsmAcc { real Ah[6], ag; };
-  auto add_row = [&](const WinRow& w, AsmAcc& A) {
-    const real D = coop_bcast16<0>(w.seg), Da = coop_bcast16<1>(w.seg);
-    const real cD = D * w.own;
-    static_for<6>([&](auto Cc) { constexpr int c = Cc; A.Ah[c] = fma(cD, coop_bcast16<2 + c>(w.seg), A.Ah[c]); });
-    A.ag = fma(Da, w.own, A.ag);
-  };
+  // ---- the iterate: a_i in lane i of the DPP rows (i < 16), a_16 and a_17 in every lane
+  real am = ME.ld(sel(i < NB, PUB_WARM + i, XCH_CB + 13 + (i - NB)));
+  real a6 = ME.ld(XCH_CB + 13 + 4), a7 = ME.ld(XCH_CB + 13 + 5);
+  bool done = !have;
+  const LdsPtr wsB = wsw + CP_WS;
 
   for (int it = 0; it < 50; it++) {
     COOP_COUNT(1, 1);
-    if (it == 8) COOP_COUNT(5, 1);
-    if (it == 49) COOP_COUNT(6, 1);
-    // (a) residuals and active set at a, H0 a on the way
-    real r0[NSETS], h0a = 0; unsigned act[NSETS];
+    // (a) the iterate to every row: 18 doubles of LDS
+    coop_lds_sync();
+    if ((drow & 1) == 0) ws[CP_AOFF + l16] = am;
+    if (hl == 0) coop_st2(ws + CP_AOFF + N, a6, a7);
+    coop_lds_sync();
+    real av[NV];
+    _Pragma("unroll") for (int j = 0; j < NV; j += 2) { const coop_vd2 v = coop_ld2(ws + CP_AOFF + j); av[j] = v[0]; av[j + 1] = v[1]; }
+    MCG_FENCE();
+    real r0[NSETS], h0a = 0; unsigned actA[NSETS], actB[NSETS];
     _Pragma("unroll") for (int s = 0; s < NSETS; s++) r0[s] = -aref[s];
-    static_for<NV>([&](auto Jj) { constexpr int j = Jj;
-      const real aj = coop_bcast16<j>(al);
-      _Pragma("unroll") for (int s = 0; s < NSETS; s++) r0[s] = fma(J[s][j], aj, r0[s]);
-      h0a = fma(H0[j], aj, h0a); });
-    _Pragma("unroll") for (int s = 0; s < NSETS; s++) act[s] = (unsigned)__ballot(Dr[s] > 0 && r0[s] < 0);
+    _Pragma("unroll") for (int j = 0; j < NV; j++) { _Pragma("unroll") for (int s = 0; s < NSETS; s++) r0[s] = fma(J[s][j], av[j], r0[s]); }
+    _Pragma("unroll") for (int j = 0; j < N; j++) h0a = fma(H0[j], av[j], h0a);
+    _Pragma("unroll") for (int s = 0; s < NSETS; s++) {
+      const unsigned long long b = __ballot(r0[s] < 0 && !done);       // (a finished half assembles nothing)
+      actA[s] = (unsigned)b; actB[s] = (unsigned)(b >> 32);
+    }
     MCG_TICK_PIN(r0, NSETS);
     COOP_TICK(ST_CO_RESID);
-    COOP_COUNT(3, __popc(act[0]) + (NSETS > 1 ? __popc(act[1 % NSETS]) : 0) + (NSETS > 2 ? __popc(act[2 % NSETS]) : 0));
-    // (b) the increment sum_active D J J^T, D aref J through the LDS window
-    AsmAcc A;
-    _Pragma("unroll") for (int c = 0; c < 6; c++) A.Ah[c] = 0;
-    A.ag = 0;
-    _Pragma("unroll") for (int s = 0; s < NSETS; s++) {
-      if (act[s] != 0u) {
-        const int nact = __popc(act[s]);
-        const int pos = __popc(act[s] & ((1u << L) - 1u));
-        const bool mine = ((act[s] >> L) & 1u) != 0u;
-        for (int w0 = 0; w0 < nact; w0 += COOP_WIN) {
-          const int nw = sel(nact - w0 < COOP_WIN, nact - w0, COOP_WIN);
-          coop_lds_sync();
-          if (mine && pos >= w0 && pos < w0 + COOP_WIN) {
-            const int o = (pos - w0) * C12_WSTRIDE;
-            ws[o] = Dr[s]; ws[o + 1] = Dr[s] * aref[s];
-            _Pragma("unroll") for (int j = 0; j < NV; j++) ws[o + 2 + j] = J[s][j];
-          }
-          if ((nw & 1) && L < C12_WSTRIDE) ws[nw * C12_WSTRIDE + L] = 0.0;
-          coop_lds_sync();
-          WinRow wa, wb;
-          load_row(0, wa); load_row(1, wb);
-          for (int t = 0; t < nw; t += 2) {
-            const int tn = sel(t + 2 < nw, t + 2, t);
-            WinRow na, nb;
-            load_row(tn, na); load_row(tn + 1, nb);
-            MCG_FENCE();
-            add_row(wa, A); add_row(wb, A);
-            MCG_FENCE();
-            wa = na; wb = nb;
+    COOP_COUNT(3, __popc(actA[0]) + __popc(actB[0]) + (NSETS > 1 ? __popc(actA[1 % NSETS]) + __popc(actB[1 % NSETS]) : 0) + (NSETS > 2 ? __popc(actA[2 % NSETS]) + __popc(actB[2 % NSETS]) : 0));
+    // (b) the increments J~^T [J~ aref~] of both environments on the matrix cores, the active rows passing through a 16-row window each
+    coop_vd4 cA0 = {0, 0, 0, 0}, cA1 = cA0, cA2 = cA0, cB0 = cA0, cB1 = cA0, cB2 = cA0;
+    {
+      // positions in the environment's list of active rows, the sets one after the other
+      int nA = 0, nB = 0, pos[NSETS]; bool mine[NSETS];
+      _Pragma("unroll") for (int s = 0; s < NSETS; s++) {
+        const unsigned own = sel(up, actB[s], actA[s]);
+        pos[s] = sel(up, nB, nA) + __popc(own & ((1u << hl) - 1u));
+        mine[s] = ((own >> hl) & 1u) != 0u;
+        nA += __popc(actA[s]); nB += __popc(actB[s]);
+      }
+      const int nmx = nA > nB ? nA : nB, n_own = sel(up, nB, nA);
+      for (int w0 = 0; w0 < nmx; w0 += COOP_WIN) {                  // uniform
+        coop_lds_sync();                                            // the window's previous readers are done
+        _Pragma("unroll") for (int s = 0; s < NSETS; s++) {
+          if (mine[s] && pos[s] >= w0 && pos[s] < w0 + COOP_WIN) {
+            const LdsPtr o = ws + (pos[s] - w0) * COOP_WSTRIDE;
+            _Pragma("unroll") for (int j = 0; j < NV; j += 2) coop_st2(o + j, J[s][j], J[s][j + 1]);
+            coop_st2(o + NV, aref[s], 0.0);
           }
         }
+        {   // zero rows complete the last group of four
+          const int left = n_own - w0;
+          const int nw = sel(left < 0, 0, sel(left > COOP_WIN, COOP_WIN, left));
+          const int npad = (-nw) & 3;
+          if (hl < COOP_WSTRIDE) { _Pragma("unroll") for (int t = 0; t < 3; t++) if (t < npad) ws[(nw + t) * COOP_WSTRIDE + hl] = 0.0; }
+        }
+        coop_lds_sync();
+        const int lA = nA - w0, lB = nB - w0;
+        const int gA = (sel(lA < 0, 0, sel(lA > COOP_WIN, COOP_WIN, lA)) + 3) >> 2, gB = (sel(lB < 0, 0, sel(lB > COOP_WIN, COOP_WIN, lB)) + 3) >> 2;
+        // four window rows per instruction: lane (k = drow, c = l16) holds W[4 g + k][c].  All operands of an environment's window first (one
+        // LDS round trip, not one per group), then its matrix instructions back to back
+        auto window = [&](const LdsPtr wse, int ng, coop_vd4& c0, coop_vd4& c1, coop_vd4& c2) {
+          real lo[4], hi[4];
+          _Pragma("unroll") for (int g = 0; g < 4; g++) { const int o = (4 * g + drow) * COOP_WSTRIDE + l16; lo[g] = wse[o]; hi[g] = wse[o + N]; }
+          MCG_FENCE();
+          _Pragma("unroll") for (int g = 0; g < 4; g++) {
+            if (g < ng) {                                           // uniform
+              const real h3 = sel(l16 < 3, hi[g], 0.0);
+              c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(lo[g], lo[g], c0, 0, 0, 0);
+              c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(lo[g], h3, c1, 0, 0, 0);
+              c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(h3, h3, c2, 0, 0, 0);
+            }
+          }
+        };
+        window(wsw, gA, cA0, cA1, cA2);
+        window(wsB, gB, cB0, cB1, cB2);
       }
     }
+    // result element v of lane (drow, l16) is entry (drow + 4 v, l16): scattered as a 16 x 16 matrix, three 16-vectors (columns 16, 17 and
+    // the gradient) and the 2 x 3 corner; then lane j of each DPP row gathers row j (= column j) and its entries of rows 16, 17
     coop_lds_sync();
-    if (ia < NV) {
-      _Pragma("unroll") for (int c = 0; c < 6; c++) ws[ia * NV + cb + c] = A.Ah[c];
-      if (hb == 0) ws[NV * NV + ia] = A.ag;
-    }
+    _Pragma("unroll") for (int v = 0; v < 4; v++) { wsw[(drow + 4 * v) * CP_MSTRIDE + l16] = cA0[v]; wsB[(drow + 4 * v) * CP_MSTRIDE + l16] = cB0[v]; }
+    if (l16 < 3) { _Pragma("unroll") for (int v = 0; v < 4; v++) { wsw[CP_VOFF + l16 * N + drow + 4 * v] = cA1[v]; wsB[CP_VOFF + l16 * N + drow + 4 * v] = cB1[v]; } }
+    if (drow < 2 && l16 < 3) { wsw[CP_COFF + drow * 3 + l16] = cA2[0]; wsB[CP_COFF + drow * 3 + l16] = cB2[0]; }
     coop_lds_sync();
-    real H[NV], g;
-    _Pragma("unroll") for (int j = 0; j < NV; j++) H[j] = ws[i * NV + j];
-    g = ws[NV * NV + i];
+    real Hc[N], e6, e7, g, c66, c76, c77, g6, g7;
+    _Pragma("unroll") for (int k = 0; k < N; k += 2) { const coop_vd2 v = coop_ld2(ws + l16 * CP_MSTRIDE + k); Hc[k] = v[0]; Hc[k + 1] = v[1]; }
+    e6 = ws[CP_VOFF + l16]; e7 = ws[CP_VOFF + N + l16]; g = ws[CP_VOFF + 2 * N + l16];
+    { const coop_vd2 u0 = coop_ld2(ws + CP_COFF), u1 = coop_ld2(ws + CP_COFF + 2), u2 = coop_ld2(ws + CP_COFF + 4);
+      c66 = u0[0]; c76 = u0[1]; g6 = u1[0]; c77 = u2[0]; g7 = u2[1]; }
     MCG_FENCE();
-    _Pragma("unroll") for (int j = 0; j < NV; j++) H[j] += H0[j];
-    g += g0;
-    MCG_TICK_PIN(H, NV);
+    _Pragma("unroll") for (int k = 0; k < N; k++) Hc[k] += H0[k];
+    g += g0; c66 += md6; c77 += md7; g6 += g06; g7 += g07;
+#ifdef MCG_COOP_DEBUG
+    const bool dbg = blockIdx.x == 0 && it == 0 && have && g_coop_dbg_done[e] == 0 && (drow & 1) == 0;
+    if (dbg) { double* o = g_coop_dbg + e * 512;
+      for (int k = 0; k < N; k++) o[l16 * NV + k] = Hc[k];
+      o[l16 * NV + 16] = e6; o[l16 * NV + 17] = e7; o[16 * NV + l16] = e6; o[17 * NV + l16] = e7;
+      o[324 + l16] = g; o[360 + l16] = am;
+      if (l16 == 0) { o[16 * NV + 16] = c66; o[16 * NV + 17] = c76; o[17 * NV + 16] = c76; o[17 * NV + 17] = c77; o[324 + 16] = g6; o[324 + 17] = g7; o[360 + 16] = a6; o[360 + 17] = a7; } }
+#endif
+    MCG_TICK_PIN(Hc, N);
     COOP_TICK(ST_CO_ASM);
-    // (c) H = L D L^T, the pivot column by row_newbcast
-    real Lr[NV], dinv[NV];
-    static_for<NV>([&](auto Kk) { constexpr int k = Kk;
-      const real dk = coop_bcast16<k>(H[k]);
+    // (c) H = L D L^T in the 16 lanes of a DPP row.  Lane j keeps the unscaled H[j][k] = L[j][k] D_k in Hc[k] (k < j), the scaled
+    // L[j][k] in Lr[k] (zero for k >= j); e6 / e7 end as H[16][j], H[17][j] (unscaled), the corner as D_16, L[17][16] D_16, D_17 + ...
+    // (the scaled L[j][k] = Hc[k] / D_k is formed again where the forward substitution needs it: sixteen more multiplications, sixteen
+    // fewer numbers across the register peak)
+    real dinv[N], dinv_own = 0;
+    static_for<N>([&](auto Kk) { constexpr int k = Kk;
+      const real dk = coop_bcast16<k>(Hc[k]);
       dinv[k] = rcp_nr(dk);
-      const real lk = H[k] * dinv[k];
-      static_for<NV - 1 - k>([&](auto Jj) { constexpr int j = k + 1 + Jj;
-        H[j] = fma(-lk, coop_bcast16<j>(H[k]), H[j]); });
-      Lr[k] = sel(i > k, lk, 0.0); });
-    MCG_TICK_PIN(Lr, NV);
+      const real lk = Hc[k] * dinv[k];
+      const real b6 = coop_bcast16<k>(e6), b7 = coop_bcast16<k>(e7);
+      static_for<N - 1 - k>([&](auto Jj) { constexpr int j = k + 1 + Jj;
+        const real sj = coop_bcast16<j>(Hc[k]);
+        Hc[j] = fma(-lk, sj, Hc[j]); });
+      const real lkm = sel(l16 > k, lk, 0.0);
+      e6 = fma(-lkm, b6, e6); e7 = fma(-lkm, b7, e7);
+      const real l6 = b6 * dinv[k], l7 = b7 * dinv[k];
+      c66 = fma(-l6, b6, c66); c76 = fma(-l7, b6, c76); c77 = fma(-l7, b7, c77);
+      dinv_own = sel(l16 == k, dinv[k], dinv_own); });
+    const real dinv6 = rcp_nr(c66), l76 = c76 * dinv6;
+    const real dinv7 = rcp_nr(fma(-l76, c76, c77));
+    MCG_TICK_PIN(Hc, N);
     COOP_TICK(ST_CO_FACTOR);
-    // (d) x = H^-1 g
+    // (d) x = H^-1 g: forward in row layout, rows 16 / 17 by two 16-lane sums; backward on the unscaled columns through one LDS transpose
     real acc = g;
-    static_for<NV>([&](auto Kk) { constexpr int k = Kk; acc = fma(-Lr[k], coop_bcast16<k>(acc), acc); });
+    static_for<N>([&](auto Kk) { constexpr int k = Kk;
+      const real yk = coop_bcast16<k>(acc);
+      acc = fma(-sel(l16 > k, Hc[k] * dinv[k], 0.0), yk, acc); });
+    const real zt = acc * dinv_own;
+    const real y6 = g6 - coop_sum16(e6 * zt);
+    const real y7 = g7 - coop_sum16(e7 * zt) - l76 * y6;
+    const real x7 = y7 * dinv7, x6 = fma(-l76, x7, y6 * dinv6);
+    acc = fma(-e6, x6, fma(-e7, x7, acc));
     coop_lds_sync();
-    if (L < NV) { _Pragma("unroll") for (int k = 0; k < NV; k++) ws[L * NV + k] = sel(L > k, H[k], 0.0); }
+    if ((drow & 1) == 0) { _Pragma("unroll") for (int k = 0; k < N; k += 2) coop_st2(ws + l16 * CP_MSTRIDE + k, sel(l16 > k, Hc[k], 0.0), sel(l16 > k + 1, Hc[k + 1], 0.0)); }
     coop_lds_sync();
-    real U[NV];
-    _Pragma("unroll") for (int j = 0; j < NV; j++) U[j] = ws[j * NV + i];
+    real U[N];                                       // U[j] = H[j][i] (unscaled) for j > i, zero otherwise
+    _Pragma("unroll") for (int j = 0; j < N; j++) U[j] = ws[j * CP_MSTRIDE + l16];
     MCG_FENCE();
-    real rx[NSETS];
-    _Pragma("unroll") for (int s = 0; s < NSETS; s++) rx[s] = -aref[s];
-    real xl = 0;
-    static_for<NV>([&](auto Kk) { constexpr int j = NV - 1 - Kk;
+    real xm = 0;
+    static_for<N>([&](auto Kk) { constexpr int j = N - 1 - Kk;
       const real xj = coop_bcast16<j>(acc) * dinv[j];
       acc = fma(-U[j], xj, acc);
-      xl = sel(i == j, xj, xl);
-      _Pragma("unroll") for (int s = 0; s < NSETS; s++) rx[s] = fma(J[s][j], xj, rx[s]); });
+      xm = sel(l16 == j, xj, xm); });
+#ifdef MCG_COOP_DEBUG
+    if (dbg) { double* o = g_coop_dbg + e * 512; o[342 + l16] = xm; if (l16 == 0) { o[342 + 16] = x6; o[342 + 17] = x7; } }
+#endif
+    // the candidate to every row
+    coop_lds_sync();
+    if ((drow & 1) == 0) ws[CP_AOFF + l16] = xm;
+    if (hl == 0) coop_st2(ws + CP_AOFF + N, x6, x7);
+    coop_lds_sync();
+    real rx[NSETS];
+    _Pragma("unroll") for (int s = 0; s < NSETS; s++) rx[s] = -aref[s];
+    _Pragma("unroll") for (int j = 0; j < NV; j += 2) {
+      const coop_vd2 v = coop_ld2(ws + CP_AOFF + j);
+      _Pragma("unroll") for (int s = 0; s < NSETS; s++) rx[s] = fma(J[s][j + 1], v[1], fma(J[s][j], v[0], rx[s]));
+    }
     MCG_TICK_PIN(rx, NSETS);
     COOP_TICK(ST_CO_SOLVE);
-    bool same = true;
-    _Pragma("unroll") for (int s = 0; s < NSETS; s++) same = same && ((unsigned)__ballot(Dr[s] > 0 && rx[s] < 0) == act[s]);
+    // (e) does each candidate keep its active set?
+    bool sameA = true, sameB = true;
+    _Pragma("unroll") for (int s = 0; s < NSETS; s++) {
+      const unsigned long long b = __ballot(rx[s] < 0 && !done);
+      sameA = sameA && (unsigned)b == actA[s]; sameB = sameB && (unsigned)(b >> 32) == actB[s];
+    }
+    const bool same = sel(up, sameB, sameA);
     COOP_TICK(ST_CO_CHECK);
-    if (same || it < MCG_COOP_FULL_STEPS) {
-      al = xl;
-      if (same) break;
-      continue;
-    }
-    // (e) exact line search (as in coop_solve; the smooth part's sums run over one DPP row)
-    COOP_COUNT(2, 1);
-    const real pl = xl - al;
-    real h0p = 0;
-    static_for<NV>([&](auto Jj) { constexpr int j = Jj; h0p = fma(H0[j], coop_bcast16<j>(pl), h0p); });
-    const bool own = l16 < NV;
-    const real s0 = coop_sum16(sel(own, (h0a - g0) * pl, 0.0)), quad = coop_sum16(sel(own, h0p * pl, 0.0));
-    real dr_[NSETS];
-    _Pragma("unroll") for (int s = 0; s < NSETS; s++) dr_[s] = rx[s] - r0[s];
-    auto dphi = [&](real alp, real& slope) {
-      COOP_COUNT(4, 1);
-      real f = 0, sl = 0;
-      _Pragma("unroll") for (int s = 0; s < NSETS; s++) {
-        const real rr = fma(alp, dr_[s], r0[s]);
-        const bool on = Dr[s] > 0 && rr < 0;
-        const real dd = Dr[s] * dr_[s];
-        f += sel(on, dd * rr, 0.0); sl += sel(on, dd * dr_[s], 0.0);
+    const bool full = same || it < MCG_COOP_FULL_STEPS;
+    const bool need = !done && !full;                // this half wants a line search
+#ifdef MCG_COOP_DEBUG
+    const bool dbt = blockIdx.x == 0 && have && !done && g_coop_dbg_done[e] == 0 && it < 8 && hl == 0;
+    if (dbt) { double* o = g_coop_dbg + e * 512 + 400 + it * 8; const unsigned a0 = sel(up, actB[0], actA[0]), a1 = sel(up, actB[1 % NSETS], actA[1 % NSETS]);
+      o[0] = __popc(a0) + (NSETS > 1 ? __popc(a1) : 0); o[1] = same; o[2] = 0; o[3] = -1; }
+#endif
+    if (!done && full) { am = xm; a6 = x6; a7 = x7; }
+    done = done || same;
+    if (__any(need)) {
+      // (f) exact line search (see coop_solve), each half its own; a half that needs none walks along with frozen numbers
+      COOP_COUNT(2, 1);
+      const real pm = xm - am, p6 = x6 - a6, p7 = x7 - a7;
+      real h0p = 0;
+      static_for<N>([&](auto Jj) { constexpr int j = Jj; h0p = fma(H0[j], coop_bcast16<j>(pm), h0p); });
+      const real s0 = coop_sum16((h0a - g0) * pm) + (md6 * a6 - g06) * p6 + (md7 * a7 - g07) * p7;
+      const real quad = coop_sum16(h0p * pm) + md6 * p6 * p6 + md7 * p7 * p7;
+      real dr_[NSETS];
+      _Pragma("unroll") for (int s = 0; s < NSETS; s++) dr_[s] = rx[s] - r0[s];
+      auto dphi = [&](real alp, real& slope) {
+        COOP_COUNT(4, 1);
+        real f = 0, sl = 0;
+        _Pragma("unroll") for (int s = 0; s < NSETS; s++) {
+          const real rr = fma(alp, dr_[s], r0[s]);
+          const bool on = rr < 0;
+          f += sel(on, dr_[s] * rr, 0.0); sl += sel(on, dr_[s] * dr_[s], 0.0);
+        }
+        slope = quad + coop_sum32h(sl);
+        return fma(alp, quad, s0) + coop_sum32h(f);
+      };
+      real lo = 0, hi = 2, sl;
+      const bool beyond = dphi(hi, sl) < 0;
+      real alp = 1.0;
+      bool fin = !need || beyond;
+#ifdef MCG_COOP_DEBUG
+      if (dbt && need && it == 1) { double* o = g_coop_dbg + e * 512 + 464 + 8 * 3; o[0] = 2; o[1] = beyond; o[2] = sl; }
+#endif
+      for (int b = 0; b < 8; b++) {
+        if (!__any(!fin)) break;                       // uniform
+        const real f = dphi(alp, sl);
+#ifdef MCG_COOP_DEBUG
+        if (dbt && need && it == 1 && !fin) { double* o = g_coop_dbg + e * 512 + 464 + b * 3; o[0] = alp; o[1] = f; o[2] = sl; }
+#endif
+        const bool neg = f < 0;
+        const real lo2 = sel(neg, alp, lo), hi2 = sel(neg, hi, alp);
+        const real nwt = alp - f / sl;
+        const real nx = sel(nwt >= lo2 && nwt <= hi2, nwt, 0.5 * (lo2 + hi2));
+        const bool moved = fabs(nx - alp) > 1e-10 * fmax(1.0, fabs(alp));
+        lo = sel(fin, lo, lo2); hi = sel(fin, hi, hi2); alp = sel(fin, alp, nx);
+        fin = fin || !moved;
       }
-      slope = quad + coop_sum32(sl);
-      return fma(alp, quad, s0) + coop_sum32(f);
-    };
-    real lo = 0, hi = 2, sl;
-    const bool beyond = dphi(hi, sl) < 0;
-    real alp = 1.0;
-    for (int b = 0; b < 8 && !beyond; b++) {
-      const real f = dphi(alp, sl);
-      const bool neg = f < 0;
-      lo = sel(neg, alp, lo); hi = sel(neg, hi, alp);
-      const real nwt = alp - f / sl;
-      const real nx = sel(nwt > lo && nwt < hi, nwt, 0.5 * (lo + hi));
-      const bool moved = fabs(nx - alp) > 1e-10 * fmax(1.0, fabs(alp));
-      alp = nx;
-      if (!moved) break;
+      const real alpha = sel(beyond, 2.0, alp);
+#ifdef MCG_COOP_DEBUG
+      if (dbt && need) { double* o = g_coop_dbg + e * 512 + 400 + it * 8; o[2] = 1; o[3] = alpha; o[4] = s0; o[5] = quad; }
+#endif
+      if (need) { am = fma(alpha, pm, am); a6 = fma(alpha, p6, a6); a7 = fma(alpha, p7, a7); }
+      MCG_TICK_PIN(&am, 1);
+      COOP_TICK(ST_CO_LS);
     }
-    const real alpha = sel(beyond, 2.0, alp);
-    al = fma(alpha, pl, al);
-    MCG_TICK_PIN(&al, 1);
-    COOP_TICK(ST_CO_LS);
+    if (!__any(!done)) break;                          // uniform: both halves have their minimiser
   }
-  if (L < NV) ME.st(PUB_WARM + L, al);
+#ifdef MCG_COOP_DEBUG
+  if (blockIdx.x == 0 && have && g_coop_dbg_done[e] == 0 && (drow & 1) == 0) {
+    double* o = g_coop_dbg + e * 512; o[380 + l16] = am; if (l16 == 0) { o[380 + 16] = a6; o[380 + 17] = a7; }
+    __builtin_amdgcn_s_waitcnt(0);
+    if (l16 == 0) g_coop_dbg_done[e] = 1;
+  }
+#endif
+  // ---- hand the accelerations back
+  if (have && (drow & 1) == 0) {
+    if (l16 < NB) ME.st(PUB_WARM + l16, am);
+    else ME.st(XCH_CB + 13 + (l16 - NB), am);
+    if (l16 == 0) { ME.st(XCH_CB + 13 + 4, a6); ME.st(XCH_CB + 13 + 5, a7); }
+  }
   COOP_TICK(ST_CO_OUT);
 }
 
-// ---- the cooperative phase.  All four waves run it between barriers S4 and S5 with the same `mask` (bit l: lane l's environment is
-// flagged).  The flagged environments are handed out one at a time from a counter in LDS (solves differ by a factor of ten in their Newton
-// iteration counts: a fixed split leaves three waves waiting for the unluckiest); the robot wave clears the counter before S4.
+// ---- the cooperative phase.  The cube wave and the M / RNE waves run it between barriers S4 and S5, all 64 lanes alive, with the same
+// `mask` (bit l: lane l's environment is flagged).  The flagged environments are handed out from a counter in LDS (solves differ by a
+// factor of ten in their Newton iteration counts: a fixed split leaves the others waiting for the unluckiest), two per turn of a wave;
+// the robot wave clears the counter before S4 and sleeps at S5.
 //
 // Where the code lives decides the kernel's HBM traffic.  An out-of-line function saves and restores every callee-saved register it
-// uses -- 218 dwords a lane for this one -- on EVERY call: with one call per wave per coupled sub-step that was 56 KB per wave-call,
-// 133 KB of scratch traffic per env-step of the scripted grasp (98x the algorithmic bytes; rocprofv3 PMC, profiles/r03v).  So the
-// common shape (18 dofs, up to 64 rows) is INLINED into the kernel's cube-wave and M / RNE-wave branches, which hold next to nothing
-// across the phase (the cube wave its cube, the others nothing), and only the robot wave -- whose live state would be spilled around
-// an inlined copy, and whose contact-free pipeline an inlined copy slowed in round 2 -- calls the out-of-line instance; the rare shapes
-// (more than nine contacts, the opt-in 12-dof routing) are out of line for everyone.  Scripted grasp: 98x -> 3.1x the algorithmic bytes.
-// (Both other placements were measured in the same GPU calls: cube wave and M / RNE waves as out-of-line per-env-step functions with
-// the phase inlined into them -- 4.8x, but the resting-cube step 0.436 -> 0.456 ms; only the cube wave out of line -- 2.9x, 0.454 ms.)
-static __device__ __noinline__ void coop_solve_rare(unsigned long long model_bits, unsigned lds_base, int e_, int wave, int ncon_, int kind_) {
+// uses -- 218 dwords a lane for the 32-lane solve -- on EVERY call: with one call per wave per coupled sub-step that was 56 KB per
+// wave-call, 133 KB of scratch traffic per env-step of the scripted grasp (98x the algorithmic bytes; rocprofv3 PMC, profiles/r03v).  So
+// the common shape (two environments of up to nine contacts) is INLINED into the kernel's cube-wave and M / RNE-wave branches, which hold
+// next to nothing across the phase (the cube wave its cube, the others nothing).  The robot wave -- whose live state would be spilled
+// around an inlined copy, and whose contact-free pipeline an inlined copy slowed in round 2 -- called an out-of-line instance until the
+// pair solve; it no longer takes part (six environments per round of the workgroup instead of four).  The rare shape (more than nine
+// contacts) and the one-environment-per-wave routing (MCG_COOP_PAIR=0: the first implementation, kept as a cross-check of the second)
+// are out of line.
+static __device__ __noinline__ void coop_solve_single(unsigned long long model_bits, unsigned lds_base, int e_, int wave, int ncon_) {
   const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)model_bits), hi = __builtin_amdgcn_readfirstlane((unsigned)(model_bits >> 32));
   const ModelPtr P = (ModelPtr)(((unsigned long long)hi << 32) | lo);
   const LdsPtr lds0 = (LdsPtr)(uintptr_t)__builtin_amdgcn_readfirstlane(lds_base);
   const int e = __builtin_amdgcn_readfirstlane(e_), w = __builtin_amdgcn_readfirstlane(wave);
-  const int ncon = __builtin_amdgcn_readfirstlane(ncon_), kind = __builtin_amdgcn_readfirstlane(kind_);
+  const int ncon = __builtin_amdgcn_readfirstlane(ncon_);
   const LdsPtr ws = lds0 + COOP_WS_ROW * PNP_LANES + w * COOP_WS_DOUBLES;
   CoopClocks CK;
 #ifdef MCG_STAGE_CLOCKS
   for (int k = 0; k < ST_CO_IDLE - ST_CO_SETUP; k++) CK.t[k] = 0;
   for (int k = 0; k < 8; k++) CK.n[k] = 0;
 #endif
-  const bool two = 10 + 6 * ncon <= 2 * PNP_LANES;
-  if (kind == 1) { if (two) coop_solve12<2>(P, lds0, e, ws, ncon, CK); else coop_solve12<COOP_SETS>(P, lds0, e, ws, ncon, CK); }
+  if (10 + 6 * ncon <= 2 * PNP_LANES) coop_solve<2>(P, lds0, e, ws, ncon, CK);
   else coop_solve<COOP_SETS>(P, lds0, e, ws, ncon, CK);
   coop_flush_clocks(CK);
 }
 
-MCG_DEV void coop_phase_body(ModelPtr P, LdsPtr lds0, unsigned m, int w) {
+// mode 0: every wave takes one environment at a time (MCG_COOP_PAIR=0) | 1: a 64-lane wave, two at a time | 2: the robot wave beside
+// 64-lane waves.  WHICH solver an environment gets must not depend on the race for the counter -- the two differ in the last bits, and a
+// run must reproduce bit for bit -- so the robot wave's share is fixed by rank: of the flagged environments, in lane order, every
+// seventh is the robot wave's (a 32-lane solve takes about as long as a pair's), the others are handed out in pairs.  (Who is paired
+// with whom does race; a half's arithmetic never sees the other half's numbers.)
+constexpr int COOP_ROBOT_EVERY = 7;
+MCG_DEV void coop_phase_body(ModelPtr P, LdsPtr lds0, unsigned m, int w, int mode) {
   const LdsPtr ws = lds0 + COOP_WS_ROW * PNP_LANES + w * COOP_WS_DOUBLES;
   CoopClocks CK;
 #ifdef MCG_STAGE_CLOCKS
@@ -739,27 +934,49 @@ MCG_DEV void coop_phase_body(ModelPtr P, LdsPtr lds0, unsigned m, int w) {
   typedef __attribute__((address_space(3))) unsigned* LdsCtr;
   const LdsCtr ctr = (LdsCtr)(lds0 + COOP_CTR_SLOT * PNP_LANES);
   const int total = __popc(m);
-  for (;;) {
+  auto grab = [&]() {
     unsigned k = 0;
     if ((threadIdx.x & 63) == 0) k = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    k = __builtin_amdgcn_readfirstlane(k);
-    if ((int)k >= total) break;
-    unsigned mm = m;
-    for (unsigned q = 0; q < k; q++) mm &= mm - 1u;          // the k-th flagged lane
-    const int e = __builtin_ctz(mm);
-    const int ncon = __builtin_amdgcn_readfirstlane((int)lds0[XCH_NCON * PNP_LANES + e]);
-    const int kind = __builtin_amdgcn_readfirstlane((int)lds0[XCH_FLAG * PNP_LANES + e]);
-    if (kind != 1 && 10 + 6 * ncon <= 2 * PNP_LANES) coop_solve<2>(P, lds0, e, ws, ncon, CK);      // up to 9 contacts: 64 rows
-    else coop_solve_rare((unsigned long long)P, (unsigned)(uintptr_t)lds0, e, w, ncon, kind);
+    return (int)__builtin_amdgcn_readfirstlane(k);
+  };
+  auto kth = [&](int k) { unsigned mm = m; for (int q = 0; q < k; q++) mm &= mm - 1u; return __builtin_ctz(mm); };      // the k-th flagged lane
+  auto ncon_of = [&](int e) { return __builtin_amdgcn_readfirstlane((int)lds0[XCH_NCON * PNP_LANES + e]); };
+  if (mode == 2) {
+    for (int k = COOP_ROBOT_EVERY - 1; k < total; k += COOP_ROBOT_EVERY) { const int e = kth(k); coop_solve_single((unsigned long long)P, (unsigned)(uintptr_t)lds0, e, w, ncon_of(e)); }
+  } else if (mode == 0) {
+    for (;;) {
+      const int k = grab();
+      if (k >= total) break;
+      const int e = kth(k);
+      coop_solve_single((unsigned long long)P, (unsigned)(uintptr_t)lds0, e, w, ncon_of(e));
+    }
+  } else {
+    const int npair = total - total / COOP_ROBOT_EVERY;              // the ranks that are not the robot wave's
+    auto rank_of = [&](int j) { return j + j / (COOP_ROBOT_EVERY - 1); };
+    for (;;) {
+      const int j1 = grab();
+      if (j1 >= npair) break;
+      const int e1 = kth(rank_of(j1)), n1 = ncon_of(e1);
+      if (10 + 6 * n1 > 2 * PNP_LANES) { coop_solve_single((unsigned long long)P, (unsigned)(uintptr_t)lds0, e1, w, n1); continue; }      // more than nine contacts
+      int e2 = e1, n2 = n1, big = -1, nbig = 0; bool have2 = false;
+      const int j2 = grab();
+      if (j2 < npair) {
+        const int ec = kth(rank_of(j2)), nc = ncon_of(ec);
+        if (10 + 6 * nc <= 2 * PNP_LANES) { e2 = ec; n2 = nc; have2 = true; } else { big = ec; nbig = nc; }
+      }
+      coop_solve_pair<2>(P, lds0, ws, e1, e2, n1, n2, have2, CK);
+      if (big >= 0) coop_solve_single((unsigned long long)P, (unsigned)(uintptr_t)lds0, big, w, nbig);
+    }
   }
   coop_flush_clocks(CK);
 }
 
-// the robot wave's instance
-static __device__ __noinline__ void coop_phase(unsigned long long model_bits, unsigned lds_base, unsigned mask, int wave) {
+// the robot wave's instance: 32 lanes, one environment at a time through the out-of-line solve (its live state stays in its registers)
+static __device__ __noinline__ void coop_phase(unsigned long long model_bits, unsigned lds_base, unsigned mask, int wave, int mode) {
   const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)model_bits), hi = __builtin_amdgcn_readfirstlane((unsigned)(model_bits >> 32));
   const ModelPtr P = (ModelPtr)(((unsigned long long)hi << 32) | lo);
-  coop_phase_body(P, (LdsPtr)(uintptr_t)__builtin_amdgcn_readfirstlane(lds_base), __builtin_amdgcn_readfirstlane(mask), __builtin_amdgcn_readfirstlane(wave));
+  coop_phase_body(P, (LdsPtr)(uintptr_t)__builtin_amdgcn_readfirstlane(lds_base), __builtin_amdgcn_readfirstlane(mask), __builtin_amdgcn_readfirstlane(wave),
+                  __builtin_amdgcn_readfirstlane(mode));
 }
 
 }  // namespace mcg

@@ -834,7 +834,7 @@ struct CubeSys {
       const bool neg = f < 0;
       lo = sel(neg, al, lo); hi = sel(neg, hi, al);
       const real nw = al - f / sl;
-      const real nx = sel(nw > lo && nw < hi, nw, 0.5 * (lo + hi));
+      const real nx = sel(nw >= lo && nw <= hi, nw, 0.5 * (lo + hi));      // closed: AT the root the step is zero and nw == al == lo or hi
       const bool moved = fabs(nx - al) > 1e-12 * fmax(1.0, fabs(al));
       al = nx;
       if (!__any(moved && !done && !beyond)) break;

@@ -31,7 +31,7 @@ int fail(int code, const char* fmt, const char* a = "") { snprintf(g_err, sizeof
 struct Cfg {
   int n, has_object, controller, fetch, reward_type, frame_skip, control_steps, max_episode_steps;
   int target_in_the_air, auto_reset, nq, nv, obs_dim, act_dim, dr_enable, block_gripper;
-  int coop12;            // PickAndPlace: environments whose robot touches only static geoms get the 12-dof cooperative solve (MCG_COOP12=1; default: all 18-dof)
+  int coop_pair;         // PickAndPlace: the cooperative phase solves two environments per wave (default; MCG_COOP_PAIR=0: one per wave, the first implementation)
   int hidden;            // Reach with reward_shaping: the cube stays in the physics as a hidden free body (mycobot.py:475-481)
   double dr_mass[2], dr_fric[2], qpos0_cube[7];
   double distance_threshold, height_offset, igx[3], dt, grip_center, grip_range;
@@ -485,76 +485,81 @@ MCG_DEV void cube_from_lds(const PnpScratch MS, Cube& Cb) {
 }
 MCG_DEV unsigned flagged_lanes(const PnpScratch MS) { return (unsigned)__ballot(MS.ld(XCH_FLAG) != 0.0); }      // the same in all four waves
 
-// the cube wave's whole env-step
-struct CubeWaveArgs { real qpos0_cube[7]; unsigned long long* cnt; int coop12; };
+// the cube wave's whole env-step.  `lower`: lanes 0-31 carry the 32 environments; lanes 32-63 are alive for the cooperative phase only
+struct CubeWaveArgs { real qpos0_cube[7]; unsigned long long* cnt; int coop_pair; };
 // (inlined into the kernel, the cooperative phase inlined into it: the wave's own state across the phase is the cube, 30 numbers)
-MCG_DEV void cube_wave(const CubeWaveArgs& C, const View& V, ModelPtr P, const PnpScratch MS, unsigned lds0, int i, int total) {
-  const bool robot_only_ok = C.coop12 != 0;
+MCG_DEV void cube_wave(const CubeWaveArgs& C, const View& V, ModelPtr P, const PnpScratch MS, unsigned lds0, int i, int total, bool lower) {
   Cube Cb; real dr[2], qlag7[7];
-  for (int k = 0; k < 3; k++) Cb.pos[k] = V.qpos(12 + k, i);
-  for (int k = 0; k < 4; k++) Cb.quat[k] = V.qpos(15 + k, i);
-  for (int k = 0; k < 6; k++) { Cb.vel[k] = V.qvel(12 + k, i); Cb.warm[k] = V.warm(12 + k, i); }
-  for (int k = 0; k < 7; k++) qlag7[k] = V.qlag(12 + k, i);
-  dr[0] = V.dr(0, i); dr[1] = V.dr(1, i);
   bool touch = false;
+  if (lower) {
+    for (int k = 0; k < 3; k++) Cb.pos[k] = V.qpos(12 + k, i);
+    for (int k = 0; k < 4; k++) Cb.quat[k] = V.qpos(15 + k, i);
+    for (int k = 0; k < 6; k++) { Cb.vel[k] = V.qvel(12 + k, i); Cb.warm[k] = V.warm(12 + k, i); }
+    for (int k = 0; k < 7; k++) qlag7[k] = V.qlag(12 + k, i);
+    dr[0] = V.dr(0, i); dr[1] = V.dr(1, i);
+  }
   MCG_TICK2_INIT();
   for (int s = 0; s < total; s++) {
-    __syncthreads();                                                // S1
-    MCG_TICK2(ST_W2_WAIT1);
-    real q10[10];
-    static_for<10>([&](auto I) { constexpr int k = I; q10[k] = MS.ld(XCH_Q + k); });
-    if (s == 0) {   // mj_checkPos / mj_checkVel for the cube on the state this env-step starts from; the robot wave reports its own verdict
+    CubeSys<PnpScratch> CS(MS, Cb, dr);
+    int kind = 0;
+    if (lower) {
+      __syncthreads();                                              // S1 (a wave passes a barrier once, whatever its lanes do)
+      MCG_TICK2(ST_W2_WAIT1);
+      real q10[10];
+      static_for<10>([&](auto I) { constexpr int k = I; q10[k] = MS.ld(XCH_Q + k); });
+      if (s == 0) { // mj_checkPos / mj_checkVel for the cube on the state this env-step starts from; the robot wave reports its own verdict
                     // (mj_resetData resets both bodies).  Per ENV-STEP here, per sub-step in the Reach kernels: in this kernel the two
                     // checks and their exchange cost 6.5 % of the resting-cube step (A/B in one GPU call, 0.455 against 0.427 ms).
-      bool cbad = false;
-      for (int k = 0; k < 3; k++) cbad = cbad || bad_value(Cb.pos[k]);
-      for (int k = 0; k < 4; k++) cbad = cbad || bad_value(Cb.quat[k]);
-      for (int k = 0; k < 6; k++) cbad = cbad || bad_value(Cb.vel[k]) || bad_value(Cb.warm[k]);
-      const bool reset = cbad || MS.ld(XCH_T1) != 0.0;
-      if (__any(reset)) {                                           // wave-uniform; rare
-        for (int k = 0; k < 3; k++) Cb.pos[k] = sel(reset, C.qpos0_cube[k], Cb.pos[k]);
-        for (int k = 0; k < 4; k++) Cb.quat[k] = sel(reset, C.qpos0_cube[3 + k], Cb.quat[k]);
-        for (int k = 0; k < 6; k++) { Cb.vel[k] = sel(reset, 0.0, Cb.vel[k]); Cb.warm[k] = sel(reset, 0.0, Cb.warm[k]); }
+        bool cbad = false;
+        for (int k = 0; k < 3; k++) cbad = cbad || bad_value(Cb.pos[k]);
+        for (int k = 0; k < 4; k++) cbad = cbad || bad_value(Cb.quat[k]);
+        for (int k = 0; k < 6; k++) cbad = cbad || bad_value(Cb.vel[k]) || bad_value(Cb.warm[k]);
+        const bool reset = cbad || MS.ld(XCH_T1) != 0.0;
+        if (__any(reset)) {                                         // wave-uniform; rare
+          for (int k = 0; k < 3; k++) Cb.pos[k] = sel(reset, C.qpos0_cube[k], Cb.pos[k]);
+          for (int k = 0; k < 4; k++) Cb.quat[k] = sel(reset, C.qpos0_cube[3 + k], Cb.quat[k]);
+          for (int k = 0; k < 6; k++) { Cb.vel[k] = sel(reset, 0.0, Cb.vel[k]); Cb.warm[k] = sel(reset, 0.0, Cb.warm[k]); }
+          CS.Cb = Cb;
+        }
+        MS.st(XCH_BADC, cbad ? 1.0 : 0.0);
+        if (__any(cbad)) { if (cbad && C.cnt) atomicAdd(C.cnt + 1, 1ull); }
       }
-      MS.st(XCH_BADC, cbad ? 1.0 : 0.0);
-      if (__any(cbad)) { if (cbad && C.cnt) atomicAdd(C.cnt + 1, 1ull); }
+      CS.cnt = C.cnt;
+      CS.prepare(P, q10);
+      touch = CS.touch[0] && CS.touch[1];
+      MCG_TICK2(ST_W2_COLLIDE);
+      // 0: nothing reaches the robot | 2: a contact does (pad / finger link / gripper base on the cube, pad or arm mesh on the table or the
+      // ground): the environment's 18 dofs go to the cooperative solve.  (1 was round 3's opt-in robot-only routing: measured, no gain, removed.)
+      kind = CS.any_pad ? 2 : 0;
+      MS.st(XCH_FLAG, (real)kind);
+      if (__any(kind != 0)) {
+        if ((threadIdx.x & 63) == 0 && C.cnt) atomicAdd(C.cnt + 3, (unsigned long long)__popc((unsigned)__ballot(kind != 0)));
+        if (kind != 0) { MS.st(XCH_NCON, (real)CS.ncon); MS.st(XCH_DR, dr[0]); MS.st(XCH_DR + 1, dr[1]); cube_to_lds(MS, CS.Cb); }      // hand the (normalised, not advanced) cube over
+      }
+      __syncthreads();                                              // S2 (the robot side's "M and bias ready")
+      CS.solve_alone(kind == 2, false);                             // flagged lanes walk an empty list, store nothing
+      if (!__any(kind == 2)) { CS.finish(qlag7); Cb = CS.Cb; }
+      MCG_TICK2(ST_W2_CUBE);
     }
-    CubeSys<PnpScratch> CS(MS, Cb, dr);
-    CS.cnt = C.cnt;
-    CS.prepare(P, q10);
-    touch = CS.touch[0] && CS.touch[1];
-    MCG_TICK2(ST_W2_COLLIDE);
-    // 0: nothing reaches the robot | 1: only static geoms do (robot and cube decouple: the cube stays here, the robot's 12 dofs go to the
-    // cooperative solve) | 2: the cube touches the robot (one coupled problem) -- or its contacts sit too high in the list to leave the
-    // parked inputs alone
-    const int kind = CS.any_pad ? ((CS.side_on[0] || CS.side_on[1] || CS.base_on || CS.cube_hi - CS.cube_lo >= ALONE_MAX_LIST || !robot_only_ok) ? 2 : 1) : 0;
-    const bool coupled = __any(kind != 0), coupled2 = __any(kind == 2);      // wave-uniform
-    MS.st(XCH_FLAG, (real)kind);
-    if (coupled) {
-      if ((threadIdx.x & 63) == 0 && C.cnt) atomicAdd(C.cnt + 3, (unsigned long long)__popcll(__ballot(kind != 0)));
-      if (kind != 0) { MS.st(XCH_NCON, (real)CS.ncon); MS.st(XCH_DR, dr[0]); MS.st(XCH_DR + 1, dr[1]); }
-      if (kind == 2) cube_to_lds(MS, CS.Cb);                        // hand the (normalised, not advanced) cube over
-    }
-    __syncthreads();                                                // S2 (the robot side's "M and bias ready")
-    CS.solve_alone(kind == 2, kind == 1);                           // flag-2 lanes walk an empty list, store nothing
-    if (!coupled2) { CS.finish(qlag7); Cb = CS.Cb; }
-    MCG_TICK2(ST_W2_CUBE);
     __syncthreads();                                                // S4: end of the lane-parallel part
     MCG_TICK2(ST_W2_WAIT2);
-    if (coupled) {
-      coop_phase_body(P, (LdsPtr)(uintptr_t)lds0, __builtin_amdgcn_readfirstlane(flagged_lanes(MS)), 1);
+    const unsigned mask = flagged_lanes(MS);                        // all 64 lanes from here (the upper half reads the lower half's columns)
+    if (mask != 0u) {
+      coop_phase_body(P, (LdsPtr)(uintptr_t)lds0, __builtin_amdgcn_readfirstlane(mask), 1, C.coop_pair != 0 ? 1 : 0);
       MCG_TICK2(ST_COUPLED);
       __syncthreads();                                              // S5
       MCG_TICK2(ST_CO_IDLE);
-      if (coupled2) {
+      if (lower) {
         _Pragma("unroll") for (int k = 0; k < 6; k++) CS.a_c[k] = sel(kind == 2, MS.ld(XCH_CB + 13 + k), CS.a_c[k]);
         CS.finish(qlag7); Cb = CS.Cb;
       }
     }
   }
-  cube_to_lds(MS, Cb);
-  for (int k = 0; k < 7; k++) MS.st(XCH_QL7 + k, qlag7[k]);
-  MS.st(XCH_T0, touch ? 1.0 : 0.0);
+  if (lower) {
+    cube_to_lds(MS, Cb);
+    for (int k = 0; k < 7; k++) MS.st(XCH_QL7 + k, qlag7[k]);
+    MS.st(XCH_T0, touch ? 1.0 : 0.0);
+  }
   __syncthreads();                                                  // end of the env-step: the robot wave takes the cube
 }
 
@@ -571,7 +576,7 @@ MCG_DEV bool pnp_substep_robot(const Cfg& C, ModelPtr P, EnvP& E, const PnpScrat
   const bool flag = MS.ld(XCH_FLAG) != 0.0;
   const unsigned mask = (unsigned)__ballot(flag);
   if (mask != 0u) {                                                 // wave-uniform, the same in all four waves
-    coop_phase((unsigned long long)P, lds0, mask, 0);
+    coop_phase((unsigned long long)P, lds0, mask, 0, C.coop_pair != 0 ? 2 : 0);      // one environment at a time here, two in the other three waves
     MCG_TICK(ST_COUPLED);
     __syncthreads();                                                // S5
     MCG_TICK(ST_CO_IDLE);
@@ -602,15 +607,16 @@ MCG_DEV bool pnp_substep_robot(const Cfg& C, ModelPtr P, EnvP& E, const PnpScrat
   return bad;
 }
 
-// the helper / RNE waves of the four-wave PickAndPlace kernel: same barriers as the cube wave
+// the helper / RNE waves of the four-wave PickAndPlace kernel: same barriers as the cube wave; lanes 32-63 are alive for the
+// cooperative phase only
 // (inlined into the kernel: these waves hold nothing across a sub-step, so the inlined cooperative phase spills nothing)
-MCG_DEV void pnp_side_wave(ModelPtr P, const PnpScratch MS, unsigned lds0, int total, bool rne) {
+MCG_DEV void pnp_side_wave(ModelPtr P, const PnpScratch MS, unsigned lds0, int total, bool rne, bool lower, bool pair) {
   for (int s = 0; s < total; s++) {
-    if (rne) rne_substep<SplitPnp>(P, MS); else helper_substep<SplitPnp>(P, MS);      // S1, S2 inside
+    if (lower) { if (rne) rne_substep<SplitPnp>(P, MS); else helper_substep<SplitPnp>(P, MS); }      // S1, S2 inside
     __syncthreads();                                                // S4
     const unsigned mask = flagged_lanes(MS);
     if (mask != 0u) {
-      coop_phase_body(P, (LdsPtr)(uintptr_t)lds0, __builtin_amdgcn_readfirstlane(mask), rne ? 3 : 2);
+      coop_phase_body(P, (LdsPtr)(uintptr_t)lds0, __builtin_amdgcn_readfirstlane(mask), rne ? 3 : 2, pair ? 1 : 0);
       __syncthreads();                                              // S5
     }
   }
@@ -621,9 +627,12 @@ template <int CONTROLLER>
 __global__ __launch_bounds__(256) void step_pnp_kernel(Cfg C, View V, const mcg_model* __restrict__ Pg,
                                                        const float* __restrict__ actions, mcg_step_out O) {
   constexpr bool DUAL = true;                    // (the one-wave variant of rounds 1-2 went with the lane-parallel coupled solve)
-  __shared__ real lds[PNP_SLOTS_DUAL][PNP_LANES];
-  const int lane = threadIdx.x & 63;
-  if (lane >= PNP_LANES) return;                 // four waves of 32 active lanes: robot, cube, helper (M), RNE
+  __shared__ __attribute__((aligned(16))) real lds[PNP_SLOTS_DUAL][PNP_LANES];
+  // four waves over 32 environments: robot, cube, helper (M), RNE.  The robot wave runs on 32 lanes; the other three keep lanes 32-63
+  // for the cooperative phase (two environments per wave there) and mask them off everywhere else (`lower`)
+  if (threadIdx.x >= PNP_LANES && threadIdx.x < 64) return;
+  const int lane = threadIdx.x & (PNP_LANES - 1);
+  const bool lower = (threadIdx.x & PNP_LANES) == 0;
   const PnpScratch MS(&lds[0][lane]);
   const ModelPtr P = as_model_ptr(Pg);
   const int i_raw = blockIdx.x * PNP_LANES + lane;
@@ -636,9 +645,9 @@ __global__ __launch_bounds__(256) void step_pnp_kernel(Cfg C, View V, const mcg_
       const int total = (CONTROLLER == MCG_CTRL_IK ? C.control_steps : 1) * C.frame_skip;
       if (threadIdx.x < 128) {
         CubeWaveArgs A; for (int k = 0; k < 7; k++) A.qpos0_cube[k] = C.qpos0_cube[k];
-        A.cnt = C.cnt; A.coop12 = C.coop12;
-        cube_wave(A, V, P, MS, lds0, i, total);
-      } else pnp_side_wave(P, MS, lds0, total, threadIdx.x >= 192);
+        A.cnt = C.cnt; A.coop_pair = C.coop_pair;
+        cube_wave(A, V, P, MS, lds0, i, total, lower);
+      } else pnp_side_wave(P, MS, lds0, total, threadIdx.x >= 192, lower, C.coop_pair != 0);
       return;
     }
   }
@@ -934,8 +943,8 @@ int mcg_create(const mcg_config* c, const mcg_model* model, int device, mcg_env*
     // Opt-in (measured): an environment whose robot touches only static geoms gets a 12-dof cooperative solve and its
     // cube stays with the cube wave.  The solve is half the price, but the cube wave then walks those lanes' longer lists in its own
     // lane-parallel solve: no net gain at 8192 environments under a random policy (PickAndPlace-IK 11.7 against 11.3 ms per step).
-    const char* c12 = getenv("MCG_COOP12");
-    C.coop12 = (c12 && c12[0] == '1');
+    const char* cp = getenv("MCG_COOP_PAIR");
+    C.coop_pair = !(cp && cp[0] == '0');
   }
   e->view.n = C.n; e->view.nq = C.nq; e->view.nv = C.nv;
   size_t nd = (size_t)state_doubles(C.nq, C.nv) * C.n;
@@ -1066,6 +1075,14 @@ int mcg_get_state(mcg_env* e, const mcg_state* dst, void* stream) { return copy_
 uint64_t mcg_get_seed(const mcg_env* e) { return e ? (uint64_t)e->cfg.seed : 0; }
 int mcg_set_seed(mcg_env* e, uint64_t seed) { if (!e) return fail(MCG_ERR_ARG, "mcg_set_seed: null handle%s"); e->cfg.seed = seed; return MCG_OK; }
 int mcg_set_state(mcg_env* e, const mcg_state* src, void* stream) { return copy_state(e, src, 1, stream); }
+
+#ifdef MCG_COOP_DEBUG
+extern "C" int mcg_debug_coop_dump(double* out, int clear) {
+  if (out) HIP_OK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_coop_dbg), sizeof(double) * 32 * 512));
+  if (clear) { static int z[32]; static double zz[32 * 512]; HIP_OK(hipMemcpyToSymbol(HIP_SYMBOL(g_coop_dbg_done), z, sizeof(z))); HIP_OK(hipMemcpyToSymbol(HIP_SYMBOL(g_coop_dbg), zz, sizeof(zz))); }
+  return 0;
+}
+#endif
 
 int mcg_get_counters(mcg_env* e, mcg_counters* out, int clear) {
   if (!e || !out) return fail(MCG_ERR_ARG, "mcg_get_counters: null argument%s");

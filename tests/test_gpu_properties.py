@@ -228,19 +228,19 @@ def test_two_wave_and_one_wave_kernels_agree(torch_cuda, controller, monkeypatch
 
 @pytest.mark.parametrize("controller", ["joint", "mocap"])
 def test_two_cooperative_routings_agree(torch_cuda, controller, monkeypatch):
-    """PickAndPlace, two different solvers for the same sub-step: by default an environment whose robot touches anything is solved as ONE
-    18-dof problem (mcg_coop.hpp: coop_solve); with MCG_COOP12=1 an environment whose robot touches only static geoms (pad / arm mesh on
-    the table) gets a 12-dof robot-only solve and its cube stays with the cube wave's lane-parallel solve (coop_solve12, DPP broadcasts
-    instead of v_readlane).  The minimiser is unique: one env-step from identical state must agree -- scripted grasp for the joint
+    """PickAndPlace, two different solvers for the same sub-step.  By default the cooperative phase solves TWO flagged environments per wave
+    (mcg_coop.hpp: coop_solve_pair -- assembly on the matrix cores, L D L^T in one 16-lane DPP row with rows 16 / 17 carried transposed);
+    with MCG_COOP_PAIR=0 it solves one per wave with the first implementation (coop_solve: LDS-window assembly on the VALU, 18-lane
+    factorisation by v_readlane).  The minimiser is unique: one env-step from identical state must agree -- scripted grasp for the joint
     controller (cube between the pads), random mocap motion (pads and links on the table) for mocap."""
     torch = torch_cuda
     from mycobotgym_amd import MyCobotVecEnv
     n = 256
     kw = dict(has_object=True, controller_type=controller, reward_type="reward_shaping", seed=6, max_episode_steps=10 ** 9)
     a_env = MyCobotVecEnv(n, **kw)
-    monkeypatch.setenv("MCG_COOP12", "1")
+    monkeypatch.setenv("MCG_COOP_PAIR", "0")
     b_env = MyCobotVecEnv(n, **kw)
-    monkeypatch.delenv("MCG_COOP12")
+    monkeypatch.delenv("MCG_COOP_PAIR")
     a_env.reset(seed=6); b_env.reset(seed=6)
     a_env.counters(clear=True)
     g = torch.Generator(device="cuda"); g.manual_seed(0)
@@ -259,7 +259,7 @@ def test_two_cooperative_routings_agree(torch_cuda, controller, monkeypatch):
         touched += int((ra >= 50.0).sum())          # grasp / lift stage of the shaped reward: both pads on the cube
     errs = np.concatenate(errs)
     c = a_env.counters()
-    print(f"\n[{controller}] PickAndPlace 18-dof routing vs robot-only 12-dof routing, one env-step from identical state: median {np.median(errs):.2e} "
+    print(f"\n[{controller}] PickAndPlace two environments per wave vs one per wave, one env-step from identical state: median {np.median(errs):.2e} "
           f"p99 {np.quantile(errs, 0.99):.2e} max {errs.max():.2e}; env-steps with both pads on the cube: {touched}; coupled env-sub-steps {c['coupled_env_substeps']}")
     assert errs.max() < 1e-8 and c["coupled_env_substeps"] > 0
     a_env.close(); b_env.close()
