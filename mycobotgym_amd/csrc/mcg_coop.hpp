@@ -43,7 +43,10 @@ constexpr int XCH_Q = LDS_POLY + 32, XCH_QD = XCH_Q + NB, COOP_CTR_SLOT = XCH_QD
 // XCH_T1 (robot wave -> cube wave, read after S1) / XCH_BADC (cube wave -> robot wave, read after S4): the other body failed mj_checkPos /
 // mj_checkVel, mj_resetData resets both
 constexpr int XCH_BADC = COOP_CTR_SLOT + 1;
-static_assert(XCH_BADC + 1 <= LDS_POLY + 64, "exchange area");
+// XCH_ACT0 / XCH_ACT1: the active set the environment's last cooperative solve ended with, as raw bits -- [signature of the contact list |
+// rows 0-31], [rows 32-63 | rows 64-95] -- cleared at the start of an env-step.  The next sub-step's solve starts from it (see coop_guess).
+constexpr int XCH_ACT0 = XCH_BADC + 1, XCH_ACT1 = XCH_ACT0 + 1;
+static_assert(XCH_ACT1 + 1 <= LDS_POLY + 64, "exchange area");
 // Line-search row area (LDS_ROW .. LDS_ROW + 144 slot rows of PNP_LANES doubles):
 //   [0, 96)    the cube wave's own solves (12 slots per contact, list positions 0..7: a lane whose cube contacts sit higher is flagged 2);
 //              between barriers S4 and S5, when every lane-parallel solve is over: cooperative workspace, 768 doubles per wave
@@ -89,6 +92,20 @@ MCG_DEV void coop_lds_sync() {         // LDS traffic between lanes of one wave:
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
+
+// ---- the first iteration's active set (coop_guess).  The oracle's Newton iteration starts from the rows violated at the warm start
+// (last sub-step's acceleration).  Those are a poor predictor here: a contact row's residual at its solution is -f / D, micrometres per
+// second squared, and aref moves by far more than that from one sub-step to the next, so the sign of a stiff row's residual at the warm
+// start is close to a coin toss and the iteration needs 3-5 rounds to find the set again.  What does persist while a contact persists is
+// WHICH rows carry force.  So a solve leaves its final active set behind, and the next sub-step's solve of the same environment -- if
+// its contact list has the same pairs in the same order -- assembles its first system over that set.  The stopping rule is untouched: a
+// candidate x = H^-1 g is accepted only if the rows it violates are exactly the rows it was assembled over, which is the KKT condition
+// of the (strictly convex) problem; a wrong guess costs one iteration and the iteration carries on from its candidate as before.
+MCG_DEV unsigned coop_sig_step(unsigned sig, int type) { return sig * 31u + (unsigned)type + 1u; }
+MCG_DEV real coop_pack(unsigned hi, unsigned lo) { return __hiloint2double((int)hi, (int)lo); }
+#ifndef MCG_COOP_GUESS
+#define MCG_COOP_GUESS 1
+#endif
 
 // Stage clocks of the cooperative solve (-DMCG_STAGE_CLOCKS): accumulated in registers, added to the global table once per coop_phase
 // (one atomic per tick from a thousand waves would itself be the largest stage).
@@ -144,11 +161,20 @@ MCG_DEV void coop_solve(ModelPtr Pm, LdsPtr lds0, int e, LdsPtr ws, int ncon, Co
   CS.derive(Pm);
   // ---- which finger sides carry a contact (their gear / finger joint frames are posed), twist columns of the ten joints about the cube centre
   bool side_any[2] = {false, false};
+  unsigned sig = (unsigned)ncon;
   for (int c = 0; c < ncon; c++) {
     const int type = (int)ME.ld(LDS_CON + c * CON_STRIDE + 15);
     side_any[0] = side_any[0] || type == PAIR_PADR_CUBE || type == PAIR_TABLE_PADR || type == PAIR_FINR_CUBE;
     side_any[1] = side_any[1] || type == PAIR_PADL_CUBE || type == PAIR_TABLE_PADL || type == PAIR_FINL_CUBE;
+    sig = coop_sig_step(sig, type);
   }
+  sig |= 0x80000000u;
+  unsigned guess[3]; bool have_guess;
+  { const real p0 = ME.ld(XCH_ACT0), p1 = ME.ld(XCH_ACT1);
+    have_guess = MCG_COOP_GUESS && (unsigned)__double2hiint(p0) == sig;
+    guess[0] = (unsigned)__double2loint(p0); guess[1] = (unsigned)__double2hiint(p1); guess[2] = (unsigned)__double2loint(p1); }
+  unsigned fin[3] = {0u, 0u, 0u}; bool conv = false;
+  COOP_COUNT(7, have_guess ? 1 : 0);
   real tc[10][6];
   _Pragma("unroll") for (int j = 0; j < 10; j++) {
     real ax[3], d[3], v[3];
@@ -288,7 +314,6 @@ MCG_DEV void coop_solve(ModelPtr Pm, LdsPtr lds0, int e, LdsPtr ws, int ncon, Co
 
   for (int it = 0; it < 50; it++) {
     COOP_COUNT(1, 1);
-    if (it == 8) COOP_COUNT(5, 1);
     if (it == 49) COOP_COUNT(6, 1);
     // (a) residuals and the active set at a; H0 a on the way (the line search's smooth gradient)
     real r0[NSETS], h0a = 0; unsigned act[NSETS];
@@ -297,7 +322,8 @@ MCG_DEV void coop_solve(ModelPtr Pm, LdsPtr lds0, int e, LdsPtr ws, int ncon, Co
       const real aj = coop_rdlane(al, j);
       _Pragma("unroll") for (int s = 0; s < NSETS; s++) r0[s] = fma(J[s][j], aj, r0[s]);
       h0a = fma(H0[j], aj, h0a); });
-    _Pragma("unroll") for (int s = 0; s < NSETS; s++) act[s] = (unsigned)__ballot(Dr[s] > 0 && r0[s] < 0);
+    const bool use_guess = it == 0 && have_guess;                    // uniform
+    _Pragma("unroll") for (int s = 0; s < NSETS; s++) act[s] = (unsigned)__ballot(Dr[s] > 0 && sel(use_guess, ((guess[s] >> L) & 1u) != 0u, r0[s] < 0));
     MCG_TICK_PIN(r0, NSETS);
     COOP_TICK(ST_CO_RESID);
     COOP_COUNT(3, __popc(act[0]) + (NSETS > 1 ? __popc(act[1 % NSETS]) : 0) + (NSETS > 2 ? __popc(act[2 % NSETS]) : 0));
@@ -402,13 +428,14 @@ MCG_DEV void coop_solve(ModelPtr Pm, LdsPtr lds0, int e, LdsPtr ws, int ncon, Co
     bool same = true;
     _Pragma("unroll") for (int s = 0; s < NSETS; s++) same = same && ((unsigned)__ballot(Dr[s] > 0 && rx[s] < 0) == act[s]);
     COOP_TICK(ST_CO_CHECK);
+    COOP_COUNT(5, (use_guess && same) ? 1 : 0);
 #ifdef MCG_COOP_DEBUG
     const bool dbt = blockIdx.x == 0 && g_coop_dbg_done[e] == 0 && it < 8 && threadIdx.x % 64 == 0;
     if (dbt) { double* o = g_coop_dbg + e * 512 + 400 + it * 8; o[0] = __popc(act[0]) + (NSETS > 1 ? __popc(act[1 % NSETS]) : 0); o[1] = same; o[2] = 0; o[3] = -1; }
 #endif
     if (same || it < MCG_COOP_FULL_STEPS) {           // uniform.  A consistent candidate is the minimiser; the first iterations step to x anyway
       al = xl;
-      if (same) break;
+      if (same) { _Pragma("unroll") for (int s = 0; s < NSETS; s++) fin[s] = act[s]; conv = true; break; }
       continue;
     }
     // (f) exact line search from a along p = x - a: phi'(alpha) = s0 + alpha quad + sum_rows D min(0, r0 + alpha dr) dr, piecewise linear and
@@ -470,6 +497,7 @@ MCG_DEV void coop_solve(ModelPtr Pm, LdsPtr lds0, int e, LdsPtr ws, int ncon, Co
   // ---- hand the accelerations back: robot part where the warm start was, cube part in the cube's warm-start slots
   if (L < NB) ME.st(PUB_WARM + L, al);
   else if (L < COOP_NV) ME.st(XCH_CB + 13 + (L - NB), al);
+  if (L == 0) { ME.st(XCH_ACT0, coop_pack(conv ? sig : 0u, fin[0])); ME.st(XCH_ACT1, coop_pack(fin[1], fin[2])); }
   COOP_TICK(ST_CO_OUT);
 }
 
@@ -532,12 +560,22 @@ MCG_DEV void coop_solve_pair(ModelPtr Pm, LdsPtr lds0, LdsPtr wsw, int eA, int e
   CS.pm_bits = (unsigned long long)Pm;
   CS.derive(Pm);
   bool side_any[2] = {false, false};
+  unsigned sig = (unsigned)ncon;
   for (int c = 0; c < nconmax; c++) {
     const int type = (int)ME.ld(LDS_CON + sel(c < ncon, c, 0) * CON_STRIDE + 15);
     const bool in = c < ncon;
     side_any[0] = side_any[0] || (in && (type == PAIR_PADR_CUBE || type == PAIR_TABLE_PADR || type == PAIR_FINR_CUBE));
     side_any[1] = side_any[1] || (in && (type == PAIR_PADL_CUBE || type == PAIR_TABLE_PADL || type == PAIR_FINL_CUBE));
+    sig = sel(in, coop_sig_step(sig, type), sig);
   }
+  sig |= 0x80000000u;
+  unsigned guess[2]; bool have_guess;                            // (per half)
+  { const real p0 = ME.ld(XCH_ACT0), p1 = ME.ld(XCH_ACT1);
+    have_guess = MCG_COOP_GUESS && (unsigned)__double2hiint(p0) == sig;
+    guess[0] = (unsigned)__double2loint(p0); guess[1] = (unsigned)__double2hiint(p1); }
+  unsigned fin[2] = {0u, 0u}; bool conv = false;
+  static_assert(NSETS <= 2, "the pair solve carries two sets of rows");
+  COOP_COUNT(7, __popcll(__ballot(hl == 0 && have && have_guess)));
   real tc[10][6];
   _Pragma("unroll") for (int j = 0; j < 10; j++) {
     real ax[3], d[3], v[3];
@@ -552,10 +590,10 @@ MCG_DEV void coop_solve_pair(ModelPtr Pm, LdsPtr lds0, LdsPtr wsw, int eA, int e
   COOP_TICK(ST_CO_SETUP);
   // ---- rows, as in coop_solve, then scaled by sqrt(D): the cost is 1/2 sum min(0, J~ a - aref~)^2 and D never appears again
   const int nsets = (10 + 6 * nconmax + PNP_LANES - 1) / PNP_LANES;          // uniform
-  real J[NSETS][NV], aref[NSETS];
+  real J[NSETS][NV], aref[NSETS]; bool lv[NSETS];
   _Pragma("unroll") for (int s = 0; s < NSETS; s++) {
     _Pragma("unroll") for (int j = 0; j < NV; j++) J[s][j] = 0;
-    aref[s] = 0;
+    aref[s] = 0; lv[s] = false;
     if (s < nsets) {
       const int r = PNP_LANES * s + hl;
       const bool is_lim = r < 10;
@@ -609,7 +647,7 @@ MCG_DEV void coop_solve_pair(ModelPtr Pm, LdsPtr lds0, LdsPtr wsw, int eA, int e
       D = sel(is_lim, fabs(sD), D); ar = sel(is_lim, al, ar);
       const real sd = sel(have && D > 0, sqrt(D), 0.0);            // (an idle half has no rows)
       _Pragma("unroll") for (int j = 0; j < NV; j++) J[s][j] *= sd;
-      aref[s] = sd * ar;
+      aref[s] = sd * ar; lv[s] = sd > 0;
     }
   }
   MCG_TICK_PIN(aref, NSETS);
@@ -662,8 +700,10 @@ MCG_DEV void coop_solve_pair(ModelPtr Pm, LdsPtr lds0, LdsPtr wsw, int eA, int e
     _Pragma("unroll") for (int s = 0; s < NSETS; s++) r0[s] = -aref[s];
     _Pragma("unroll") for (int j = 0; j < NV; j++) { _Pragma("unroll") for (int s = 0; s < NSETS; s++) r0[s] = fma(J[s][j], av[j], r0[s]); }
     _Pragma("unroll") for (int j = 0; j < N; j++) h0a = fma(H0[j], av[j], h0a);
+    const bool use_guess = it == 0 && have_guess;                      // (per half)
     _Pragma("unroll") for (int s = 0; s < NSETS; s++) {
-      const unsigned long long b = __ballot(r0[s] < 0 && !done);       // (a finished half assembles nothing)
+      const bool on = sel(use_guess, lv[s] && ((guess[s] >> hl) & 1u) != 0u, r0[s] < 0);
+      const unsigned long long b = __ballot(on && !done);              // (a finished half assembles nothing)
       actA[s] = (unsigned)b; actB[s] = (unsigned)(b >> 32);
     }
     MCG_TICK_PIN(r0, NSETS);
@@ -810,6 +850,7 @@ MCG_DEV void coop_solve_pair(ModelPtr Pm, LdsPtr lds0, LdsPtr wsw, int eA, int e
     }
     const bool same = sel(up, sameB, sameA);
     COOP_TICK(ST_CO_CHECK);
+    COOP_COUNT(5, __popcll(__ballot(hl == 0 && have && use_guess && same)));
     const bool full = same || it < MCG_COOP_FULL_STEPS;
     const bool need = !done && !full;                // this half wants a line search
 #ifdef MCG_COOP_DEBUG
@@ -818,6 +859,9 @@ MCG_DEV void coop_solve_pair(ModelPtr Pm, LdsPtr lds0, LdsPtr wsw, int eA, int e
       o[0] = __popc(a0) + (NSETS > 1 ? __popc(a1) : 0); o[1] = same; o[2] = 0; o[3] = -1; }
 #endif
     if (!done && full) { am = xm; a6 = x6; a7 = x7; }
+    { const bool fresh = !done && same;
+      _Pragma("unroll") for (int s = 0; s < NSETS; s++) fin[s] = sel(fresh, sel(up, actB[s], actA[s]), fin[s]);
+      conv = conv || fresh; }
     done = done || same;
     if (__any(need)) {
       // (f) exact line search (see coop_solve), each half its own; a half that needs none walks along with frozen numbers
@@ -882,7 +926,8 @@ MCG_DEV void coop_solve_pair(ModelPtr Pm, LdsPtr lds0, LdsPtr wsw, int eA, int e
   if (have && (drow & 1) == 0) {
     if (l16 < NB) ME.st(PUB_WARM + l16, am);
     else ME.st(XCH_CB + 13 + (l16 - NB), am);
-    if (l16 == 0) { ME.st(XCH_CB + 13 + 4, a6); ME.st(XCH_CB + 13 + 5, a7); }
+    if (l16 == 0) { ME.st(XCH_CB + 13 + 4, a6); ME.st(XCH_CB + 13 + 5, a7);
+                    ME.st(XCH_ACT0, coop_pack(conv ? sig : 0u, fin[0])); ME.st(XCH_ACT1, coop_pack(fin[1 % NSETS], 0u)); }
   }
   COOP_TICK(ST_CO_OUT);
 }

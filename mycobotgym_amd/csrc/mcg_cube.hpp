@@ -334,6 +334,7 @@ struct CubeSys {
 
     // ---- P4 collision, in the oracle's pair order (the cap of MAXCON contacts then cuts the same tail): arm-side meshes on the
     // ground / the table (mesh by mesh), then the primitive geoms: ground-pads, ground-cube, table-pads, table-cube, pads-cube
+    MCG_TICK2(ST_A_ENTRY);
     ContactList<LS> CL{S, 0};
     real hc[3]; ldc<3>(Q->cube_half, hc);
     real tp[3], th[3]; ldc<3>(Q->table_pos, tp); ldc<3>(Q->table_half, th);
@@ -444,6 +445,7 @@ struct CubeSys {
           hull(i, R, p);
           if constexpr (i == 5) { hull(6, R, p); hull(7, R, p); }
         } });
+      MCG_TICK2(ST_A_G);
       const real dxe = p[0] - Cb.pos[0], dye = p[1] - Cb.pos[1], dze = p[2] - Cb.pos[2];
       reach = dxe*dxe + dye*dye + dze*dze < 0.2 * 0.2;                  // link6 origin within 20 cm of the cube
       _Pragma("unroll") for (int k = 0; k < 9; k++) R6[k] = R[k];
@@ -482,6 +484,7 @@ struct CubeSys {
     // table: pads, cube.  The table is a static axis-aligned box: its three face axes are separating axes of the SAT, so
     // "the pad's extent along one of them clears the table" skips the pair with the result the full test would give.
     const real Rt[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    MCG_TICK2(ST_A_TWIST);
     static_for<2>([&](auto Sd) { constexpr int sd = Sd;
       bool near = padlive;
       _Pragma("unroll") for (int k = 0; k < 3; k++) {
@@ -493,6 +496,7 @@ struct CubeSys {
         box_box(CL, near, tp, Rt, th, pc[sd], Rs[sd], ph[sd], PAIR_TABLE_PADR + sd);
         any_pad = any_pad || (CL.n > before);
       } });
+    MCG_TICK2(ST_A_LOOP);
     {
       const real dx = Cb.pos[0] - tp[0], dy = Cb.pos[1] - tp[1], dz = Cb.pos[2] - tp[2];
       const real rs = sqrt(dot3(th, th)) + sqrt(dot3(hc, hc));
@@ -510,6 +514,7 @@ struct CubeSys {
         touch[sd] = CL.n > before;
         any_pad = any_pad || touch[sd]; });
     }
+    MCG_TICK2(ST_A_MAP);
     // Finger-link meshes - cube (second stage; the oracle's box_polytope with full = 1, the mesh as geom1): right, left.  Separating-axis test over the cube's three face axes and the
     // polytope's 13 canonical axes, ONE contact along the axis of least penetration: a cube face -> at the polytope's deepest vertex;
     // a polytope axis -> at the cube's deepest corner along it.  Each entry stands for the two identical geoms the reference attaches.
@@ -595,6 +600,7 @@ struct CubeSys {
       mesh_cube(0, Rs[0], pf[0], PAIR_FINR_CUBE);
       mesh_cube(1, Rs[1], pf[1], PAIR_FINL_CUBE);
     }
+    MCG_TICK2(ST_A_STORE);
     ncon = CL.n; ndropped = CL.ndrop;
     if (__any(CL.ndrop > 0)) { if (CL.ndrop > 0 && cnt) atomicAdd(cnt + 2, (unsigned long long)CL.ndrop); }      // MAXCON cut the list (MuJoCo has no such cap)
     scan_sides();

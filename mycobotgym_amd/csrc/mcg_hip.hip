@@ -660,7 +660,8 @@ __global__ __launch_bounds__(256) void step_pnp_kernel(Cfg C, View V, const mcg_
   const bool bad0 = guard_robot(E.R, E.qlag6);   // the state as loaded (a caller may have set it): mj_step's first check
   bool hadbad = bad0;
   if constexpr (DUAL) { static_for<NB>([&](auto I) { constexpr int k = I; MS.st(XCH_Q + k, E.R.q[k]); MS.st(XCH_QD + k, E.R.qd[k]); });   // q(0), qd(0) for the other waves
-                        MS.st(XCH_T1, hadbad ? 1.0 : 0.0); }
+                        MS.st(XCH_T1, hadbad ? 1.0 : 0.0);
+                        MS.st(XCH_ACT0, 0.0); MS.st(XCH_ACT1, 0.0); }       // no active set carried into an env-step (mcg_coop.hpp: coop_guess)
   MCG_TICK(ST_LOAD);
   E.touch = false;
   int nsub = 0;

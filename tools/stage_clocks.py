@@ -18,15 +18,15 @@ NAMES = ["load", "controller", "sincos", "rne", "actuation", "crb->M", "rows: we
          "rows: arm axes in link6 frame", "rows: connects + coupling", "rows: limits",
          "coupled: initial masks", "coupled: assembly over contacts", "coupled: Schur complement", "coupled: LDL + back-substitution",
          "coupled: consistency + line-search rows", "coupled: line search + remask",
-         "cube wave: waiting for q (S1)", "cube wave: collision", "cube wave: solve + finish", "cube wave: waiting at S2",
+         "cube wave: waiting for q (S1)", "cube wave: collision (rest: per-contact solver numbers)", "cube wave: solve + finish", "cube wave: waiting at S2",
          "robot wave: waiting at S2",
-         "assemble phase: entry loads", "assemble phase: G <- H_eq, Cm <- 0", "assemble phase: twist columns, relative twists",
-         "assemble phase: contact loop", "assemble phase: mapping to dofs", "assemble phase: stores",
+         "collision: cube frame, pair numbers", "collision: arm chain + arm meshes on table / ground", "collision: pad frames, ground plane",
+         "collision: table - pads", "collision: table - cube, pads - cube", "collision: gripper base / finger links - cube",
          "coop: env data, twist columns", "coop: rows", "coop: H0, g0", "coop: residuals, active set", "coop: assembly (LDS window)",
          "coop: gradient + LDL", "coop: solves + transpose", "coop: consistency check", "coop: line search", "coop: hand back", "coop: idle at S5"]
 COUNTS = ["robot sub-steps", "robot Newton iterations", "robot line searches", "cube Newton iterations", "cube line searches",
           "coupled solves", "coupled Newton iterations", "coupled line searches", "wave-max contacts (per collision pass)",
-          "coop active rows (sum over iterations)", "coop line-search evaluations", "coop solves of 9+ iterations", "coop solves at the 50-iteration cap", "coop 12-dof solves"]
+          "coop active rows (sum over iterations)", "coop line-search evaluations", "coop solves whose carried active set was confirmed at once", "coop solves at the 50-iteration cap", "coop solves that started from a carried active set"]
 fresh = "--fresh-actions" in sys.argv
 grasp = "--grasp" in sys.argv           # PickAndPlace joint with every env holding the cube (scripted grasp state)
 L = _abi.load()
