@@ -260,6 +260,130 @@ MCG_DEV void pyramid_row(const CubeRows& R, int r, const real* mu, real* j) {
   _Pragma("unroll") for (int d = 0; d < 6; d++) { const real jk = sel3(k, R.J1[d], R.J2[d], R.Jt[d]); j[d] = R.Jn[d] + m * jk; }
 }
 
+// Arm-side mesh geoms (support polytopes) against the ground plane and the table, body by body as the chain is walked: the oracle's
+// rule (mco_collision.c: plane_polytope / box_polytope) -- separating-axis test over the table's face axes, ONE contact at the
+// deepest vertex along the face of least penetration; the deepest vertex below z = 0 for the ground.  Broad phase: the lowest
+// point of the vertices' bounding box in the body frame.
+template <class SINK>
+MCG_DEV void mesh_table_ground(ModelPtr Pm, int pi, const real* Rio, const real* pio, const real* tp, const real* th, SINK& CL) {
+    ModelPtr H = launder(Pm);
+    real bx[6]; ldc<6>(H->link_hull_box[pi], bx);
+    const real cz = pio[2] + Rio[6] * bx[0] + Rio[7] * bx[1] + Rio[8] * bx[2];
+    const real ez = fabs(Rio[6]) * bx[3] + fabs(Rio[7]) * bx[4] + fabs(Rio[8]) * bx[5];
+    if (!__any(cz - ez < tp[2] + th[2])) return;                      // wave-uniform: nothing of it reaches the table top's height
+    real lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY}, wz[3] = {0, 0, 0};
+    // four vertices per batch of scalar loads: a wave alone on its SIMD pays every s_load round trip in full, and 26 dependent
+    // ones per mesh were most of this pass under a policy that keeps the arm near the table (the last batch repeats vertex 25:
+    // a repeated vertex changes neither the extremes nor the first lowest one)
+    for (int kb = 0; kb < 26; kb += 4) {
+      real v4[4][3];
+      { ModelPtr Hb = launder(Pm);
+        _Pragma("unroll") for (int u = 0; u < 4; u++) { const int k = sel(kb + u < 26, kb + u, 25); ldc<3>(Hb->link_hull[pi][k], v4[u]); } }
+      _Pragma("unroll") for (int u = 0; u < 4; u++) {
+        real w[3];
+        _Pragma("unroll") for (int r = 0; r < 3; r++) w[r] = pio[r] + Rio[3*r]*v4[u][0] + Rio[3*r+1]*v4[u][1] + Rio[3*r+2]*v4[u][2];
+        const bool lower = w[2] < lo[2];                               // first occurrence of the minimum, as the oracle keeps it
+        _Pragma("unroll") for (int r = 0; r < 3; r++) { wz[r] = sel(lower, w[r], wz[r]); lo[r] = fmin(lo[r], w[r]); hi[r] = fmax(hi[r], w[r]); }
+      }
+    }
+    const int mult = (int)H->link_mult;
+    {   // ground plane z = 0
+      const real n[3] = {0, 0, 1};
+      const real pos[3] = {wz[0], wz[1], wz[2] - 0.5 * lo[2]};
+      CL.add(pos, n, lo[2] < 0 ? lo[2] : 1.0, PAIR_TABLE_LINK0 + pi, mult);
+    }
+    {   // table (static, axis-aligned): faces +-x, +-y, +-z
+      bool sep = false; real depth = INFINITY; int axis = 0; bool plus = true;
+      _Pragma("unroll") for (int a = 0; a < 3; a++) {
+        const real l = lo[a] - tp[a], hgh = hi[a] - tp[a];
+        sep = sep || (l > th[a]) || (hgh < -th[a]);
+        const real dp = th[a] - l, dn = hgh + th[a];
+        const bool tp_ = dp < depth;                                   // selects, no lane-divergent branch (compiler hazard, mcg_dynamics.hpp)
+        depth = sel(tp_, dp, depth); axis = sel(tp_, a, axis); plus = sel(tp_, true, plus);
+        const bool tn_ = dn < depth;
+        depth = sel(tn_, dn, depth); axis = sel(tn_, a, axis); plus = sel(tn_, false, plus);
+      }
+      // ... or one of the polytope's own 13 canonical axes separates (mcg_model.link_ext): without them a link diagonally off an
+      // edge of the table counts as touching whenever its table-aligned extent overlaps the table
+      if (__any(!sep)) {
+        real ext[26]; ldc<26>(&H->link_ext[pi][0][0], ext);
+        static_for<13>([&](auto Kk) { constexpr int k = Kk;
+          real w[3];
+          _Pragma("unroll") for (int r = 0; r < 3; r++) w[r] = MCG_DIR13[k][0] * Rio[3*r] + MCG_DIR13[k][1] * Rio[3*r+1] + MCG_DIR13[k][2] * Rio[3*r+2];
+          const real rel = (pio[0] - tp[0]) * w[0] + (pio[1] - tp[1]) * w[1] + (pio[2] - tp[2]) * w[2];
+          const real rad = th[0] * fabs(w[0]) + th[1] * fabs(w[1]) + th[2] * fabs(w[2]);
+          sep = sep || (rel + ext[2*k] > rad) || (rel + ext[2*k + 1] < -rad); });
+      }
+      const bool topface = (axis == 2) && plus;
+      real wd[3] = {wz[0], wz[1], wz[2]};
+      if (__any(!sep && !topface)) {                                   // rare: a side or bottom face wins: find that face's deepest vertex
+        real best = INFINITY;
+        for (int k = 0; k < 26; k++) {
+          real v[3]; ldc<3>(H->link_hull[pi][k], v);
+          real w[3];
+          _Pragma("unroll") for (int r = 0; r < 3; r++) w[r] = pio[r] + Rio[3*r]*v[0] + Rio[3*r+1]*v[1] + Rio[3*r+2]*v[2];
+          const real c = sel3(axis, w[0], w[1], w[2]);
+          const real key = plus ? c : -c;                              // face +a: the smallest coordinate; face -a: the largest
+          const bool better = !topface && key < best;
+          best = sel(better, key, best);
+          _Pragma("unroll") for (int r = 0; r < 3; r++) wd[r] = sel(better, w[r], wd[r]);
+        }
+      }
+      real n[3] = {0, 0, 0};
+      _Pragma("unroll") for (int r = 0; r < 3; r++) n[r] = (r == axis) ? (plus ? 1.0 : -1.0) : 0.0;
+      const real pos[3] = {wd[0] + 0.5 * depth * n[0], wd[1] + 0.5 * depth * n[1], wd[2] + 0.5 * depth * n[2]};
+      CL.add(pos, n, sep ? 1.0 : -depth, PAIR_TABLE_LINK0 + pi, mult);
+    }
+}
+
+// ---- the arm-side mesh pass on the M / RNE waves of the four-wave kernel (round 3).  The cube wave's collision pass was the longest
+// stretch of a PickAndPlace-IK sub-step (92 k of ~215 k clocks, half of it the eight arm meshes against the table: stage clocks in
+// profiles/r03/stage_clocks_collision_split.log) while the M and RNE waves, done after ~10 k, waited for it at S2.  They now walk the arm
+// chain themselves (from the sines / cosines they hold anyway) and test four meshes each -- M: links 1-4, RNE: links 5, 6, flange,
+// gripper base -- leaving their contacts in a staging area (the row area, unused between S1 and S2); after barrier S1b the cube wave
+// puts them IN FRONT of its own entries (the oracle's pair order) and applies the cap of MAXCON to the merged list (CubeSys::merge_staged).
+constexpr int STAGE_STRIDE = 8, STAGE_A = LDS_ROW, STAGE_B = LDS_ROW + 8 * STAGE_STRIDE, STAGE_NA = LDS_ROW + 16 * STAGE_STRIDE, STAGE_NB = STAGE_NA + 1;
+static_assert(STAGE_NB + 1 <= LDS_ROW + MAXCON * 12, "staging area");
+template <class LS>
+struct MeshStage {        // pos[3] normal[3] dist type; a wave's four meshes give at most eight entries (ground and table each)
+  const LS S; int base; int n = 0;
+  MCG_DEV void add(const real* pos, const real* normal, real dist, int type, int) {
+    const bool ok = dist < 0;
+    if (ok) {
+      const int b = base + n * STAGE_STRIDE;
+      _Pragma("unroll") for (int k = 0; k < 3; k++) { S.st(b + k, pos[k]); S.st(b + 3 + k, normal[k]); }
+      S.st(b + 6, dist); S.st(b + 7, (real)type);
+    }
+    n += sel(ok, 1, 0);
+  }
+};
+template <int P0, int P1, class LS>
+MCG_DEV void arm_mesh_stage(ModelPtr Pm, const LS S, const real* sn, const real* cs, int base, int count_slot) {
+  ModelPtr Q = launder(Pm);
+  real tp[3], th[3]; ldc<3>(Q->table_pos, tp); ldc<3>(Q->table_half, th);
+  real R[9], p[3];
+  _Pragma("unroll") for (int k = 0; k < 9; k++) R[k] = Q->base_mat[k];
+  _Pragma("unroll") for (int k = 0; k < 3; k++) p[k] = Q->base_pos[k];
+  MeshStage<LS> ST{S, base};
+  constexpr int LASTB = P1 - 1 < 5 ? P1 - 1 : 5;                 // polytope p rides on arm body min(p, 5)
+  static_for<LASTB + 1>([&](auto I) { constexpr int i = I; constexpr int K = AXK[i]; constexpr int A = (K + 1) % 3, B = (K + 2) % 3;
+    real r[3]; ldc<3>(Q->body[i].r, r);
+    const real rad = Q->body[i].hull_rad;
+    _Pragma("unroll") for (int k = 0; k < 3; k++) p[k] += R[3*k]*r[0] + R[3*k+1]*r[1] + R[3*k+2]*r[2];
+    const real sn_ = sn[i], cs_ = cs[i];                         // of AXS[i] * q[i], as the cube wave's own walk computes them
+    _Pragma("unroll") for (int k = 0; k < 3; k++) {
+      const real ca = R[3*k + A], cb = R[3*k + B];
+      R[3*k + A] = cs_ * ca + sn_ * cb; R[3*k + B] = -sn_ * ca + cs_ * cb;
+    }
+    if constexpr (i >= (P0 < 5 ? P0 : 5)) {
+      if (__any(p[2] - rad < tp[2] + th[2])) {                    // wave-uniform: the body's bounding sphere reaches the table top's height
+        if constexpr (i < 5) mesh_table_ground(Pm, i, R, p, tp, th, ST);
+        else { static_for<P1 - (P0 > 5 ? P0 : 5)>([&](auto Mm) { constexpr int m = (P0 > 5 ? P0 : 5) + Mm; mesh_table_ground(Pm, m, R, p, tp, th, ST); }); }
+      }
+    } });
+  S.st(count_slot, (real)ST.n);
+}
+
 // The cube and its contacts for one sub-step: prepared before the robot's Newton solve, finished after it.
 template <class LS>
 struct CubeSys {
@@ -309,6 +433,64 @@ struct CubeSys {
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)pm_bits), hi = __builtin_amdgcn_readfirstlane((unsigned)(pm_bits >> 32));
     return (ModelPtr)(((unsigned long long)hi << 32) | lo);
   }
+  // The M / RNE waves' staged arm-mesh contacts go IN FRONT of this wave's entries (the oracle's pair order: arm meshes first), and the
+  // cap of MAXCON contacts is applied to the merged list as ContactList::add applies it entry by entry: a mesh entry stands for
+  // link_mult identical contacts, this wave's entries keep min(their take, what is left).
+  MCG_DEV void merge_staged(ModelPtr Pm, ContactList<LS>& CL) {
+    const int nA = (int)S.ld(STAGE_NA), nB = (int)S.ld(STAGE_NB), nM = nA + nB;
+    if (!__any(nM > 0)) return;                                          // wave-uniform
+    const int mult = (int)launder(Pm)->link_mult;
+    int ncap = 0, km = 0, drop = 0;
+    for (int e = 0; __any(e < nM); e++) {
+      const bool in = e < nM;
+      const int take = sel(mult < MAXCON - ncap, mult, MAXCON - ncap);
+      const bool ok = in && take > 0;
+      km += sel(ok, 1, 0); ncap += sel(ok, take, 0); drop += sel(in, mult - sel(take > 0, take, 0), 0);
+    }
+    const int nC = CL.n;
+    int kc = 0;
+    for (int c = 0; __any(c < nC); c++) {
+      const bool in = c < nC;
+      const int slot = LDS_CON + sel(in, c, 0) * CON_STRIDE + 13;
+      const int tl = sel(in, (int)S.ld(slot), 0);
+      const int take = sel(tl < MAXCON - ncap, tl, MAXCON - ncap);
+      const bool ok = in && take > 0;
+      if (ok && take != tl) S.st(slot, (real)take);
+      kc += sel(ok, 1, 0); ncap += sel(ok, take, 0); drop += sel(in, tl - sel(take > 0, take, 0), 0);
+    }
+    for (int c = MAXCON - 1; c >= 0; c--) {                              // this wave's kept entries move up by km, top down
+      const bool mv = c < kc && km > 0;
+      if (__any(mv)) {
+        if (mv) {
+          real v[CON_STRIDE];
+          _Pragma("unroll") for (int k = 0; k < CON_STRIDE; k++) v[k] = S.ld(LDS_CON + c * CON_STRIDE + k);
+          _Pragma("unroll") for (int k = 0; k < CON_STRIDE; k++) S.st(LDS_CON + (c + km) * CON_STRIDE + k, v[k]);
+        }
+      }
+    }
+    for (int e = 0; __any(e < km); e++) {
+      if (e < km) {
+        const int src = sel(e < nA, STAGE_A + e * STAGE_STRIDE, STAGE_B + (e - nA) * STAGE_STRIDE);
+        real pos[3], nrm[3], t1[3], t2[3];
+        _Pragma("unroll") for (int k = 0; k < 3; k++) { pos[k] = S.ld(src + k); nrm[k] = S.ld(src + 3 + k); }
+        const real dist = S.ld(src + 6), type = S.ld(src + 7);
+        make_frame(nrm, t1, t2);
+        const int take = sel(mult < MAXCON - e * mult, mult, MAXCON - e * mult);
+        const int b = LDS_CON + e * CON_STRIDE;
+        _Pragma("unroll") for (int k = 0; k < 3; k++) { S.st(b + k, pos[k]); S.st(b + 3 + k, nrm[k]); S.st(b + 6 + k, t1[k]); S.st(b + 9 + k, t2[k]); }
+        S.st(b + 12, dist); S.st(b + 13, (real)take); S.st(b + 15, type);
+      }
+    }
+    CL.n = km + kc; CL.ncap = ncap; CL.ndrop += drop;
+    // what the list now holds decides the flags (the cap may have cut an entry this wave had room for)
+    any_pad = false; touch[0] = touch[1] = false;
+    for (int c = 0; __any(c < CL.n); c++) {
+      const int type = sel(c < CL.n, (int)S.ld(LDS_CON + sel(c < CL.n, c, 0) * CON_STRIDE + 15), PAIR_TABLE_CUBE);
+      any_pad = any_pad || type != PAIR_TABLE_CUBE;
+      touch[0] = touch[0] || type == PAIR_PADR_CUBE; touch[1] = touch[1] || type == PAIR_PADL_CUBE;
+    }
+  }
+
   MCG_DEV void scan_sides() {
     side_on[0] = side_on[1] = tab_on = stat_on = base_on = false; cube_hi = -1; cube_lo = 0;
     for (int c = 0; __any(c < ncon); c++) {
@@ -320,6 +502,8 @@ struct CubeSys {
       tab_on = tab_on || ((c < ncon) && pair_has_cube(type) && pair_class(type) == 0); stat_on = stat_on || ((c < ncon) && !pair_has_cube(type));
     }
   }
+  // SPLIT (the cube wave of the four-wave kernel): the arm meshes are tested by the M / RNE waves meanwhile and merged in after S1b
+  template <bool SPLIT = false>
   MCG_DEV void prepare(ModelPtr Pm, const real* qr) {
     pm_bits = (unsigned long long)Pm;
     {   // mj_kinematics normalises the stored quaternion
@@ -362,80 +546,10 @@ struct CubeSys {
           Rio[3*k + A] = cs_ * ca + sn_ * cb; Rio[3*k + B] = -sn_ * ca + cs_ * cb;
         }
       };
-      // Arm-side mesh geoms (support polytopes) against the ground plane and the table, body by body as the chain is walked: the oracle's
-      // rule (mco_collision.c: plane_polytope / box_polytope) -- separating-axis test over the table's face axes, ONE contact at the
-      // deepest vertex along the face of least penetration; the deepest vertex below z = 0 for the ground.  Broad phase: the lowest
-      // point of the vertices' bounding box in the body frame.
       auto hull = [&](int pi, const real* Rio, const real* pio) {
-        ModelPtr H = launder(Pm);
-        real bx[6]; ldc<6>(H->link_hull_box[pi], bx);
-        const real cz = pio[2] + Rio[6] * bx[0] + Rio[7] * bx[1] + Rio[8] * bx[2];
-        const real ez = fabs(Rio[6]) * bx[3] + fabs(Rio[7]) * bx[4] + fabs(Rio[8]) * bx[5];
-        if (!__any(cz - ez < tp[2] + th[2])) return;                      // wave-uniform: nothing of it reaches the table top's height
-        real lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY}, wz[3] = {0, 0, 0};
-        // four vertices per batch of scalar loads: a wave alone on its SIMD pays every s_load round trip in full, and 26 dependent
-        // ones per mesh were most of this pass under a policy that keeps the arm near the table (the last batch repeats vertex 25:
-        // a repeated vertex changes neither the extremes nor the first lowest one)
-        for (int kb = 0; kb < 26; kb += 4) {
-          real v4[4][3];
-          { ModelPtr Hb = launder(Pm);
-            _Pragma("unroll") for (int u = 0; u < 4; u++) { const int k = sel(kb + u < 26, kb + u, 25); ldc<3>(Hb->link_hull[pi][k], v4[u]); } }
-          _Pragma("unroll") for (int u = 0; u < 4; u++) {
-            real w[3];
-            _Pragma("unroll") for (int r = 0; r < 3; r++) w[r] = pio[r] + Rio[3*r]*v4[u][0] + Rio[3*r+1]*v4[u][1] + Rio[3*r+2]*v4[u][2];
-            const bool lower = w[2] < lo[2];                               // first occurrence of the minimum, as the oracle keeps it
-            _Pragma("unroll") for (int r = 0; r < 3; r++) { wz[r] = sel(lower, w[r], wz[r]); lo[r] = fmin(lo[r], w[r]); hi[r] = fmax(hi[r], w[r]); }
-          }
-        }
-        const int mult = (int)H->link_mult;
+        if constexpr (SPLIT) return;                                      // (the M / RNE waves test the arm meshes: arm_mesh_stage)
         const int before = CL.n;
-        {   // ground plane z = 0
-          const real n[3] = {0, 0, 1};
-          const real pos[3] = {wz[0], wz[1], wz[2] - 0.5 * lo[2]};
-          CL.add(pos, n, lo[2] < 0 ? lo[2] : 1.0, PAIR_TABLE_LINK0 + pi, mult);
-        }
-        {   // table (static, axis-aligned): faces +-x, +-y, +-z
-          bool sep = false; real depth = INFINITY; int axis = 0; bool plus = true;
-          _Pragma("unroll") for (int a = 0; a < 3; a++) {
-            const real l = lo[a] - tp[a], hgh = hi[a] - tp[a];
-            sep = sep || (l > th[a]) || (hgh < -th[a]);
-            const real dp = th[a] - l, dn = hgh + th[a];
-            const bool tp_ = dp < depth;                                   // selects, no lane-divergent branch (compiler hazard, mcg_dynamics.hpp)
-            depth = sel(tp_, dp, depth); axis = sel(tp_, a, axis); plus = sel(tp_, true, plus);
-            const bool tn_ = dn < depth;
-            depth = sel(tn_, dn, depth); axis = sel(tn_, a, axis); plus = sel(tn_, false, plus);
-          }
-          // ... or one of the polytope's own 13 canonical axes separates (mcg_model.link_ext): without them a link diagonally off an
-          // edge of the table counts as touching whenever its table-aligned extent overlaps the table
-          if (__any(!sep)) {
-            real ext[26]; ldc<26>(&H->link_ext[pi][0][0], ext);
-            static_for<13>([&](auto Kk) { constexpr int k = Kk;
-              real w[3];
-              _Pragma("unroll") for (int r = 0; r < 3; r++) w[r] = MCG_DIR13[k][0] * Rio[3*r] + MCG_DIR13[k][1] * Rio[3*r+1] + MCG_DIR13[k][2] * Rio[3*r+2];
-              const real rel = (pio[0] - tp[0]) * w[0] + (pio[1] - tp[1]) * w[1] + (pio[2] - tp[2]) * w[2];
-              const real rad = th[0] * fabs(w[0]) + th[1] * fabs(w[1]) + th[2] * fabs(w[2]);
-              sep = sep || (rel + ext[2*k] > rad) || (rel + ext[2*k + 1] < -rad); });
-          }
-          const bool topface = (axis == 2) && plus;
-          real wd[3] = {wz[0], wz[1], wz[2]};
-          if (__any(!sep && !topface)) {                                   // rare: a side or bottom face wins: find that face's deepest vertex
-            real best = INFINITY;
-            for (int k = 0; k < 26; k++) {
-              real v[3]; ldc<3>(H->link_hull[pi][k], v);
-              real w[3];
-              _Pragma("unroll") for (int r = 0; r < 3; r++) w[r] = pio[r] + Rio[3*r]*v[0] + Rio[3*r+1]*v[1] + Rio[3*r+2]*v[2];
-              const real c = sel3(axis, w[0], w[1], w[2]);
-              const real key = plus ? c : -c;                              // face +a: the smallest coordinate; face -a: the largest
-              const bool better = !topface && key < best;
-              best = sel(better, key, best);
-              _Pragma("unroll") for (int r = 0; r < 3; r++) wd[r] = sel(better, w[r], wd[r]);
-            }
-          }
-          real n[3] = {0, 0, 0};
-          _Pragma("unroll") for (int r = 0; r < 3; r++) n[r] = (r == axis) ? (plus ? 1.0 : -1.0) : 0.0;
-          const real pos[3] = {wd[0] + 0.5 * depth * n[0], wd[1] + 0.5 * depth * n[1], wd[2] + 0.5 * depth * n[2]};
-          CL.add(pos, n, sep ? 1.0 : -depth, PAIR_TABLE_LINK0 + pi, mult);
-        }
+        mesh_table_ground(Pm, pi, Rio, pio, tp, th, CL);
         any_pad = any_pad || (CL.n > before);
       };
       static_for<6>([&](auto I) { constexpr int i = I; real r[3]; ldc<3>(Q->body[i].r, r);
@@ -601,6 +715,7 @@ struct CubeSys {
       mesh_cube(1, Rs[1], pf[1], PAIR_FINL_CUBE);
     }
     MCG_TICK2(ST_A_STORE);
+    if constexpr (SPLIT) { __syncthreads(); merge_staged(Pm, CL); }       // S1b
     ncon = CL.n; ndropped = CL.ndrop;
     if (__any(CL.ndrop > 0)) { if (CL.ndrop > 0 && cnt) atomicAdd(cnt + 2, (unsigned long long)CL.ndrop); }      // MAXCON cut the list (MuJoCo has no such cap)
     scan_sides();

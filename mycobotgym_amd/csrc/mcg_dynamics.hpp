@@ -383,6 +383,7 @@ typedef LaneScratchT<64> LaneScratch;
 // Coupling hook: PickAndPlace passes an object that, when a finger pad touches the cube, solves the robot and cube
 // accelerations together (the Euler step needs no constraint force: M a carries it).  Reach passes NoCoupling (compiled out).
 struct NoCoupling { static constexpr bool enabled = false, publishes = false; };
+struct NoSideWork { MCG_DEV void operator()(const real*, const real*) const {} };      // what a helper / RNE wave does after its own share, before S1b
 // A hook with `publishes` (and not `enabled`) is handed the Newton system's smooth right-hand side and the limit rows once they are
 // complete: the four-wave PickAndPlace kernel parks them in LDS for the cooperative coupled solve (mcg_coop.hpp).
 
@@ -611,9 +612,9 @@ MCG_DEV void euler_accel(ModelPtr Pm, real h, const LS MS, const real* a, real* 
 // read it; only the rare general iteration does -- but in registers it stays live through the factorisation, the kernel's register peak.
 // With it the Euler step also re-reads q(t), qd(t) from the slots they were published in for the other waves (QB, QDB) instead of
 // carrying them through the solve, and the lagged configuration (q of this forward pass, for observations and IK) goes to slots QLAG.
-struct NoSplit { static constexpr bool enabled = false, rne_remote = false, factor_remote = false, early_heq = false, warm_lds = false;
+struct NoSplit { static constexpr bool enabled = false, rne_remote = false, factor_remote = false, early_heq = false, warm_lds = false, mesh_split = false;
                  static constexpr int QB = 0, QDB = 0, FS = 0, WARM = 0, QLAG = 0; };
-struct SplitMain { static constexpr bool enabled = true, rne_remote = true, factor_remote = true, early_heq = true, warm_lds = true;
+struct SplitMain { static constexpr bool enabled = true, rne_remote = true, factor_remote = true, early_heq = true, warm_lds = true, mesh_split = false;
                    static constexpr int QB = LDS_QB, QDB = LDS_QDB, FS = LDS_FS, WARM = LDS_WARM, QLAG = LDS_QLAG; };
 
 // COMMIT = false: the new q / qd / qacc_warmstart go to *next and S stays as it was (speculative sub-step of the two-wave
@@ -854,6 +855,7 @@ MCG_DEV bool robot_substep(ModelPtr Pm, Robot& S, real* qlag6, const LS MS, CPL*
       static_for<6>([&](auto I) { constexpr int j = I; g0[j] = fma(Jw[r][j], da, g0[j]); }); });
   if constexpr (SPL::early_heq) assemble_heq(std::false_type{});      // J^T D J only: M is not there yet
   if constexpr (SPL::enabled) {
+    if constexpr (SPL::mesh_split) __syncthreads();                 // S1b (four-wave PickAndPlace kernel: the M / RNE waves' arm-mesh contacts are staged)
     __syncthreads();                                                // S2: M and passive - bias are in LDS
     if constexpr (SPL::rne_remote) static_for<NB>([&](auto I) { constexpr int i = I; fs[i] += MS.ld(SPL::FS + i); });
   }
@@ -1081,8 +1083,8 @@ MCG_DEV bool robot_substep(ModelPtr Pm, Robot& S, real* qlag6, const LS MS, CPL*
 }
 
 // The helper wave's share of one sub-step (see SplitMain).
-template <class SPL = SplitMain, class LS>
-MCG_DEV void helper_substep(ModelPtr Pm, const LS MS) {
+template <class SPL = SplitMain, class LS, class SIDE = NoSideWork>
+MCG_DEV void helper_substep(ModelPtr Pm, const LS MS, const SIDE& side = SIDE{}) {
   __syncthreads();                                                  // S1
   real cs[NB], sn[NB];
   {
@@ -1092,6 +1094,7 @@ MCG_DEV void helper_substep(ModelPtr Pm, const LS MS) {
   static_for<NB>([&](auto I) { constexpr int i = I; pin(sn[i]); pin(cs[i]); });
   MCG_FENCE();
   crb_to_lds(Pm, cs, sn, MS);
+  if constexpr (SPL::mesh_split) { side(sn, cs); __syncthreads(); } // S1b
   __syncthreads();                                                  // S2
   if constexpr (SPL::factor_remote) {
     const real h = launder(Pm)->timestep;
@@ -1107,8 +1110,8 @@ MCG_DEV void helper_substep(ModelPtr Pm, const LS MS) {
 }
 
 // The RNE wave's share of one sub-step (see SplitMain).
-template <class SPL = SplitMain, class LS>
-MCG_DEV void rne_substep(ModelPtr Pm, const LS MS) {
+template <class SPL = SplitMain, class LS, class SIDE = NoSideWork>
+MCG_DEV void rne_substep(ModelPtr Pm, const LS MS, const SIDE& side = SIDE{}) {
   __syncthreads();                                                  // S1
   real cs[NB], sn[NB], qd[NB], fs[NB];
   {
@@ -1119,6 +1122,7 @@ MCG_DEV void rne_substep(ModelPtr Pm, const LS MS) {
   MCG_FENCE();
   rne_bias(Pm, cs, sn, qd, fs);
   static_for<NB>([&](auto I) { constexpr int i = I; MS.st(SPL::FS + i, fs[i]); });
+  if constexpr (SPL::mesh_split) { side(sn, cs); __syncthreads(); } // S1b
   __syncthreads();                                                  // S2
   if constexpr (SPL::factor_remote) __syncthreads();                // S3
 }

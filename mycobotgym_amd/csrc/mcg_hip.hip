@@ -440,6 +440,8 @@ MCG_DEV void hide_object(real* obs, real* ag) {
 // (owns the cube for the whole env-step), M (composite rigid bodies) and RNE (bias forces), as in the Reach kernel.  Barriers per
 // sub-step:
 //   S1  q(t), qd(t) of the robot are published         (the cube wave needs the pads' pose for the collision pass)
+//   S1b the M / RNE waves have staged the arm-mesh contacts (they test the eight arm meshes against the table / the ground after their own
+//       share, four each, while the cube wave collides the primitive geoms); the cube wave merges them in front of its own
 //   S2  M, passive - bias, the collision results and each lane's FLAG (a contact reaches the robot) are published
 //   S4  both sides are done; every wave reads the same flags
 //   S5  only when some lane is flagged: the cooperative coupled solves are done
@@ -455,7 +457,7 @@ constexpr int PNP_SLOTS_DUAL = PNP_SLOTS + NB;
 static_assert(PNP_SLOTS_DUAL * PNP_LANES * 8 <= 160 * 1024, "LDS of a CU");
 // robot-side split of the four-wave PickAndPlace kernel: M from the helper wave, passive - bias from the RNE wave, the constraint
 // part of H_eq assembled before barrier S2; the Euler step stays with M a (no room for the factor in LDS)
-struct SplitPnp { static constexpr bool enabled = true, rne_remote = true, factor_remote = false, early_heq = true, warm_lds = false;
+struct SplitPnp { static constexpr bool enabled = true, rne_remote = true, factor_remote = false, early_heq = true, warm_lds = false, mesh_split = true;
                   static constexpr int QB = XCH_Q, QDB = XCH_QD, FS = XCH_FS, WARM = 0, QLAG = 0; };
 
 // the robot wave's hook into robot_substep: park a flagged lane's Newton inputs in its own column of the row area
@@ -525,7 +527,7 @@ MCG_DEV void cube_wave(const CubeWaveArgs& C, const View& V, ModelPtr P, const P
         if (__any(cbad)) { if (cbad && C.cnt) atomicAdd(C.cnt + 1, 1ull); }
       }
       CS.cnt = C.cnt;
-      CS.prepare(P, q10);
+      CS.template prepare<true>(P, q10);                           // S1b inside: the M / RNE waves' arm-mesh contacts are merged in
       touch = CS.touch[0] && CS.touch[1];
       MCG_TICK2(ST_W2_COLLIDE);
       // 0: nothing reaches the robot | 2: a contact does (pad / finger link / gripper base on the cube, pad or arm mesh on the table or the
@@ -612,7 +614,11 @@ MCG_DEV bool pnp_substep_robot(const Cfg& C, ModelPtr P, EnvP& E, const PnpScrat
 // (inlined into the kernel: these waves hold nothing across a sub-step, so the inlined cooperative phase spills nothing)
 MCG_DEV void pnp_side_wave(ModelPtr P, const PnpScratch MS, unsigned lds0, int total, bool rne, bool lower, bool pair) {
   for (int s = 0; s < total; s++) {
-    if (lower) { if (rne) rne_substep<SplitPnp>(P, MS); else helper_substep<SplitPnp>(P, MS); }      // S1, S2 inside
+    // S1, S1b, S2 inside; after its own share each wave tests four of the arm meshes against the table / the ground (mcg_cube.hpp)
+    if (lower) {
+      if (rne) rne_substep<SplitPnp>(P, MS, [&](const real* sn, const real* cs) { arm_mesh_stage<4, 8>(P, MS, sn, cs, STAGE_B, STAGE_NB); });
+      else helper_substep<SplitPnp>(P, MS, [&](const real* sn, const real* cs) { arm_mesh_stage<0, 4>(P, MS, sn, cs, STAGE_A, STAGE_NA); });
+    }
     __syncthreads();                                                // S4
     const unsigned mask = flagged_lanes(MS);
     if (mask != 0u) {

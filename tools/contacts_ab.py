@@ -47,3 +47,14 @@ else:
     o0 = d["obs"]["observation"] if isinstance(d["obs"], dict) else d["obs"]
     err = (o1 - o0).abs().max(dim=1).values
     print(f"  one env-step from the same state: max obs difference {err.max().item():.3e}, envs above 1e-9: {(err > 1e-9).sum().item()}")
+    # who differs: environments whose list (at the start of the step) held an arm-mesh entry, against the others
+    ty = ref["type"]; cnt = ref["count"]
+    idx = torch.arange(ty.shape[1])[None, :] < cnt[:, None]
+    arm = ((ty >= 5) & (ty < 13) & idx).any(dim=1)           # PAIR_TABLE_LINK0 .. + 7 (mcg_cube.hpp)
+    for name, m in (("arm-mesh entry in the list", arm), ("none", ~arm)):
+        e = err[m]
+        if len(e): print(f"    {name}: {len(e)} envs, above 1e-9: {(e > 1e-9).sum().item()}, above 1e-12: {(e > 1e-12).sum().item()}, above 0: {(e > 0).sum().item()}, median {e.median().item():.2e}")
+    q = torch.tensor([0.5, 0.9, 0.99, 0.999]).to(err.dtype)
+    print("    quantiles of the difference (50/90/99/99.9 %):", [f"{v:.2e}" for v in torch.quantile(err, q).tolist()])
+    for i in (err > 1e-9).nonzero().flatten()[:6].tolist():
+        print("    env", i, "err %.3e" % err[i].item(), "types", ty[i][:cnt[i]].tolist())
