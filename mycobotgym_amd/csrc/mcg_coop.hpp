@@ -46,7 +46,7 @@ constexpr int XCH_BADC = COOP_CTR_SLOT + 1;
 // XCH_ACT0 / XCH_ACT1: the active set the environment's last cooperative solve ended with, as raw bits -- [signature of the contact list |
 // rows 0-31], [rows 32-63 | rows 64-95] -- cleared at the start of an env-step.  The next sub-step's solve starts from it (see coop_guess).
 constexpr int XCH_ACT0 = XCH_BADC + 1, XCH_ACT1 = XCH_ACT0 + 1;
-static_assert(XCH_ACT1 + 1 <= LDS_POLY + 64, "exchange area");
+static_assert(XCH_ACT1 + 1 <= LDS_POLY + 60, "exchange area (slots 60, 61: the staging waves' flags, mcg_cube.hpp)");
 // Line-search row area (LDS_ROW .. LDS_ROW + 144 slot rows of PNP_LANES doubles):
 //   [0, 96)    the cube wave's own solves (12 slots per contact, list positions 0..7: a lane whose cube contacts sit higher is flagged 2);
 //              between barriers S4 and S5, when every lane-parallel solve is over: cooperative workspace, 768 doubles per wave
@@ -685,6 +685,15 @@ MCG_DEV void coop_solve_pair(ModelPtr Pm, LdsPtr lds0, LdsPtr wsw, int eA, int e
   real a6 = ME.ld(XCH_CB + 13 + 4), a7 = ME.ld(XCH_CB + 13 + 5);
   bool done = !have;
   const LdsPtr wsB = wsw + CP_WS;
+  // The increments J~^T [J~ aref~] stay in the matrix cores' accumulators ACROSS the iterations: an iteration passes only the rows whose
+  // membership changed through the window -- entering rows with weight +1, leaving rows with -1 (column 19 of the window row; the A
+  // operand carries it) -- instead of the whole active set again.  The second iteration of a solve (the usual count under a random
+  // policy is two: the carried set, then the corrected one) moves a handful of rows, not the forty its set holds; the resting cube's
+  // 24 rows are assembled once.  The first iteration is what it was, bit for bit; later ones differ from a fresh assembly by the
+  // rounding of a sum taken in another order.
+  coop_vd4 cA0 = {0, 0, 0, 0}, cA1 = cA0, cA2 = cA0, cB0 = cA0, cB1 = cA0, cB2 = cA0;
+  bool was[NSETS];
+  _Pragma("unroll") for (int s = 0; s < NSETS; s++) was[s] = false;
 
   for (int it = 0; it < 50; it++) {
     COOP_COUNT(1, 1);
@@ -701,24 +710,30 @@ MCG_DEV void coop_solve_pair(ModelPtr Pm, LdsPtr lds0, LdsPtr wsw, int eA, int e
     _Pragma("unroll") for (int j = 0; j < NV; j++) { _Pragma("unroll") for (int s = 0; s < NSETS; s++) r0[s] = fma(J[s][j], av[j], r0[s]); }
     _Pragma("unroll") for (int j = 0; j < N; j++) h0a = fma(H0[j], av[j], h0a);
     const bool use_guess = it == 0 && have_guess;                      // (per half)
+    unsigned dltA[NSETS], dltB[NSETS]; real wgt[NSETS];
     _Pragma("unroll") for (int s = 0; s < NSETS; s++) {
       const bool on = sel(use_guess, lv[s] && ((guess[s] >> hl) & 1u) != 0u, r0[s] < 0);
       const unsigned long long b = __ballot(on && !done);              // (a finished half assembles nothing)
       actA[s] = (unsigned)b; actB[s] = (unsigned)(b >> 32);
+      const bool chg = !done && on != was[s];                          // (... and changes nothing)
+      const unsigned long long d = __ballot(chg);
+      dltA[s] = (unsigned)d; dltB[s] = (unsigned)(d >> 32);
+      wgt[s] = sel(on, 1.0, -1.0);
+      was[s] = sel(done, was[s], on);
     }
     MCG_TICK_PIN(r0, NSETS);
     COOP_TICK(ST_CO_RESID);
-    COOP_COUNT(3, __popc(actA[0]) + __popc(actB[0]) + (NSETS > 1 ? __popc(actA[1 % NSETS]) + __popc(actB[1 % NSETS]) : 0) + (NSETS > 2 ? __popc(actA[2 % NSETS]) + __popc(actB[2 % NSETS]) : 0));
-    // (b) the increments J~^T [J~ aref~] of both environments on the matrix cores, the active rows passing through a 16-row window each
-    coop_vd4 cA0 = {0, 0, 0, 0}, cA1 = cA0, cA2 = cA0, cB0 = cA0, cB1 = cA0, cB2 = cA0;
+    COOP_COUNT(3, __popc(dltA[0]) + __popc(dltB[0]) + (NSETS > 1 ? __popc(dltA[1 % NSETS]) + __popc(dltB[1 % NSETS]) : 0) + (NSETS > 2 ? __popc(dltA[2 % NSETS]) + __popc(dltB[2 % NSETS]) : 0));
+    // (b) the increments J~^T [J~ aref~] of both environments on the matrix cores, the rows that enter or leave the active set passing
+    // through a 16-row window each
     {
-      // positions in the environment's list of active rows, the sets one after the other
+      // positions in the environment's list of changed rows, the sets one after the other
       int nA = 0, nB = 0, pos[NSETS]; bool mine[NSETS];
       _Pragma("unroll") for (int s = 0; s < NSETS; s++) {
-        const unsigned own = sel(up, actB[s], actA[s]);
+        const unsigned own = sel(up, dltB[s], dltA[s]);
         pos[s] = sel(up, nB, nA) + __popc(own & ((1u << hl) - 1u));
         mine[s] = ((own >> hl) & 1u) != 0u;
-        nA += __popc(actA[s]); nB += __popc(actB[s]);
+        nA += __popc(dltA[s]); nB += __popc(dltB[s]);
       }
       const int nmx = nA > nB ? nA : nB, n_own = sel(up, nB, nA);
       for (int w0 = 0; w0 < nmx; w0 += COOP_WIN) {                  // uniform
@@ -727,7 +742,7 @@ MCG_DEV void coop_solve_pair(ModelPtr Pm, LdsPtr lds0, LdsPtr wsw, int eA, int e
           if (mine[s] && pos[s] >= w0 && pos[s] < w0 + COOP_WIN) {
             const LdsPtr o = ws + (pos[s] - w0) * COOP_WSTRIDE;
             _Pragma("unroll") for (int j = 0; j < NV; j += 2) coop_st2(o + j, J[s][j], J[s][j + 1]);
-            coop_st2(o + NV, aref[s], 0.0);
+            coop_st2(o + NV, aref[s], wgt[s]);
           }
         }
         {   // zero rows complete the last group of four
@@ -742,15 +757,16 @@ MCG_DEV void coop_solve_pair(ModelPtr Pm, LdsPtr lds0, LdsPtr wsw, int eA, int e
         // four window rows per instruction: lane (k = drow, c = l16) holds W[4 g + k][c].  All operands of an environment's window first (one
         // LDS round trip, not one per group), then its matrix instructions back to back
         auto window = [&](const LdsPtr wse, int ng, coop_vd4& c0, coop_vd4& c1, coop_vd4& c2) {
-          real lo[4], hi[4];
-          _Pragma("unroll") for (int g = 0; g < 4; g++) { const int o = (4 * g + drow) * COOP_WSTRIDE + l16; lo[g] = wse[o]; hi[g] = wse[o + N]; }
+          real lo[4], hi[4], wg[4];
+          _Pragma("unroll") for (int g = 0; g < 4; g++) { const int o = (4 * g + drow) * COOP_WSTRIDE; lo[g] = wse[o + l16]; hi[g] = wse[o + l16 + N]; wg[g] = wse[o + NV + 1]; }
           MCG_FENCE();
           _Pragma("unroll") for (int g = 0; g < 4; g++) {
             if (g < ng) {                                           // uniform
               const real h3 = sel(l16 < 3, hi[g], 0.0);
-              c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(lo[g], lo[g], c0, 0, 0, 0);
-              c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(lo[g], h3, c1, 0, 0, 0);
-              c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(h3, h3, c2, 0, 0, 0);
+              const real la = lo[g] * wg[g], ha = h3 * wg[g];         // the row's weight (+1 entering, -1 leaving, 0 padding) on the A operand
+              c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(la, lo[g], c0, 0, 0, 0);
+              c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(la, h3, c1, 0, 0, 0);
+              c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(ha, h3, c2, 0, 0, 0);
             }
           }
         };

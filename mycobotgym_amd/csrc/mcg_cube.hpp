@@ -715,7 +715,7 @@ struct CubeSys {
       mesh_cube(1, Rs[1], pf[1], PAIR_FINL_CUBE);
     }
     MCG_TICK2(ST_A_STORE);
-    if constexpr (SPLIT) { __syncthreads(); merge_staged(Pm, CL); }       // S1b
+    if constexpr (SPLIT) { __syncthreads(); MCG_TICK2(ST_CUBE_FIN); merge_staged(Pm, CL); MCG_TICK2(ST_COLLIDE); }       // S1b
     ncon = CL.n; ndropped = CL.ndrop;
     if (__any(CL.ndrop > 0)) { if (CL.ndrop > 0 && cnt) atomicAdd(cnt + 2, (unsigned long long)CL.ndrop); }      // MAXCON cut the list (MuJoCo has no such cap)
     scan_sides();
@@ -731,6 +731,7 @@ struct CubeSys {
         for (int k = 0; k < CON_STRIDE; k++) S.st(LDS_CON + c * CON_STRIDE + k, 0.0);
       }
     }
+    MCG_TICK2(ST_CUBE);
     // ---- P5 per-contact solver numbers (the 6 pyramid rows of a contact share D and the position term)
     real par_t[15], par_p[15];
     ldc<15>(Q->contact_par[PAIR_TABLE_CUBE], par_t); ldc<15>(Q->contact_par[PAIR_PADR_CUBE], par_p);

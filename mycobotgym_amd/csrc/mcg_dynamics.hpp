@@ -1086,6 +1086,7 @@ MCG_DEV bool robot_substep(ModelPtr Pm, Robot& S, real* qlag6, const LS MS, CPL*
 template <class SPL = SplitMain, class LS, class SIDE = NoSideWork>
 MCG_DEV void helper_substep(ModelPtr Pm, const LS MS, const SIDE& side = SIDE{}) {
   __syncthreads();                                                  // S1
+  if constexpr (SPL::mesh_split) MCG_TICK(ST_C_CHECK);
   real cs[NB], sn[NB];
   {
     const TrigC T = load_trig();
@@ -1094,8 +1095,9 @@ MCG_DEV void helper_substep(ModelPtr Pm, const LS MS, const SIDE& side = SIDE{})
   static_for<NB>([&](auto I) { constexpr int i = I; pin(sn[i]); pin(cs[i]); });
   MCG_FENCE();
   crb_to_lds(Pm, cs, sn, MS);
-  if constexpr (SPL::mesh_split) { side(sn, cs); __syncthreads(); } // S1b
+  if constexpr (SPL::mesh_split) { MCG_TICK(ST_C_MASK); side(sn, cs); MCG_TICK(ST_C_ASSEMBLE); __syncthreads(); MCG_TICK(ST_C_SCHUR); } // S1b
   __syncthreads();                                                  // S2
+  if constexpr (SPL::mesh_split) MCG_TICK(ST_C_SOLVE);
   if constexpr (SPL::factor_remote) {
     const real h = launder(Pm)->timestep;
     real Mh[NB * (NB + 1) / 2], dinv[NB];
@@ -1113,6 +1115,7 @@ MCG_DEV void helper_substep(ModelPtr Pm, const LS MS, const SIDE& side = SIDE{})
 template <class SPL = SplitMain, class LS, class SIDE = NoSideWork>
 MCG_DEV void rne_substep(ModelPtr Pm, const LS MS, const SIDE& side = SIDE{}) {
   __syncthreads();                                                  // S1
+  if constexpr (SPL::mesh_split) MCG_TICK(ST_C_CHECK);
   real cs[NB], sn[NB], qd[NB], fs[NB];
   {
     const TrigC T = load_trig();
@@ -1122,8 +1125,9 @@ MCG_DEV void rne_substep(ModelPtr Pm, const LS MS, const SIDE& side = SIDE{}) {
   MCG_FENCE();
   rne_bias(Pm, cs, sn, qd, fs);
   static_for<NB>([&](auto I) { constexpr int i = I; MS.st(SPL::FS + i, fs[i]); });
-  if constexpr (SPL::mesh_split) { side(sn, cs); __syncthreads(); } // S1b
+  if constexpr (SPL::mesh_split) { MCG_TICK(ST_C_MASK); side(sn, cs); MCG_TICK(ST_C_ASSEMBLE); __syncthreads(); MCG_TICK(ST_C_SCHUR); } // S1b
   __syncthreads();                                                  // S2
+  if constexpr (SPL::mesh_split) MCG_TICK(ST_C_SOLVE);
   if constexpr (SPL::factor_remote) __syncthreads();                // S3
 }
 

@@ -613,6 +613,7 @@ MCG_DEV bool pnp_substep_robot(const Cfg& C, ModelPtr P, EnvP& E, const PnpScrat
 // cooperative phase only
 // (inlined into the kernel: these waves hold nothing across a sub-step, so the inlined cooperative phase spills nothing)
 MCG_DEV void pnp_side_wave(ModelPtr P, const PnpScratch MS, unsigned lds0, int total, bool rne, bool lower, bool pair) {
+  MCG_TICK_INIT();
   for (int s = 0; s < total; s++) {
     // S1, S1b, S2 inside; after its own share each wave tests four of the arm meshes against the table / the ground (mcg_cube.hpp)
     if (lower) {
@@ -620,11 +621,13 @@ MCG_DEV void pnp_side_wave(ModelPtr P, const PnpScratch MS, unsigned lds0, int t
       else helper_substep<SplitPnp>(P, MS, [&](const real* sn, const real* cs) { arm_mesh_stage<0, 4>(P, MS, sn, cs, STAGE_A, STAGE_NA); });
     }
     __syncthreads();                                                // S4
+    MCG_TICK(ST_C_LS);
     const unsigned mask = flagged_lanes(MS);
     if (mask != 0u) {
       coop_phase_body(P, (LdsPtr)(uintptr_t)lds0, __builtin_amdgcn_readfirstlane(mask), rne ? 3 : 2, pair ? 1 : 0);
       __syncthreads();                                              // S5
     }
+    MCG_TICK_INIT();                                                // (stage clocks: the cooperative phase keeps its own)
   }
   __syncthreads();                                                  // end of the env-step
 }

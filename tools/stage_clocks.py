@@ -13,11 +13,11 @@ import torch
 from mycobotgym_amd import MyCobotVecEnv, _abi
 
 NAMES = ["load", "controller", "sincos", "rne", "actuation", "crb->M", "rows: weld / rest", "g0", "newton: other (setup, line search)", "euler: factor M+hB, solve, integrate",
-         "collide", "cube solve", "coupled solve", "cube finish", "post (obs/reward/reset/store)",
+         "cube wave: merging the staged arm-mesh contacts", "cube wave: side scan, zero fill", "coupled solve", "cube wave: waiting at S1b", "post (obs/reward/reset/store)",
          "newton: build H", "newton: factor H", "newton: solve", "newton: active-set check", "euler: forces/rhs",
          "rows: arm axes in link6 frame", "rows: connects + coupling", "rows: limits",
-         "coupled: initial masks", "coupled: assembly over contacts", "coupled: Schur complement", "coupled: LDL + back-substitution",
-         "coupled: consistency + line-search rows", "coupled: line search + remask",
+         "M / RNE waves: own share (CRB / bias)", "M / RNE waves: four arm meshes each", "M / RNE waves: waiting at S1b", "M / RNE waves: S1b -> S2",
+         "M / RNE waves: waiting for q (S1)", "M / RNE waves: S2 -> S4",
          "cube wave: waiting for q (S1)", "cube wave: collision (rest: per-contact solver numbers)", "cube wave: solve + finish", "cube wave: waiting at S2",
          "robot wave: waiting at S2",
          "collision: cube frame, pair numbers", "collision: arm chain + arm meshes on table / ground", "collision: pad frames, ground plane",
