@@ -591,6 +591,10 @@ MCG_DEV void coop_solve_pair(ModelPtr Pm, LdsPtr lds0, LdsPtr wsw, int eA, int e
   // ---- rows, as in coop_solve, then scaled by sqrt(D): the cost is 1/2 sum min(0, J~ a - aref~)^2 and D never appears again
   const int nsets = (10 + 6 * nconmax + PNP_LANES - 1) / PNP_LANES;          // uniform
   real J[NSETS][NV], aref[NSETS]; bool lv[NSETS];
+#ifdef MCG_STAGE_CLOCKS
+  int rowcls[NSETS];                                                // 0 limit, 1 static geom - robot, 2 a contact of the cube
+  _Pragma("unroll") for (int s = 0; s < NSETS; s++) rowcls[s] = 0;
+#endif
   _Pragma("unroll") for (int s = 0; s < NSETS; s++) {
     _Pragma("unroll") for (int j = 0; j < NV; j++) J[s][j] = 0;
     aref[s] = 0; lv[s] = false;
@@ -645,6 +649,9 @@ MCG_DEV void coop_solve_pair(ModelPtr Pm, LdsPtr lds0, LdsPtr wsw, int eA, int e
       real D = sel(live, Dc, 0.0), ar = sel(live, -Bc * vel - kterm, 0.0);
       _Pragma("unroll") for (int j = 0; j < 10; j++) J[s][j] = sel(is_lim, sel(j == jl, sgn, 0.0), J[s][j]);
       D = sel(is_lim, fabs(sD), D); ar = sel(is_lim, al, ar);
+#ifdef MCG_STAGE_CLOCKS
+      rowcls[s] = sel(is_lim, 0, sel(has_cube, 2, 1));
+#endif
       const real sd = sel(have && D > 0, sqrt(D), 0.0);            // (an idle half has no rows)
       _Pragma("unroll") for (int j = 0; j < NV; j++) J[s][j] *= sd;
       aref[s] = sd * ar; lv[s] = sd > 0;
@@ -936,6 +943,26 @@ MCG_DEV void coop_solve_pair(ModelPtr Pm, LdsPtr lds0, LdsPtr wsw, int eA, int e
     double* o = g_coop_dbg + e * 512; o[380 + l16] = am; if (l16 == 0) { o[380 + 16] = a6; o[380 + 17] = a7; }
     __builtin_amdgcn_s_waitcnt(0);
     if (l16 == 0) g_coop_dbg_done[e] = 1;
+  }
+#endif
+#ifdef MCG_STAGE_CLOCKS
+  {   // where a carried active set was wrong: rows by class, missing from / surplus in the guess
+    _Pragma("unroll") for (int s = 0; s < NSETS; s++) {
+      const bool g = ((guess[s] >> hl) & 1u) != 0u && lv[s], f = ((fin[s] >> hl) & 1u) != 0u;
+      const bool cnt = have && have_guess && conv;
+      const unsigned long long wrong = __ballot(cnt && g != f);
+      const unsigned long long w0 = __ballot(cnt && g != f && rowcls[s] == 0), w1 = __ballot(cnt && g != f && rowcls[s] == 1), w2 = __ballot(cnt && g != f && rowcls[s] == 2);
+      const unsigned long long miss = __ballot(cnt && !g && f), extra = __ballot(cnt && g && !f);
+      if (T == 0 && wrong) {
+        atomicAdd(&g_stage_clocks[ST_COUNT + CN_G_LIM], (unsigned long long)__popcll(w0)); atomicAdd(&g_stage_clocks[ST_COUNT + CN_G_STAT], (unsigned long long)__popcll(w1));
+        atomicAdd(&g_stage_clocks[ST_COUNT + CN_G_CUBE], (unsigned long long)__popcll(w2));
+        atomicAdd(&g_stage_clocks[ST_COUNT + CN_G_MISSING], (unsigned long long)__popcll(miss)); atomicAdd(&g_stage_clocks[ST_COUNT + CN_G_EXTRA], (unsigned long long)__popcll(extra));
+      }
+    }
+    bool anyw = false;
+    _Pragma("unroll") for (int s = 0; s < NSETS; s++) anyw = anyw || (have && have_guess && conv && (((guess[s] >> hl) & 1u) != 0u && lv[s]) != (((fin[s] >> hl) & 1u) != 0u));
+    const unsigned long long aw = __ballot(anyw);
+    if (T == 0) atomicAdd(&g_stage_clocks[ST_COUNT + CN_G_FAILED], (unsigned long long)(((unsigned)aw != 0u) + ((unsigned)(aw >> 32) != 0u)));
   }
 #endif
   // ---- hand the accelerations back

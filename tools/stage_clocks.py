@@ -26,7 +26,9 @@ NAMES = ["load", "controller", "sincos", "rne", "actuation", "crb->M", "rows: we
          "coop: gradient + LDL", "coop: solves + transpose", "coop: consistency check", "coop: line search", "coop: hand back", "coop: idle at S5"]
 COUNTS = ["robot sub-steps", "robot Newton iterations", "robot line searches", "cube Newton iterations", "cube line searches",
           "coupled solves", "coupled Newton iterations", "coupled line searches", "wave-max contacts (per collision pass)",
-          "coop active rows (sum over iterations)", "coop line-search evaluations", "coop solves whose carried active set was confirmed at once", "coop solves at the 50-iteration cap", "coop solves that started from a carried active set"]
+          "coop active rows (sum over iterations)", "coop line-search evaluations", "coop solves whose carried active set was confirmed at once", "coop solves at the 50-iteration cap", "coop solves that started from a carried active set",
+          "pair solves whose carried set was wrong", "wrong rows: joint limits", "wrong rows: static geom - robot contacts", "wrong rows: contacts of the cube",
+          "wrong rows: missing from the carried set", "wrong rows: surplus in the carried set"]
 fresh = "--fresh-actions" in sys.argv
 grasp = "--grasp" in sys.argv           # PickAndPlace joint with every env holding the cube (scripted grasp state)
 L = _abi.load()
