@@ -946,6 +946,17 @@ MCG_DEV void coop_solve_pair(ModelPtr Pm, LdsPtr lds0, LdsPtr wsw, int eA, int e
   }
 #endif
 #ifdef MCG_STAGE_CLOCKS
+  {   // census: would the set of TWO sub-steps ago have been right (period-2 chatter)?
+    const real q0 = ME.ld(LDS_POLY + 62), q1 = ME.ld(LDS_POLY + 63);
+    const bool sig2 = (unsigned)__double2hiint(q0) == sig;
+    const unsigned g20 = (unsigned)__double2loint(q0), g21 = (unsigned)__double2hiint(q1);
+    const bool eq2 = have && conv && sig2 && g20 == fin[0] && g21 == fin[1 % NSETS];
+    const bool eq1 = have && conv && have_guess && guess[0] == fin[0] && guess[1 % NSETS] == fin[1 % NSETS];
+    const unsigned long long b2 = __ballot(eq2 && hl == 0), b1 = __ballot(eq1 && hl == 0), b12 = __ballot(eq2 && !eq1 && hl == 0);
+    if (T == 0) { atomicAdd(&g_stage_clocks[ST_COUNT + CN_G_EQ1], (unsigned long long)__popcll(b1)); atomicAdd(&g_stage_clocks[ST_COUNT + CN_G_EQ2], (unsigned long long)__popcll(b2));
+                  atomicAdd(&g_stage_clocks[ST_COUNT + CN_G_EQ2N1], (unsigned long long)__popcll(b12)); }
+    if (have && hl == 0) { ME.st(LDS_POLY + 62, ME.ld(XCH_ACT0)); ME.st(LDS_POLY + 63, ME.ld(XCH_ACT1)); }      // (before the hand-back overwrites them)
+  }
   {   // where a carried active set was wrong: rows by class, missing from / surplus in the guess
     _Pragma("unroll") for (int s = 0; s < NSETS; s++) {
       const bool g = ((guess[s] >> hl) & 1u) != 0u && lv[s], f = ((fin[s] >> hl) & 1u) != 0u;

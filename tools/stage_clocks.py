@@ -28,7 +28,8 @@ COUNTS = ["robot sub-steps", "robot Newton iterations", "robot line searches", "
           "coupled solves", "coupled Newton iterations", "coupled line searches", "wave-max contacts (per collision pass)",
           "coop active rows (sum over iterations)", "coop line-search evaluations", "coop solves whose carried active set was confirmed at once", "coop solves at the 50-iteration cap", "coop solves that started from a carried active set",
           "pair solves whose carried set was wrong", "wrong rows: joint limits", "wrong rows: static geom - robot contacts", "wrong rows: contacts of the cube",
-          "wrong rows: missing from the carried set", "wrong rows: surplus in the carried set"]
+          "wrong rows: missing from the carried set", "wrong rows: surplus in the carried set",
+          "pair solves whose final set = the set of the last sub-step", "... = the set of two sub-steps ago", "... = the set of two sub-steps ago and not the last one's"]
 fresh = "--fresh-actions" in sys.argv
 grasp = "--grasp" in sys.argv           # PickAndPlace joint with every env holding the cube (scripted grasp state)
 L = _abi.load()
