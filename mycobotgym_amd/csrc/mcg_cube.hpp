@@ -733,6 +733,11 @@ struct CubeSys {
     }
     MCG_TICK2(ST_CUBE);
     // ---- P5 per-contact solver numbers (the 6 pyramid rows of a contact share D and the position term)
+#if MCG_DUP == 1
+    for (int dup = 0; dup < 2; dup++) {      // critical-path probe: the pass twice (the second from the first's multiplicities, restored)
+    if (dup == 1) { for (int c = 0; __any(c < ncon); c++) if (c < ncon) S.st(LDS_CON + c * CON_STRIDE + 13, S.ld(LDS_ACT + c)); }
+    else { for (int c = 0; __any(c < ncon); c++) if (c < ncon) S.st(LDS_ACT + c, S.ld(LDS_CON + c * CON_STRIDE + 13)); }
+#endif
     real par_t[15], par_p[15];
     ldc<15>(Q->contact_par[PAIR_TABLE_CUBE], par_t); ldc<15>(Q->contact_par[PAIR_PADR_CUBE], par_p);
     const bool any_tp = __any(any_pad);      // wave-uniform: table / ground - pad contacts may exist
@@ -770,6 +775,9 @@ struct CubeSys {
       const real Rpy = fmax(MINVAL, Q->contact_rpy * m0*m0 * Rn);      // 2 mu^2 R [RECALL]; 4 mu^2 R under contact_rule = "keyframe" (include/mcg.h)
       if (c < ncon) { S.st(b + 13, mult / Rpy); S.st(b + 14, kk * imp * dist); }
     }
+#if MCG_DUP == 1
+    }
+#endif
 #ifdef MCG_DBG_PRINT
     if (blockIdx.x == 0 && threadIdx.x == 0) {
       printf("[prepare] ncon %d any_pad %d touch %d %d cube pos %.9g %.9g %.9g\n", ncon, (int)any_pad, (int)touch[0], (int)touch[1], Cb.pos[0], Cb.pos[1], Cb.pos[2]);

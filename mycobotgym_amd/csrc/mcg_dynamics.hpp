@@ -15,6 +15,9 @@
 // Numbers (offsets, inertias, gains, solver parameters) come from the mcg_model block in device memory; its
 // reads are wave-uniform and become scalar loads.
 #pragma once
+#ifndef MCG_DUP
+#define MCG_DUP 0       // development probes of the four-wave kernel's critical path: a stage executed twice (1 cube wave's solver numbers, 2 M / RNE
+#endif                  // waves' arm meshes, 3 robot wave's H_eq assembly) -- a stage off the critical path costs nothing when doubled
 
 #include <type_traits>
 #include <hip/hip_runtime.h>
@@ -854,6 +857,9 @@ MCG_DEV bool robot_substep(ModelPtr Pm, Robot& S, real* qlag6, const LS MS, CPL*
     static_for<6>([&](auto Rr) { constexpr int r = Rr; const real da = Dw[r / 3] * arefw[r];
       static_for<6>([&](auto I) { constexpr int j = I; g0[j] = fma(Jw[r][j], da, g0[j]); }); });
   if constexpr (SPL::early_heq) assemble_heq(std::false_type{});      // J^T D J only: M is not there yet
+#if MCG_DUP == 3        // critical-path probe: the robot wave's assembly twice (same numbers to the same slots)
+  if constexpr (SPL::early_heq && SPL::mesh_split) { MCG_FENCE(); static_for<2>([&](auto Sd) { constexpr int sd = Sd; pin(Dc[sd]); }); assemble_heq(std::false_type{}); }
+#endif
   if constexpr (SPL::enabled) {
     if constexpr (SPL::mesh_split) __syncthreads();                 // S1b (four-wave PickAndPlace kernel: the M / RNE waves' arm-mesh contacts are staged)
     __syncthreads();                                                // S2: M and passive - bias are in LDS

@@ -617,8 +617,13 @@ MCG_DEV void pnp_side_wave(ModelPtr P, const PnpScratch MS, unsigned lds0, int t
   for (int s = 0; s < total; s++) {
     // S1, S1b, S2 inside; after its own share each wave tests four of the arm meshes against the table / the ground (mcg_cube.hpp)
     if (lower) {
+#if MCG_DUP == 2      // critical-path probe: the four meshes twice (the second pass stores the same records again)
+      if (rne) rne_substep<SplitPnp>(P, MS, [&](const real* sn, const real* cs) { arm_mesh_stage<4, 8>(P, MS, sn, cs, STAGE_B, STAGE_NB); MCG_FENCE(); arm_mesh_stage<4, 8>(P, MS, sn, cs, STAGE_B, STAGE_NB); });
+      else helper_substep<SplitPnp>(P, MS, [&](const real* sn, const real* cs) { arm_mesh_stage<0, 4>(P, MS, sn, cs, STAGE_A, STAGE_NA); MCG_FENCE(); arm_mesh_stage<0, 4>(P, MS, sn, cs, STAGE_A, STAGE_NA); });
+#else
       if (rne) rne_substep<SplitPnp>(P, MS, [&](const real* sn, const real* cs) { arm_mesh_stage<4, 8>(P, MS, sn, cs, STAGE_B, STAGE_NB); });
       else helper_substep<SplitPnp>(P, MS, [&](const real* sn, const real* cs) { arm_mesh_stage<0, 4>(P, MS, sn, cs, STAGE_A, STAGE_NA); });
+#endif
     }
     __syncthreads();                                                // S4
     MCG_TICK(ST_C_LS);
