@@ -1023,6 +1023,8 @@ static __device__ __noinline__ void coop_solve_single(unsigned long long model_b
 // seventh is the robot wave's (a 32-lane solve takes about as long as a pair's), the others are handed out in pairs.  (Who is paired
 // with whom does race; a half's arithmetic never sees the other half's numbers.)
 constexpr int COOP_ROBOT_EVERY = 7;
+template <bool PAIRS = true>      // PAIRS = false: the robot wave's instance (modes 0 and 2 only) -- without the inlined pair solve its out-of-line
+                                  // frame saves a handful of registers per call instead of ~50 dwords a lane
 MCG_DEV void coop_phase_body(ModelPtr P, LdsPtr lds0, unsigned m, int w, int mode) {
   const LdsPtr ws = lds0 + COOP_WS_ROW * PNP_LANES + w * COOP_WS_DOUBLES;
   CoopClocks CK;
@@ -1049,7 +1051,7 @@ MCG_DEV void coop_phase_body(ModelPtr P, LdsPtr lds0, unsigned m, int w, int mod
       const int e = kth(k);
       coop_solve_single((unsigned long long)P, (unsigned)(uintptr_t)lds0, e, w, ncon_of(e));
     }
-  } else {
+  } else if constexpr (PAIRS) {
     const int npair = total - total / COOP_ROBOT_EVERY;              // the ranks that are not the robot wave's
     auto rank_of = [&](int j) { return j + j / (COOP_ROBOT_EVERY - 1); };
     for (;;) {
@@ -1074,8 +1076,8 @@ MCG_DEV void coop_phase_body(ModelPtr P, LdsPtr lds0, unsigned m, int w, int mod
 static __device__ __noinline__ void coop_phase(unsigned long long model_bits, unsigned lds_base, unsigned mask, int wave, int mode) {
   const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)model_bits), hi = __builtin_amdgcn_readfirstlane((unsigned)(model_bits >> 32));
   const ModelPtr P = (ModelPtr)(((unsigned long long)hi << 32) | lo);
-  coop_phase_body(P, (LdsPtr)(uintptr_t)__builtin_amdgcn_readfirstlane(lds_base), __builtin_amdgcn_readfirstlane(mask), __builtin_amdgcn_readfirstlane(wave),
-                  __builtin_amdgcn_readfirstlane(mode));
+  coop_phase_body<false>(P, (LdsPtr)(uintptr_t)__builtin_amdgcn_readfirstlane(lds_base), __builtin_amdgcn_readfirstlane(mask), __builtin_amdgcn_readfirstlane(wave),
+                         __builtin_amdgcn_readfirstlane(mode));
 }
 
 }  // namespace mcg

@@ -578,7 +578,9 @@ MCG_DEV bool pnp_substep_robot(const Cfg& C, ModelPtr P, EnvP& E, const PnpScrat
   const bool flag = MS.ld(XCH_FLAG) != 0.0;
   const unsigned mask = (unsigned)__ballot(flag);
   if (mask != 0u) {                                                 // wave-uniform, the same in all four waves
-    coop_phase((unsigned long long)P, lds0, mask, 0, C.coop_pair != 0 ? 2 : 0);      // one environment at a time here, two in the other three waves
+    // one environment at a time here, two in the other three waves; with fewer flagged environments than a round of the workgroup takes
+    // this wave has no share (its rank-fixed share is every COOP_ROBOT_EVERY-th) and does not pay the call
+    if (C.coop_pair == 0 || __popc(mask) >= COOP_ROBOT_EVERY) coop_phase((unsigned long long)P, lds0, mask, 0, C.coop_pair != 0 ? 2 : 0);
     MCG_TICK(ST_COUPLED);
     __syncthreads();                                                // S5
     MCG_TICK(ST_CO_IDLE);
