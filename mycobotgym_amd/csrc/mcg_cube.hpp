@@ -264,6 +264,9 @@ MCG_DEV void pyramid_row(const CubeRows& R, int r, const real* mu, real* j) {
 // rule (mco_collision.c: plane_polytope / box_polytope) -- separating-axis test over the table's face axes, ONE contact at the
 // deepest vertex along the face of least penetration; the deepest vertex below z = 0 for the ground.  Broad phase: the lowest
 // point of the vertices' bounding box in the body frame.
+#ifndef MESH_BATCH
+#define MESH_BATCH 13       // vertices per batch of scalar loads: two dependent round trips per mesh (4 per batch were seven; A/B of 4 / 7 / 13 / 26 in profiles/r03/ab_mesh_vertex_batch.log)
+#endif
 template <class SINK>
 MCG_DEV void mesh_table_ground(ModelPtr Pm, int pi, const real* Rio, const real* pio, const real* tp, const real* th, SINK& CL) {
     ModelPtr H = launder(Pm);
@@ -275,11 +278,11 @@ MCG_DEV void mesh_table_ground(ModelPtr Pm, int pi, const real* Rio, const real*
     // four vertices per batch of scalar loads: a wave alone on its SIMD pays every s_load round trip in full, and 26 dependent
     // ones per mesh were most of this pass under a policy that keeps the arm near the table (the last batch repeats vertex 25:
     // a repeated vertex changes neither the extremes nor the first lowest one)
-    for (int kb = 0; kb < 26; kb += 4) {
-      real v4[4][3];
+    for (int kb = 0; kb < 26; kb += MESH_BATCH) {
+      real v4[MESH_BATCH][3];
       { ModelPtr Hb = launder(Pm);
-        _Pragma("unroll") for (int u = 0; u < 4; u++) { const int k = sel(kb + u < 26, kb + u, 25); ldc<3>(Hb->link_hull[pi][k], v4[u]); } }
-      _Pragma("unroll") for (int u = 0; u < 4; u++) {
+        _Pragma("unroll") for (int u = 0; u < MESH_BATCH; u++) { const int k = sel(kb + u < 26, kb + u, 25); ldc<3>(Hb->link_hull[pi][k], v4[u]); } }
+      _Pragma("unroll") for (int u = 0; u < MESH_BATCH; u++) {
         real w[3];
         _Pragma("unroll") for (int r = 0; r < 3; r++) w[r] = pio[r] + Rio[3*r]*v4[u][0] + Rio[3*r+1]*v4[u][1] + Rio[3*r+2]*v4[u][2];
         const bool lower = w[2] < lo[2];                               // first occurrence of the minimum, as the oracle keeps it
