@@ -129,6 +129,29 @@ def _contact_poses(kind, count=128, seed=0):
     return np.array(poses)
 
 
+def _cap_poses(count=64, seed=11, depth=-1e-2):
+    """Arm poses with an arm-side mesh contact AND a contact list at the cap of 12 (the oracle's count, duplicated mesh geoms counted
+    twice): the arm-mesh entries, first in the oracle's pair order, push entries of the tail off the list.  Such poses are deep ones
+    under uniform sampling (median penetration 7 cm); the shallowest 1 % are kept."""
+    from tests.common import load_json
+    from oracle import pyoracle as po
+    tab = load_json("mycobot280")
+    m = po.OracleModel(tab, enable_contact=True, scope_geom=tab["geom_name"].index("object0"))
+    d = po.OracleData(m)
+    rng = np.random.default_rng(seed)
+    poses = []
+    while len(poses) < count:
+        q = np.array(tab["qpos0"], float)
+        q[:6] = rng.uniform(-2.5, 2.5, 6); q[6] = q[8] = rng.uniform(0, 0.7)
+        d.set_state(qpos=q, qvel=np.zeros(18)); d.forward()
+        n = int(d.get("ncon", (1,), np.int32)[0]); nefc = int(d.get("nefc", (1,), np.int32)[0])
+        if n < 12: continue
+        rows = d.get("efc_type", (224,), np.int32)[:nefc] == 2
+        per_contact = np.bincount(d.get("efc_id", (224,), np.int32)[:nefc][rows])
+        if (per_contact == 4).any() and d.get("efc_pos", (224,))[:nefc][rows].min() > depth: poses.append(q)
+    return np.array(poses)
+
+
 def _pose_prepare(poses):
     def prepare(ora):
         s = ora.get_state()
@@ -154,6 +177,39 @@ def test_substeps_arm_meshes_on_the_table_and_the_ground(torch_cuda):
     print(f"\narm meshes on the table / ground, 200 sub-steps x 128 envs: {worst}, contact counts seen {sorted(ncon)}")
     assert max(ncon) > 4
     assert worst["obs"] < 1e-10 and worst["qpos"] < 1e-10 and worst["qvel"] < 1e-6
+
+
+def test_substeps_arm_meshes_with_the_cap_cutting_the_merged_list(torch_cuda):
+    """Round 3: the arm meshes are tested by the M / RNE waves and merged IN FRONT of the cube wave's entries after barrier S1b
+    (CubeSys::merge_staged); with the list at the cap of MAXCON = 12 contacts the merge decides which entries of the tail are cut, as the
+    oracle's pair order does.  Per-sub-step parity on such states (teacher-forced), and the kernels' own count of cut contacts."""
+    poses = _cap_poses()
+    n = len(poses)
+    from tests.common import make_pair, sync_oracle_to, step_errors
+    kw = dict(has_object=True, controller_type="joint", reward_type="dense", seed=5, frame_skip=1, max_episode_steps=10 ** 9)
+    envs, ora = make_pair(n, **kw)
+    envs.reset(seed=5); ora.reset(seed=5)
+    _pose_prepare(poses)(ora)
+    sync_oracle_to(envs, ora)
+    kc = envs.debug_contacts()
+    at_cap = int((kc["mult"].sum(dim=1) >= 12).sum()); cut = int((kc["dropped"] > 0).sum())
+    link = ((kc["type"] >= 5) & (kc["type"] < 13) & (torch_cuda.arange(12, device=kc["type"].device)[None, :] < kc["count"][:, None])).any(dim=1)
+    envs.counters(clear=True)
+    a = np.clip(ora.get_state()["ctrl"], -1, 1).astype(np.float32)
+    worst = dict(obs=0.0, qpos=0.0)
+    for t in range(12):                                           # a dozen sub-steps: the deep ones among these states blow up soon after
+        sync_oracle_to(envs, ora)
+        e, flags_equal, o = step_errors(envs, ora, a)
+        assert flags_equal
+        st, so = envs.get_state(), ora.get_state()
+        worst["obs"] = max(worst["obs"], float(e.max()))
+        worst["qpos"] = max(worst["qpos"], float(np.abs(st["qpos"].cpu().numpy().T - so["qpos"]).max()))
+    dropped = envs.counters()["contacts_dropped"]
+    print(f"\narm meshes + list at the cap, 12 sub-steps x {n} envs: {worst}; envs at the cap {at_cap}, with cut contacts {cut}, with a link entry "
+          f"{int(link.sum())}; contacts cut over the run (mcg_counters) {dropped}")
+    assert at_cap >= n // 2 and int(link.sum()) >= n // 2 and cut > 0 and dropped > 0
+    assert worst["obs"] < 1e-10 and worst["qpos"] < 1e-10          # measured 1.5e-14, 1.0e-13 (14 of 64 envs with cut contacts)
+    envs.close()
 
 
 def _finger_mesh_poses(count=128, seed=2, meshes=("right_finger_link", "left_finger_link")):
