@@ -212,6 +212,47 @@ def test_substeps_arm_meshes_with_the_cap_cutting_the_merged_list(torch_cuda):
     envs.close()
 
 
+def test_whole_env_step_from_random_policy_states(torch_cuda):
+    """One WHOLE env-step (20 sub-steps inside one launch: what the teacher-forced per-sub-step tests cannot see -- staging areas, flags and
+    carried active sets that live from one sub-step to the next) against the oracle, from states a random IK policy reached on the GPU:
+    half of the picked environments hold an arm-mesh contact (the staged / merged entries of the M / RNE waves), half do not."""
+    torch = torch_cuda
+    from mycobotgym_amd import MyCobotVecEnv
+    from tests.common import make_pair, step_errors
+    n0 = 2048
+    src = MyCobotVecEnv(n0, has_object=True, controller_type="IK", reward_type="dense", seed=3)
+    src.reset(seed=3)
+    g = torch.Generator(device="cuda"); g.manual_seed(99)
+    for t in range(80): src.step_async(torch.rand(n0, src.action_dim, device="cuda", generator=g) * 2 - 1)
+    torch.cuda.synchronize()
+    st = {k: v.cpu() for k, v in src.get_state().items()}
+    kc = src.debug_contacts()
+    ty, cnt = kc["type"].cpu(), kc["count"].cpu()
+    src.close()
+    live = torch.arange(ty.shape[1])[None, :] < cnt[:, None]
+    arm = ((ty >= 5) & (ty < 13) & live).any(dim=1)
+    n = 128
+    pick = torch.cat([arm.nonzero().flatten()[: n // 2], (~arm).nonzero().flatten()[: n - min(n // 2, int(arm.sum()))]])[:n]
+    n = len(pick)
+    assert int(arm[pick].sum()) >= 16, "the random policy reached too few arm-mesh contacts"
+    envs, ora = make_pair(n, has_object=True, controller_type="joint", reward_type="dense", seed=0, max_episode_steps=10 ** 9)
+    envs.reset(seed=0); ora.reset(seed=0)
+    sel = {k: (v[..., pick] if v.ndim and v.shape[-1] == n0 else v) for k, v in st.items()}
+    ost = {k: sel[k].numpy().T.copy() for k in ("qpos", "qvel", "warm", "qpos_lag", "goal", "ctrl")}
+    ost["elapsed"] = np.zeros(n, np.int32); ost["episode"] = sel["episode"].numpy().astype(np.int32)
+    ora.set_state(**ost)
+    envs.set_state(qpos=sel["qpos"], qvel=sel["qvel"], ctrl=sel["ctrl"], warm=sel["warm"], qpos_lag=sel["qpos_lag"], goal=sel["goal"],
+                   elapsed=torch.zeros(n, dtype=torch.int32), episode=sel["episode"])
+    a = np.clip(ost["ctrl"] + 0.05 * np.random.default_rng(1).normal(size=(n, 7)), -1, 1).astype(np.float32)      # joint targets near the reached pose
+    e, flags_equal, o = step_errors(envs, ora, a)
+    assert flags_equal
+    isarm = arm[pick].numpy()
+    print(f"\none env-step (20 sub-steps, one launch) from random-policy states: max error vs oracle {e[isarm].max():.2e} over {int(isarm.sum())} envs with an "
+          f"arm-mesh contact, {e[~isarm].max():.2e} over {int((~isarm).sum())} without")
+    assert e.max() < 1e-9                                          # measured 5e-12 / 7e-14 here, 3e-11 / 2e-12 over 256 envs (tools/state_vs_oracle.py)
+    envs.close()
+
+
 def _finger_mesh_poses(count=128, seed=2, meshes=("right_finger_link", "left_finger_link")):
     """Gripper poses around the cube (the scripted-grasp states, perturbed) in which the bounding box of one of `meshes` touches the
     cube (the oracle's contact list names the geoms); shallow contacts only (a deep one is a violent state)."""
