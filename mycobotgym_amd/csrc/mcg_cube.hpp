@@ -387,6 +387,82 @@ MCG_DEV void arm_mesh_stage(ModelPtr Pm, const LS S, const real* sn, const real*
   S.st(count_slot, (real)ST.n);
 }
 
+// ---- P5 in the four-wave kernel: the solver numbers of list positions r, r + 3, r + 6, r + 9 of every lane -- the cube wave takes r = 0, the
+// M wave 1, the RNE wave 2, between barriers S1c (the merged list and its length are published) and S2.  The contact-at-a-time pass of the
+// cube wave alone sat on the workgroup's critical path with three waves waiting (profiles/r03/ab_critical_path_probes.log: executed twice it
+// cost PickAndPlace-IK 9 % and the resting cube 10 %).  The expressions are CubeSys::prepare's, operand for operand; the four contacts of a
+// wave's share are independent chains in one stretch of code.
+constexpr int STAGE_NCON = STAGE_NA;      // the staging area is consumed by then: its first count slot carries the merged list's length
+template <class LS>
+MCG_DEV void solver_numbers_share(ModelPtr Pm, const LS S, real dr1, int r0) {
+  ModelPtr Q = launder(Pm);
+  const int ncon = (int)S.ld(STAGE_NCON);
+  if (!__any(r0 < ncon)) return;                                                  // wave-uniform
+  real dist[4], mult[4]; int type[4]; bool in[4];
+  _Pragma("unroll") for (int u = 0; u < 4; u++) {
+    const int c = r0 + 3 * u; in[u] = c < ncon;
+    const int b = LDS_CON + c * CON_STRIDE;
+    dist[u] = S.ld(b + 12); mult[u] = S.ld(b + 13); type[u] = sel(in[u], (int)S.ld(b + 15), 0);
+  }
+  bool afin = false, atp = false, alink = false;
+  _Pragma("unroll") for (int u = 0; u < 4; u++) {
+    const bool fincube = type[u] >= PAIR_FINR_CUBE, tabpad = type[u] >= PAIR_TABLE_PADR && !fincube, tablink = type[u] >= PAIR_TABLE_LINK0 && !fincube;
+    afin = afin || fincube; atp = atp || tabpad; alink = alink || tablink;
+  }
+  afin = __any(afin); atp = __any(atp); alink = __any(alink);
+  const real ft = Q->geom_friction0[0], fp = Q->geom_friction0[1] * dr1, fcb = Q->geom_friction0[2] * dr1;
+  const real mu_tc0 = fmax(ft, fcb), mu_pc0 = fmax(fp, fcb), mu_tp0 = fmax(ft, fp);
+  real par_t[10], par_p[10];
+  ldc<10>(Q->contact_par[PAIR_TABLE_CUBE], par_t); ldc<10>(Q->contact_par[PAIR_PADR_CUBE], par_p);
+  const real cd0 = Q->contact_diag[PAIR_TABLE_CUBE][0], cd1 = Q->contact_diag[PAIR_PADR_CUBE][0], cd2 = Q->contact_diag[PAIR_PADL_CUBE][0], rpy = Q->contact_rpy;
+  real imp[4], kk[4], m0[4], tran[4];
+  _Pragma("unroll") for (int u = 0; u < 4; u++) {
+    const bool padcube = type[u] == PAIR_PADR_CUBE || type[u] == PAIR_PADL_CUBE;
+    imp[u] = sel(padcube, impedance(par_p, dist[u]), impedance(par_t, dist[u]));
+    kk[u] = sel(padcube, par_p[0], par_t[0]);
+    m0[u] = sel(padcube, mu_pc0, mu_tc0);
+    tran[u] = sel(type[u] == PAIR_PADR_CUBE, cd1, sel(type[u] == PAIR_PADL_CUBE, cd2, cd0));
+  }
+  if (afin) {
+    ModelPtr Qb = launder(Pm);
+    real par_mc[10]; ldc<10>(Qb->contact_par[PAR_FIN_CUBE], par_mc);
+    const real mu_mc0 = fmax(Qb->fin_par[1], fcb), fin2 = Qb->fin_par[2], fin3 = Qb->fin_par[3], base = Qb->link_diag[7][0] + cd0;
+    _Pragma("unroll") for (int u = 0; u < 4; u++) {
+      const bool fincube = type[u] >= PAIR_FINR_CUBE;
+      imp[u] = sel(fincube, impedance(par_mc, dist[u]), imp[u]); kk[u] = sel(fincube, par_mc[0], kk[u]); m0[u] = sel(fincube, mu_mc0, m0[u]);
+      tran[u] = sel(type[u] == PAIR_FINR_CUBE, fin2, sel(type[u] == PAIR_FINL_CUBE, fin3, tran[u]));
+      tran[u] = sel(type[u] == PAIR_BASE_CUBE, base, tran[u]);
+    }
+  }
+  if (atp) {
+    ModelPtr Qb = launder(Pm);
+    real par_tp[10]; ldc<10>(Qb->contact_par[PAIR_TABLE_PADR], par_tp);
+    const real cd3 = Qb->contact_diag[PAIR_TABLE_PADR][0], cd4 = Qb->contact_diag[PAIR_TABLE_PADL][0];
+    _Pragma("unroll") for (int u = 0; u < 4; u++) {
+      const bool fincube = type[u] >= PAIR_FINR_CUBE, tablink = type[u] >= PAIR_TABLE_LINK0 && !fincube, tabp = (type[u] >= PAIR_TABLE_PADR && !fincube) && !tablink;
+      imp[u] = sel(tabp, impedance(par_tp, dist[u]), imp[u]); kk[u] = sel(tabp, par_tp[0], kk[u]); m0[u] = sel(tabp, mu_tp0, m0[u]);
+      tran[u] = sel(type[u] == PAIR_TABLE_PADR, cd3, sel(type[u] == PAIR_TABLE_PADL, cd4, tran[u]));
+    }
+  }
+  if (alink) {
+    ModelPtr Qb = launder(Pm);
+    real par_tl[11], ldg[8]; ldc<11>(Qb->contact_par[PAIR_TABLE_LINK0], par_tl);
+    _Pragma("unroll") for (int k = 0; k < 8; k++) ldg[k] = Qb->link_diag[k][0];
+    _Pragma("unroll") for (int u = 0; u < 4; u++) {
+      const bool fincube = type[u] >= PAIR_FINR_CUBE, tablink = type[u] >= PAIR_TABLE_LINK0 && !fincube;
+      imp[u] = sel(tablink, impedance(par_tl, dist[u]), imp[u]); kk[u] = sel(tablink, par_tl[0], kk[u]); m0[u] = sel(tablink, par_tl[10], m0[u]);
+      real tl = tran[u];
+      static_for<8>([&](auto Pp) { constexpr int pp = Pp; tl = sel(type[u] == PAIR_TABLE_LINK0 + pp, ldg[pp], tl); });
+      tran[u] = tl;
+    }
+  }
+  _Pragma("unroll") for (int u = 0; u < 4; u++) {
+    const real Rn = fmax(MINVAL, (1 - imp[u]) * tran[u] * (1 + m0[u]*m0[u]) / imp[u]);
+    const real Rpy = fmax(MINVAL, rpy * m0[u]*m0[u] * Rn);
+    if (in[u]) { const int b = LDS_CON + (r0 + 3 * u) * CON_STRIDE; S.st(b + 13, mult[u] / Rpy); S.st(b + 14, kk[u] * imp[u] * dist[u]); }
+  }
+}
+
 // The cube and its contacts for one sub-step: prepared before the robot's Newton solve, finished after it.
 template <class LS>
 struct CubeSys {
@@ -735,6 +811,12 @@ struct CubeSys {
       }
     }
     MCG_TICK2(ST_CUBE);
+    if constexpr (SPLIT) {      // the four-wave kernel: the pass is shared by the cube, M and RNE waves (solver_numbers_share)
+      S.st(STAGE_NCON, (real)ncon);
+      __syncthreads();                                                  // S1c
+      solver_numbers_share(Pm, S, dr[1], 0);
+      return;
+    }
     // ---- P5 per-contact solver numbers (the 6 pyramid rows of a contact share D and the position term)
 #if MCG_DUP == 1
     for (int dup = 0; dup < 2; dup++) {      // critical-path probe: the pass twice (the second from the first's multiplicities, restored)

@@ -386,7 +386,7 @@ typedef LaneScratchT<64> LaneScratch;
 // Coupling hook: PickAndPlace passes an object that, when a finger pad touches the cube, solves the robot and cube
 // accelerations together (the Euler step needs no constraint force: M a carries it).  Reach passes NoCoupling (compiled out).
 struct NoCoupling { static constexpr bool enabled = false, publishes = false; };
-struct NoSideWork { MCG_DEV void operator()(const real*, const real*) const {} };      // what a helper / RNE wave does after its own share, before S1b
+struct NoSideWork { MCG_DEV void operator()(const real*, const real*) const {} MCG_DEV void numbers() const {} };      // what a helper / RNE wave does after its own share, before S1b
 // A hook with `publishes` (and not `enabled`) is handed the Newton system's smooth right-hand side and the limit rows once they are
 // complete: the four-wave PickAndPlace kernel parks them in LDS for the cooperative coupled solve (mcg_coop.hpp).
 
@@ -861,7 +861,7 @@ MCG_DEV bool robot_substep(ModelPtr Pm, Robot& S, real* qlag6, const LS MS, CPL*
   if constexpr (SPL::early_heq && SPL::mesh_split) { MCG_FENCE(); static_for<2>([&](auto Sd) { constexpr int sd = Sd; pin(Dc[sd]); }); assemble_heq(std::false_type{}); }
 #endif
   if constexpr (SPL::enabled) {
-    if constexpr (SPL::mesh_split) __syncthreads();                 // S1b (four-wave PickAndPlace kernel: the M / RNE waves' arm-mesh contacts are staged)
+    if constexpr (SPL::mesh_split) { __syncthreads(); __syncthreads(); }      // S1b, S1c (four-wave PickAndPlace kernel: the M / RNE waves' arm-mesh contacts are staged; the merged list is published)
     __syncthreads();                                                // S2: M and passive - bias are in LDS
     if constexpr (SPL::rne_remote) static_for<NB>([&](auto I) { constexpr int i = I; fs[i] += MS.ld(SPL::FS + i); });
   }
@@ -1101,7 +1101,7 @@ MCG_DEV void helper_substep(ModelPtr Pm, const LS MS, const SIDE& side = SIDE{})
   static_for<NB>([&](auto I) { constexpr int i = I; pin(sn[i]); pin(cs[i]); });
   MCG_FENCE();
   crb_to_lds(Pm, cs, sn, MS);
-  if constexpr (SPL::mesh_split) { MCG_TICK(ST_C_MASK); side(sn, cs); MCG_TICK(ST_C_ASSEMBLE); __syncthreads(); MCG_TICK(ST_C_SCHUR); } // S1b
+  if constexpr (SPL::mesh_split) { MCG_TICK(ST_C_MASK); side(sn, cs); MCG_TICK(ST_C_ASSEMBLE); __syncthreads(); MCG_TICK(ST_C_SCHUR); __syncthreads(); side.numbers(); } // S1b, S1c, this wave's share of the solver numbers
   __syncthreads();                                                  // S2
   if constexpr (SPL::mesh_split) MCG_TICK(ST_C_SOLVE);
   if constexpr (SPL::factor_remote) {
@@ -1131,7 +1131,7 @@ MCG_DEV void rne_substep(ModelPtr Pm, const LS MS, const SIDE& side = SIDE{}) {
   MCG_FENCE();
   rne_bias(Pm, cs, sn, qd, fs);
   static_for<NB>([&](auto I) { constexpr int i = I; MS.st(SPL::FS + i, fs[i]); });
-  if constexpr (SPL::mesh_split) { MCG_TICK(ST_C_MASK); side(sn, cs); MCG_TICK(ST_C_ASSEMBLE); __syncthreads(); MCG_TICK(ST_C_SCHUR); } // S1b
+  if constexpr (SPL::mesh_split) { MCG_TICK(ST_C_MASK); side(sn, cs); MCG_TICK(ST_C_ASSEMBLE); __syncthreads(); MCG_TICK(ST_C_SCHUR); __syncthreads(); side.numbers(); } // S1b, S1c, this wave's share of the solver numbers
   __syncthreads();                                                  // S2
   if constexpr (SPL::mesh_split) MCG_TICK(ST_C_SOLVE);
   if constexpr (SPL::factor_remote) __syncthreads();                // S3

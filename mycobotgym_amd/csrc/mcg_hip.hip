@@ -614,7 +614,13 @@ MCG_DEV bool pnp_substep_robot(const Cfg& C, ModelPtr P, EnvP& E, const PnpScrat
 // the helper / RNE waves of the four-wave PickAndPlace kernel: same barriers as the cube wave; lanes 32-63 are alive for the
 // cooperative phase only
 // (inlined into the kernel: these waves hold nothing across a sub-step, so the inlined cooperative phase spills nothing)
-MCG_DEV void pnp_side_wave(ModelPtr P, const PnpScratch MS, unsigned lds0, int total, bool rne, bool lower, bool pair) {
+// what a side wave does between S1 and S2 besides its own share: four arm meshes (staged for S1b), then its third of the solver numbers
+template <int P0, int P1> struct PnpSideWork {
+  ModelPtr P; const PnpScratch MS; int base, count_slot; real dr1; int share;
+  MCG_DEV void operator()(const real* sn, const real* cs) const { arm_mesh_stage<P0, P1>(P, MS, sn, cs, base, count_slot); }
+  MCG_DEV void numbers() const { solver_numbers_share(P, MS, dr1, share); }
+};
+MCG_DEV void pnp_side_wave(ModelPtr P, const PnpScratch MS, unsigned lds0, int total, bool rne, bool lower, bool pair, real dr1) {
   MCG_TICK_INIT();
   for (int s = 0; s < total; s++) {
     // S1, S1b, S2 inside; after its own share each wave tests four of the arm meshes against the table / the ground (mcg_cube.hpp)
@@ -623,8 +629,8 @@ MCG_DEV void pnp_side_wave(ModelPtr P, const PnpScratch MS, unsigned lds0, int t
       if (rne) rne_substep<SplitPnp>(P, MS, [&](const real* sn, const real* cs) { arm_mesh_stage<4, 8>(P, MS, sn, cs, STAGE_B, STAGE_NB); MCG_FENCE(); arm_mesh_stage<4, 8>(P, MS, sn, cs, STAGE_B, STAGE_NB); });
       else helper_substep<SplitPnp>(P, MS, [&](const real* sn, const real* cs) { arm_mesh_stage<0, 4>(P, MS, sn, cs, STAGE_A, STAGE_NA); MCG_FENCE(); arm_mesh_stage<0, 4>(P, MS, sn, cs, STAGE_A, STAGE_NA); });
 #else
-      if (rne) rne_substep<SplitPnp>(P, MS, [&](const real* sn, const real* cs) { arm_mesh_stage<4, 8>(P, MS, sn, cs, STAGE_B, STAGE_NB); });
-      else helper_substep<SplitPnp>(P, MS, [&](const real* sn, const real* cs) { arm_mesh_stage<0, 4>(P, MS, sn, cs, STAGE_A, STAGE_NA); });
+      if (rne) rne_substep<SplitPnp>(P, MS, PnpSideWork<4, 8>{P, MS, STAGE_B, STAGE_NB, dr1, 2});
+      else helper_substep<SplitPnp>(P, MS, PnpSideWork<0, 4>{P, MS, STAGE_A, STAGE_NA, dr1, 1});
 #endif
     }
     __syncthreads();                                                // S4
@@ -663,7 +669,7 @@ __global__ __launch_bounds__(256) void step_pnp_kernel(Cfg C, View V, const mcg_
         CubeWaveArgs A; for (int k = 0; k < 7; k++) A.qpos0_cube[k] = C.qpos0_cube[k];
         A.cnt = C.cnt; A.coop_pair = C.coop_pair;
         cube_wave(A, V, P, MS, lds0, i, total, lower);
-      } else pnp_side_wave(P, MS, lds0, total, threadIdx.x >= 192, lower, C.coop_pair != 0);
+      } else pnp_side_wave(P, MS, lds0, total, threadIdx.x >= 192, lower, C.coop_pair != 0, lower ? V.dr(1, i) : 1.0);
       return;
     }
   }
