@@ -1,12 +1,12 @@
 /*
  * ORACLE -- TEST INFRASTRUCTURE ONLY (see mco_physics.h).
  *
- * P4 `mj_collision` restated for the primitive geoms of the PickAndPlace scene: the cube, the table box, the two
- * finger-pad boxes and the ground plane (/root/reference/mycobotgym/envs/assets/mycobot280_main.xml:81,87,195-199,
- * 222-225,262).  The 28 mesh geoms (convex hulls in MuJoCo) are outside this build's scope and never
- * produce contacts here.  With `collide_scope_geom` set (the build's configuration) only pairs involving the cube are
- * tested: pads touching the table or each other would, in MuJoCo, be preceded by finger-mesh contacts that are out
- * of scope anyway, so modelling them without the meshes is not closer to the reference than leaving them out.
+ * P4 `mj_collision` restated for the PickAndPlace scene: the primitive geoms -- the cube, the table box, the two finger-pad boxes and the
+ * ground plane (/root/reference/mycobotgym/envs/assets/mycobot280_main.xml:81,87,195-199,222-225,262) -- among each other, and the mesh
+ * geoms of the arm and the gripper (:105-247; convex hulls in MuJoCo, collision polytopes here: mycobotgym_amd/model/polytope.py)
+ * against the ground, the table and the cube.  Not built: mesh <-> mesh pairs (self-collision) and the arm base's mesh (its STL is
+ * absent from the reference checkout).  With `collide_scope_geom` set (the build's configuration) only primitive pairs that involve
+ * the cube, or a static geom and a pad, are tested.
  *
  * Pair filter [RECALL mj_collision]: both geoms' bodies welded to the world -> skip; same weld body -> skip;
  * parent-child weld bodies -> skip unless the parent is the world; `<exclude>` pairs -> skip;
@@ -59,7 +59,9 @@ static void mix_params(const mco_model* m, int g1, int g2, mco_contact* c) {
 }
 
 static void add_contact(const mco_model* m, mco_data* d, int g1, int g2, const double* pos, const double* normal, double dist) {
-  if (!(dist < 0) || d->ncon >= MCO_MAXCON) return;
+  if (!(dist < 0)) return;
+  if (d->nentry >= m->maxentry || d->ncon >= MCO_MAXCON) { d->ndrop++; return; }      /* the build's cap (MuJoCo has none) */
+  d->nentry++;
   mco_contact* c = &d->contact[d->ncon++];
   memset(c, 0, sizeof(*c));
   c->geom1 = g1; c->geom2 = g2; c->dist = dist;
@@ -91,11 +93,7 @@ static void plane_box(const mco_model* m, mco_data* d, int gp, int gb) {
 static void box_box(const mco_model* m, mco_data* d, int ga, int gb) {
   const double* Ra = d->geom_xmat[ga]; const double* Rb = d->geom_xmat[gb];
   const double* ha = m->geom_size[ga]; const double* hb = m->geom_size[gb];
-  double pa[3], pb[3];                  /* box centres (a mesh geom's bounding box is off its frame origin by obb_center, else zero) */
-  for (int r = 0; r < 3; r++) {
-    pa[r] = d->geom_xpos[ga][r] + Ra[3*r]*m->obb_center[ga][0] + Ra[3*r+1]*m->obb_center[ga][1] + Ra[3*r+2]*m->obb_center[ga][2];
-    pb[r] = d->geom_xpos[gb][r] + Rb[3*r]*m->obb_center[gb][0] + Rb[3*r+1]*m->obb_center[gb][1] + Rb[3*r+2]*m->obb_center[gb][2];
-  }
+  const double* pa = d->geom_xpos[ga]; const double* pb = d->geom_xpos[gb];
   double A[3][3], B[3][3], p[3] = { pb[0] - pa[0], pb[1] - pa[1], pb[2] - pa[2] };
   for (int k = 0; k < 3; k++) { col(Ra, k, A[k]); col(Rb, k, B[k]); }
   double C[3][3], Q[3][3];              /* C = A^T B, Q = |C| */
@@ -219,109 +217,161 @@ static int filtered(const mco_model* m, int g1, int g2) {
   return 0;
 }
 
-/* ------------------------------------------------------------------- static box / plane - support polytope of a mesh */
-static void world_vertex(const mco_model* m, const mco_data* d, int g, int k, double* w) {
-  const double* R = d->geom_xmat[g]; const double* p = d->geom_xpos[g]; const double* v = m->hull_vert[g][k];
-  for (int r = 0; r < 3; r++) w[r] = p[r] + R[3*r]*v[0] + R[3*r+1]*v[1] + R[3*r+2]*v[2];
+/* --------------------------------------------------------------- ground plane / box <-> collision polytope of a mesh geom */
+/* The tables (mycobotgym_amd/model/polytope.py: pack) in geom coordinates, struct-of-arrays, padded to multiples of 64. */
+typedef struct { int nv, nf, ne; const double *vx, *vy, *vz, *fx, *fy, *fz, *fd, *e[13]; } poly_view;
+static poly_view poly_of(const mco_model* m, int mesh) {
+  const double* meta = m->poly + 8 * mesh;
+  poly_view P; P.nv = (int)meta[0]; P.nf = (int)meta[1]; P.ne = (int)meta[2];
+  const double* b = m->poly + (long)meta[3]; int vp = (int)meta[4], fp = (int)meta[5], ep = (int)meta[6];
+  P.vx = b; P.vy = b + vp; P.vz = b + 2*vp; b += 3*vp;
+  P.fx = b; P.fy = b + fp; P.fz = b + 2*fp; P.fd = b + 3*fp; b += 4*fp;
+  for (int k = 0; k < 13; k++) P.e[k] = b + k*ep;
+  return P;
 }
-static void plane_polytope(const mco_model* m, mco_data* d, int gp, int gm) {
+static double sgn1(double x) { return x > 0 ? 1.0 : -1.0; }
+
+/* Ground plane: the polytope's lowest vertex (first occurrence), if it is below the plane.  Returns 1 and fills pos / normal / dist. */
+static int plane_polytope(const mco_model* m, const mco_data* d, int gp, int gm, double* pos, double* normal, double* dist) {
+  poly_view P = poly_of(m, m->geom_poly[gm]);
+  const double* R = d->geom_xmat[gm]; const double* p = d->geom_xpos[gm];
   double n[3]; col(d->geom_xmat[gp], 2, n);
   const double* pp = d->geom_xpos[gp];
-  double best = 0, bw[3] = {0, 0, 0}; int found = 0;
-  for (int k = 0; k < m->hull_nvert[gm]; k++) {
-    double w[3]; world_vertex(m, d, gm, k, w);
-    double rel[3] = { w[0] - pp[0], w[1] - pp[1], w[2] - pp[2] };
-    double dist = dot3(rel, n);
-    if (dist < 0 && (!found || dist < best)) { best = dist; memcpy(bw, w, sizeof(bw)); found = 1; }
+  double best = INFINITY; int kb = 0;
+  for (int k = 0; k < P.nv; k++) {
+    double w[3]; for (int r = 0; r < 3; r++) w[r] = p[r] + R[3*r]*P.vx[k] + R[3*r+1]*P.vy[k] + R[3*r+2]*P.vz[k];
+    double h = (w[0] - pp[0])*n[0] + (w[1] - pp[1])*n[1] + (w[2] - pp[2])*n[2];
+    if (h < best) { best = h; kb = k; }
   }
-  if (!found) return;
-  double pos[3] = { bw[0] - 0.5*best*n[0], bw[1] - 0.5*best*n[1], bw[2] - 0.5*best*n[2] };
-  add_contact(m, d, gp, gm, pos, n, best);
+  if (!(best < 0)) return 0;
+  double w[3]; for (int r = 0; r < 3; r++) w[r] = p[r] + R[3*r]*P.vx[kb] + R[3*r+1]*P.vy[kb] + R[3*r+2]*P.vz[kb];
+  for (int r = 0; r < 3; r++) { pos[r] = w[r] - 0.5*best*n[r]; normal[r] = n[r]; }
+  *dist = best;
+  return 1;
 }
-/* Box <-> support polytope of a mesh.  Separating-axis test over the box's three face axes and the polytope's own 13 canonical axes
- * (its frame's axes, face diagonals and space diagonals: the directions its vertices are support points of -- together they bound the
- * polytope by its 26-DOP).  Without the 13 a polytope diagonally off an edge of the box counts as touching whenever its box-aligned
- * extent overlaps the box (round 2: a finger 2.4 cm from the cube's centre; a link beside the table's edge).  ONE contact:
- *   full = 0 (the static table): along the box FACE of least penetration, at the polytope's deepest vertex;
- *   full = 1 (the cube):         along the axis of least penetration among all 16; for a polytope axis the contact sits at the box's
- *                                deepest corner along it.
- * flip: the mesh is geom1 and the box geom2 (a gripper mesh against the cube, which comes later in geom order): the contact's normal
- * then points from the mesh to the box. */
-static const int DIR13[13][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}, {1, 1, 0}, {1, -1, 0}, {1, 0, 1}, {1, 0, -1}, {0, 1, 1}, {0, 1, -1}, {1, 1, 1}, {1, 1, -1}, {1, -1, 1}, {1, -1, -1}};
-static void box_polytope(const mco_model* m, mco_data* d, int gb, int gm, int full, int flip) {
-  const double* pb = d->geom_xpos[gb]; const double* Rb = d->geom_xmat[gb]; const double* h = m->geom_size[gb];
+
+/* Box <-> polytope, EXACT: the two convex shapes overlap iff no facet normal of their Minkowski difference separates them, and the
+ * least of the overlaps along those normals is the penetration depth.  The facet normals are (all in the MESH frame, n pointing from
+ * the polytope to the box, sep(n) = min over the box of x.n  -  max over the polytope of v.n, > 0 = separated):
+ *   B  the box's face axes, n = +b_j / -b_j (candidate 2 j, 2 j + 1): the polytope's extent along b_j from its vertices;
+ *   P  the polytope's face normals n_f: sep = n_f.c - sum_j h_j |n_f.b_j| - d_f;
+ *   E  n = +-(e_k x b_j) / |e_k x b_j| for polytope edge k and box axis j (candidate j ne + k), taken only if n lies in the edge's
+ *      normal cone (n.u1 >= 0 and n.u2 >= 0: then the edge is the polytope's support set along n; a box always has a supporting edge
+ *      along b_j for a direction perpendicular to it), and |e_k x b_j| >= 1e-6.
+ * Within a family the largest sep wins, the lowest candidate on ties; between the families the order is B, E, P and a later family
+ * replaces an earlier one only if its sep is larger by more than 1e-12 (parallel features: a rounding-level tie must not decide where
+ * the contact sits).  There is NO preference of face axes as box-box has one (its 5 %): the witness features of an axis that is not the
+ * axis of least penetration need not touch -- a finger link's deepest vertex along a face axis of the cube can lie 1.7 cm beside the
+ * 2 cm cube, a polytope face's witness corner of the table 15 cm along the table's edge -- so the axis is the exact minimum, whose
+ * witnesses do touch.
+ * ONE contact, as MuJoCo's convex-convex pairs have:
+ *   B: at the polytope's deepest vertex along n (lowest index), half a depth back;  P: at the box's deepest corner along -n, half a
+ *   depth forward;  E: midway between the closest points of the polytope's edge and the box's supporting edge (line parameters
+ *   clamped to the two segments).
+ * flip = 0: the box is geom1 (the static table), the contact normal points from the box to the mesh; 1: the mesh is geom1. */
+#define POLY_TIE 1e-12
+static int box_polytope(const mco_model* m, const mco_data* d, int gb, int gm, int flip, double* pos, double* normal, double* dist) {
+  poly_view P = poly_of(m, m->geom_poly[gm]);
+  const double* Rm = d->geom_xmat[gm]; const double* pm = d->geom_xpos[gm];
+  const double* Rb = d->geom_xmat[gb]; const double* pb = d->geom_xpos[gb]; const double* h = m->geom_size[gb];
+  double c[3], b[3][3];                                  /* the box in the mesh frame: centre, axes (rows) */
+  { double rel[3] = { pb[0] - pm[0], pb[1] - pm[1], pb[2] - pm[2] };
+    for (int k = 0; k < 3; k++) c[k] = Rm[k]*rel[0] + Rm[3 + k]*rel[1] + Rm[6 + k]*rel[2];
+    for (int j = 0; j < 3; j++) for (int k = 0; k < 3; k++) b[j][k] = Rm[k]*Rb[j] + Rm[3 + k]*Rb[3 + j] + Rm[6 + k]*Rb[6 + j]; }
+  /* B */
+  double sB = -INFINITY; int cB = 0, vB = 0;
+  for (int j = 0; j < 3; j++) {
+    double mx = -INFINITY, mn = INFINITY; int kx = 0, kn = 0;
+    for (int k = 0; k < P.nv; k++) {
+      double t = P.vx[k]*b[j][0] + P.vy[k]*b[j][1] + P.vz[k]*b[j][2];
+      if (t > mx) { mx = t; kx = k; }
+      if (t < mn) { mn = t; kn = k; }
+    }
+    double cb = dot3(c, b[j]);
+    double sp = (cb - h[j]) - mx, sn = mn - (cb + h[j]);
+    if (sp > sB) { sB = sp; cB = 2*j; vB = kx; }
+    if (sn > sB) { sB = sn; cB = 2*j + 1; vB = kn; }
+  }
+  if (sB > 0) return 0;
+  /* P */
+  double sP = -INFINITY; int cP = 0;
+  for (int f = 0; f < P.nf; f++) {
+    double n[3] = { P.fx[f], P.fy[f], P.fz[f] };
+    double s = (dot3(n, c) - (h[0]*fabs(dot3(n, b[0])) + h[1]*fabs(dot3(n, b[1])) + h[2]*fabs(dot3(n, b[2])))) - P.fd[f];
+    if (s > sP) { sP = s; cP = f; }
+  }
+  if (sP > 0) return 0;
+  /* E */
+  double sE = -INFINITY, nE[3] = { 0, 0, 0 }; int jE = 0, kE = 0;
+  for (int j = 0; j < 3; j++) {
+    int i1 = (j + 1) % 3, i2 = (j + 2) % 3;
+    for (int k = 0; k < P.ne; k++) {
+      double e[3] = { P.e[3][k], P.e[4][k], P.e[5][k] }, x[3];
+      cross3(x, e, b[j]);
+      double len = sqrt(dot3(x, x));
+      if (len < EDGE_MIN_SIN) continue;
+      double il = 1.0 / len; x[0] *= il; x[1] *= il; x[2] *= il;
+      double t1 = x[0]*P.e[6][k] + x[1]*P.e[7][k] + x[2]*P.e[8][k], t2 = x[0]*P.e[9][k] + x[1]*P.e[10][k] + x[2]*P.e[11][k];
+      double sg = (t1 >= 0 && t2 >= 0) ? 1.0 : ((t1 <= 0 && t2 <= 0) ? -1.0 : 0.0);
+      if (sg == 0.0) continue;
+      double n[3] = { sg*x[0], sg*x[1], sg*x[2] };
+      double s = (dot3(n, c) - (h[i1]*fabs(dot3(n, b[i1])) + h[i2]*fabs(dot3(n, b[i2])))) - (n[0]*P.e[0][k] + n[1]*P.e[1][k] + n[2]*P.e[2][k]);
+      if (s > sE) { sE = s; jE = j; kE = k; nE[0] = n[0]; nE[1] = n[1]; nE[2] = n[2]; }
+    }
+  }
+  if (sE > 0) return 0;
+  /* the axis of least penetration and its contact (mesh frame) */
+  double n[3], q[3], s = sB; int kind = 0;
+  if (sE > s + POLY_TIE) { s = sE; kind = 1; }
+  if (sP > s + POLY_TIE) { s = sP; kind = 2; }
+  if (kind == 1) { n[0] = nE[0]; n[1] = nE[1]; n[2] = nE[2];
+    int i1 = (jE + 1) % 3, i2 = (jE + 2) % 3;
+    double pe[3] = { P.e[0][kE], P.e[1][kE], P.e[2][kE] }, e[3] = { P.e[3][kE], P.e[4][kE], P.e[5][kE] }, qb[3];
+    double g1 = sgn1(dot3(b[i1], n)) * h[i1], g2 = sgn1(dot3(b[i2], n)) * h[i2];
+    for (int k = 0; k < 3; k++) qb[k] = c[k] - g1*b[i1][k] - g2*b[i2][k];           /* a point of the box's supporting edge along -n */
+    double w[3] = { qb[0] - pe[0], qb[1] - pe[1], qb[2] - pe[2] };
+    double uaub = dot3(e, b[jE]), q1 = dot3(e, w), q2 = -dot3(b[jE], w), dd = 1 - uaub*uaub;
+    double ts = dd <= 1e-12 ? 0 : (q1 + uaub*q2) / dd, tt = dd <= 1e-12 ? 0 : (uaub*q1 + q2) / dd;
+    ts = fmin(fmax(ts, 0.0), P.e[12][kE]); tt = fmin(fmax(tt, -h[jE]), h[jE]);
+    for (int k = 0; k < 3; k++) q[k] = 0.5 * ((pe[k] + ts*e[k]) + (qb[k] + tt*b[jE][k]));
+  } else if (kind == 2) {
+    n[0] = P.fx[cP]; n[1] = P.fy[cP]; n[2] = P.fz[cP];
+    double g0 = sgn1(dot3(b[0], n)) * h[0], g1 = sgn1(dot3(b[1], n)) * h[1], g2 = sgn1(dot3(b[2], n)) * h[2];
+    for (int k = 0; k < 3; k++) q[k] = (c[k] - g0*b[0][k] - g1*b[1][k] - g2*b[2][k]) - 0.5*s*n[k];      /* the box's deepest corner, half a depth forward */
+  } else {
+    int j = cB >> 1; double sg = (cB & 1) ? -1.0 : 1.0;
+    for (int k = 0; k < 3; k++) n[k] = sg * b[j][k];
+    q[0] = P.vx[vB] + 0.5*s*n[0]; q[1] = P.vy[vB] + 0.5*s*n[1]; q[2] = P.vz[vB] + 0.5*s*n[2];             /* the deepest vertex, half a depth back */
+  }
+  for (int r = 0; r < 3; r++) {
+    pos[r] = pm[r] + Rm[3*r]*q[0] + Rm[3*r+1]*q[1] + Rm[3*r+2]*q[2];
+    double nw = Rm[3*r]*n[0] + Rm[3*r+1]*n[1] + Rm[3*r+2]*n[2];
+    normal[r] = flip ? nw : -nw;
+  }
+  *dist = s;
+  return 1;
+}
+
+/* conservative broad phase for the oracle's own speed (it cannot change a result): the polytope's bounding sphere against the box */
+static int poly_far_from_box(const mco_model* m, const mco_data* d, int gb, int gm) {
+  poly_view P = poly_of(m, m->geom_poly[gm]);
   double lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
-  double wlo[3][3], whi[3][3];                      /* the vertices that realise the extremes (first occurrence) */
-  for (int k = 0; k < m->hull_nvert[gm]; k++) {
-    double w[3]; world_vertex(m, d, gm, k, w);
-    double rel[3] = { w[0] - pb[0], w[1] - pb[1], w[2] - pb[2] };
-    for (int a = 0; a < 3; a++) {
-      double ax[3]; col(Rb, a, ax);
-      double c = dot3(rel, ax);
-      if (c < lo[a]) { lo[a] = c; memcpy(wlo[a], w, sizeof(w)); }
-      if (c > hi[a]) { hi[a] = c; memcpy(whi[a], w, sizeof(w)); }
-    }
-  }
-  for (int a = 0; a < 3; a++) if (lo[a] > h[a] || hi[a] < -h[a]) return;      /* a face axis separates */
-  double depth = INFINITY; int axis = 0, sign = 1; double n[3] = { 0, 0, 0 };
-  for (int a = 0; a < 3; a++) {
-    double dp = h[a] - lo[a], dn = hi[a] + h[a];    /* push the polytope out through face +a / -a */
-    if (dp < depth) { depth = dp; axis = a; sign = 1; }
-    if (dn < depth) { depth = dn; axis = a; sign = -1; }
-  }
-  if (!m->rule[7]) {      /* study switch rule[7] = 1: the face axes alone (the first version of this test) */
-    const double* Rm = d->geom_xmat[gm]; const double* pm = d->geom_xpos[gm];
-    for (int k = 0; k < 13; k++) {
-      double mn = INFINITY, mx = -INFINITY;
-      for (int v = 0; v < m->hull_nvert[gm]; v++) {
-        const double* hv = m->hull_vert[gm][v];
-        double c = DIR13[k][0]*hv[0] + DIR13[k][1]*hv[1] + DIR13[k][2]*hv[2];
-        if (c < mn) mn = c;
-        if (c > mx) mx = c;
-      }
-      double w[3];
-      for (int r = 0; r < 3; r++) w[r] = Rm[3*r]*DIR13[k][0] + Rm[3*r+1]*DIR13[k][1] + Rm[3*r+2]*DIR13[k][2];
-      double rel = (pm[0] - pb[0])*w[0] + (pm[1] - pb[1])*w[1] + (pm[2] - pb[2])*w[2];      /* polytope origin - box centre, along w */
-      double rad = 0;
-      for (int a = 0; a < 3; a++) { double ax[3]; col(Rb, a, ax); rad += h[a] * fabs(dot3(ax, w)); }
-      if (rel + mn > rad || rel + mx < -rad) return;
-      if (full) {
-        int l2 = DIR13[k][0]*DIR13[k][0] + DIR13[k][1]*DIR13[k][1] + DIR13[k][2]*DIR13[k][2];
-        double il = 1.0 / (l2 == 1 ? 1.0 : (l2 == 2 ? 1.4142135623730951 : 1.7320508075688772));      /* the kernels' constants */
-        double dp = (rad - (rel + mn)) * il, dn = ((rel + mx) + rad) * il;        /* push the polytope out along +w / -w */
-        if (dp < depth) { depth = dp; axis = 3 + k; sign = 1; for (int r = 0; r < 3; r++) n[r] = w[r] * il; }
-        if (dn < depth) { depth = dn; axis = 3 + k; sign = -1; for (int r = 0; r < 3; r++) n[r] = -w[r] * il; }
-      }
-    }
-  }
-  double pos[3];
-  if (axis < 3) {
-    col(Rb, axis, n); for (int k = 0; k < 3; k++) n[k] *= sign;               /* from the box to the mesh */
-    const double* w = sign > 0 ? wlo[axis] : whi[axis];                        /* the vertex deepest inside */
-    for (int k = 0; k < 3; k++) pos[k] = w[k] + 0.5*depth*n[k];
-  } else {                                                                     /* the box's deepest corner along n, half a depth back */
-    double xb[3] = { pb[0], pb[1], pb[2] };
-    for (int a = 0; a < 3; a++) { double ax[3]; col(Rb, a, ax); double sg = dot3(n, ax) > 0 ? 1.0 : -1.0; for (int k = 0; k < 3; k++) xb[k] += sg * h[a] * ax[k]; }
-    for (int k = 0; k < 3; k++) pos[k] = xb[k] - 0.5*depth*n[k];
-  }
-  if (flip) { double nn[3] = { -n[0], -n[1], -n[2] }; add_contact(m, d, gm, gb, pos, nn, -depth); }
-  else add_contact(m, d, gb, gm, pos, n, -depth);
+  for (int k = 0; k < P.nv; k++) { double v[3] = { P.vx[k], P.vy[k], P.vz[k] }; for (int r = 0; r < 3; r++) { if (v[r] < lo[r]) lo[r] = v[r]; if (v[r] > hi[r]) hi[r] = v[r]; } }
+  double cm[3] = { 0.5*(lo[0] + hi[0]), 0.5*(lo[1] + hi[1]), 0.5*(lo[2] + hi[2]) }, rad = 0.5 * sqrt((hi[0]-lo[0])*(hi[0]-lo[0]) + (hi[1]-lo[1])*(hi[1]-lo[1]) + (hi[2]-lo[2])*(hi[2]-lo[2]));
+  const double* Rm = d->geom_xmat[gm]; const double* pm = d->geom_xpos[gm];
+  const double* Rb = d->geom_xmat[gb]; const double* pb = d->geom_xpos[gb]; const double* h = m->geom_size[gb];
+  double w[3]; for (int r = 0; r < 3; r++) w[r] = pm[r] + Rm[3*r]*cm[0] + Rm[3*r+1]*cm[1] + Rm[3*r+2]*cm[2] - pb[r];
+  double d2 = 0;
+  for (int a = 0; a < 3; a++) { double t = fabs(Rb[a]*w[0] + Rb[3 + a]*w[1] + Rb[6 + a]*w[2]) - h[a]; if (t > 0) d2 += t*t; }
+  return d2 > (rad + 1e-6) * (rad + 1e-6);
 }
 
 void mco_collision(const mco_model* m, mco_data* d) {
-  d->ncon = 0;
-  /* static primitive <-> arm-side mesh (support polytope): these pairs first, mesh by mesh (the order the kernels emit them in) */
-  for (int g2 = 0; g2 < m->ngeom; g2++) {
-    if (m->geom_type[g2] != MCO_GEOM_MESH || m->hull_nvert[g2] <= 0 || (m->collide_extra[g2] != 3 && m->collide_extra[g2] != 5)) continue;
-    for (int g1 = 0; g1 < m->ngeom; g1++) {
-      if (m->collide_extra[g1] != 1 || filtered(m, g1, g2)) continue;
-      if (m->geom_type[g1] == MCO_GEOM_PLANE) plane_polytope(m, d, g1, g2);
-      else if (m->geom_type[g1] == MCO_GEOM_BOX) box_polytope(m, d, g1, g2, 0, 0);
-    }
-  }
+  d->ncon = 0; d->nentry = 0; d->ndrop = 0;
+  /* the primitive geoms, in geom order: ground - pads, ground - cube, table - pads, table - cube, pads - cube (the order the kernels emit them in) */
   for (int g1 = 0; g1 < m->ngeom; g1++) for (int g2 = g1 + 1; g2 < m->ngeom; g2++) {
     int t1 = m->geom_type[g1], t2 = m->geom_type[g2];
-    if (t1 == MCO_GEOM_MESH || t2 == MCO_GEOM_MESH) continue;           /* convex-mesh collision: out of scope */
+    if (t1 == MCO_GEOM_MESH || t2 == MCO_GEOM_MESH) continue;
     if (m->collide_scope_geom >= 0 && g1 != m->collide_scope_geom && g2 != m->collide_scope_geom
         && !(m->collide_extra[g1] && m->collide_extra[g2] && m->collide_extra[g1] != m->collide_extra[g2])) continue;
     if (filtered(m, g1, g2)) continue;
@@ -334,14 +384,33 @@ void mco_collision(const mco_model* m, mco_data* d) {
       box_box(m, d, g1, g2);
     }
   }
-  /* finger-link meshes (collide_extra 4; 5 = a mesh that also collides with the static geoms above: the rule supports the gripper base
-   * that way, the build does not enable it -- a fourth contact class costs the kernels' coupled solve 50 %) <-> the cube (SURVEY 8f-4,
-   * second stage), after the primitive pairs, geom by geom (the reference attaches every mesh twice: the twin's contact follows at once) */
-  if (m->collide_scope_geom >= 0 && m->geom_type[m->collide_scope_geom] == MCO_GEOM_BOX) {
-    int gc = m->collide_scope_geom;
-    for (int g = 0; g < m->ngeom; g++) {
-      if (m->geom_type[g] != MCO_GEOM_MESH || m->hull_nvert[g] <= 0 || (m->collide_extra[g] != 4 && m->collide_extra[g] != 5) || filtered(m, g, gc)) continue;
-      box_polytope(m, d, gc, g, 1, g < gc);
+  /* the mesh geoms, polytope by polytope (links 1-6, flange, gripper base, gear / finger links right and left, hinge links), each against
+   * the ground plane, the static boxes (the table) and the scope geom (the cube), in that order.  The reference attaches every mesh
+   * twice (a visual and a collision geom of equal pose, both colliding): the twins' identical contacts follow each other and form ONE
+   * entry of the list. */
+  if (!m->poly) return;
+  for (int mi = 0; mi < MCO_NMESH; mi++) {
+    int tw[4], ntw = 0;
+    for (int g = 0; g < m->ngeom && ntw < 4; g++) if (m->geom_type[g] == MCO_GEOM_MESH && m->geom_poly[g] == mi) tw[ntw++] = g;
+    if (!ntw) continue;
+    for (int pass = 0; pass < 2; pass++) for (int go = 0; go < m->ngeom; go++) {
+      if (pass == 0 ? (m->collide_extra[go] != 1) : (go != m->collide_scope_geom)) continue;
+      if (m->geom_type[go] != MCO_GEOM_PLANE && m->geom_type[go] != MCO_GEOM_BOX) continue;
+      int gm = tw[0];
+      double pos[3], nrm[3], dist; int hit;
+      if (m->geom_type[go] == MCO_GEOM_PLANE) hit = plane_polytope(m, d, go, gm, pos, nrm, &dist);
+      else hit = poly_far_from_box(m, d, go, gm) ? 0 : box_polytope(m, d, go, gm, gm < go, pos, nrm, &dist);
+      if (!hit) continue;
+      int live = 0;
+      for (int t = 0; t < ntw; t++) live += !filtered(m, go, tw[t]);
+      if (!live) continue;
+      if (d->nentry >= m->maxentry || d->ncon + live > MCO_MAXCON) { d->ndrop += live; continue; }
+      int keep = d->nentry;
+      for (int t = 0; t < ntw; t++) {
+        if (filtered(m, go, tw[t])) continue;
+        d->nentry = keep;                                                /* the twins share one entry */
+        if (tw[t] < go) add_contact(m, d, tw[t], go, pos, nrm, dist); else add_contact(m, d, go, tw[t], pos, nrm, dist);
+      }
     }
   }
 }

@@ -852,7 +852,7 @@ typedef struct { const char* name; size_t off; int count; int is_int; } field_t;
 #define MF_D(f) { #f, offsetof(mco_model, f), (int)(sizeof(((mco_model*)0)->f) / sizeof(double)), 0 }
 static const field_t model_fields[] = {
   MF_I(nbody), MF_I(njnt), MF_I(nq), MF_I(nv), MF_I(ngeom), MF_I(nsite), MF_I(nu), MF_I(neq), MF_I(ntendon),
-  MF_I(nexclude), MF_I(enable_contact), MF_I(collide_scope_geom), MF_I(collide_extra), MF_I(hull_nvert), MF_D(hull_vert), MF_D(obb_center), MF_I(rule), MF_D(timestep), MF_D(gravity), MF_D(meaninertia),
+  MF_I(nexclude), MF_I(enable_contact), MF_I(collide_scope_geom), MF_I(collide_extra), MF_I(geom_poly), MF_I(maxentry), MF_I(rule), MF_D(timestep), MF_D(gravity), MF_D(meaninertia),
   MF_I(body_parent), MF_I(body_rootid), MF_I(body_weldid), MF_I(body_dofadr), MF_I(body_dofnum), MF_I(body_mocapid),
   MF_D(body_pos), MF_D(body_quat), MF_D(body_ipos), MF_D(body_iquat), MF_D(body_mass), MF_D(body_inertia),
   MF_I(jnt_type), MF_I(jnt_body), MF_I(jnt_qposadr), MF_I(jnt_dofadr), MF_I(jnt_limited),
@@ -876,7 +876,7 @@ static const field_t data_fields[] = {
   DF_D(qM), DF_D(qfrc_passive), DF_D(qfrc_bias), DF_D(act_force), DF_D(qfrc_actuator), DF_D(qfrc_smooth),
   DF_D(qacc_smooth), DF_I(ncon), DF_I(nefc), DF_I(ne), DF_I(nl), DF_I(efc_type), DF_I(efc_id), DF_D(efc_J),
   DF_D(efc_pos), DF_D(efc_diagApprox), DF_D(efc_R), DF_D(efc_D), DF_D(efc_KBIP), DF_D(efc_vel), DF_D(efc_aref),
-  DF_D(efc_force), DF_D(qfrc_constraint), DF_D(qacc), DF_I(solver_iter), DF_I(warning_badstate),
+  DF_D(efc_force), DF_D(qfrc_constraint), DF_D(qacc), DF_I(solver_iter), DF_I(warning_badstate), DF_I(nentry), DF_I(ndrop),
   DF_D(mocap_pos), DF_D(mocap_quat), DF_D(contact),      /* contact: raw, 28 doubles per mco_contact (the last two hold four ints) */
 };
 
@@ -897,6 +897,7 @@ int mco_model_set_d(mco_model* m, const char* field, const double* v, int n) {
   if (!f || f->is_int || n > f->count) return -1;
   memcpy((char*)m + f->off, v, sizeof(double) * n); return 0;
 }
+void mco_model_set_poly(mco_model* m, const double* blob) { m->poly = blob; }
 int mco_model_get_d(const mco_model* m, const char* field, double* v, int n) {
   const field_t* f = find(model_fields, NMODEL, field);
   if (!f || f->is_int || n > f->count) return -1;

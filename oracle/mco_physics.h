@@ -38,8 +38,9 @@ extern "C" {
 #define MCO_MAXTEN 2
 #define MCO_MAXTENJ 4
 #define MCO_MAXEXCL 16
-#define MCO_MAXCON 12      /* contacts kept per env; the HIP kernels use the same cap (MAXCON in mcg_cube.hpp) */
-#define MCO_MAXEFC 224
+#define MCO_MAXCON 64      /* contacts an env can hold (a mesh geom's twin counts); the list is cut in ENTRIES, see mco_model.maxentry */
+#define MCO_MAXEFC 416
+#define MCO_NMESH 14       /* collision polytopes (mycobotgym_amd/model/polytope.py: MESH_NAMES) */
 #define MCO_MAXMOCAP 1
 
 enum { MCO_JNT_FREE = 0, MCO_JNT_HINGE = 3 };
@@ -52,19 +53,17 @@ typedef struct mco_model {
   double timestep, gravity[3], meaninertia;
   int enable_contact;            /* 0: collision stage skipped (Reach / free-space configs) */
   int collide_scope_geom;        /* >= 0: only pairs that involve this geom collide (the build's scoped set: the cube) ... */
-  int collide_extra[48];         /* ... plus pairs of one geom flagged 1 (static: ground plane, table) and one flagged 2 (finger pad)
-                                    or 3 (arm-side mesh geom with a support polytope, below) */
-  /* Convex-mesh collision, first stage: MuJoCo collides a mesh geom's convex hull (libccd MPR, one contact per pair);
-   * restated here for mesh <-> static box / plane only, on the SUPPORT POLYTOPE of the hull (its support points in 26 directions,
-   * mycobotgym_amd/model/mjcf.py): separating-axis test over the box's face axes, one contact at the deepest vertex along the face of
-   * least penetration.  hull_nvert[g] = 0: geom g's mesh does not collide. */
-  int hull_nvert[48];
-  double hull_vert[48][26][3];   /* geom frame */
-  /* second stage: a finger-link mesh (collide_extra 4; 5 = 3 and 4, unused) collides with the cube on the same support
-   * polytope, 16-axis separating-axis test, one contact along the axis of least penetration (mco_collision.c: box_polytope).  Tried and
-   * dropped: the mesh's oriented bounding box through box-box (obb_center: a box geom's centre offset, zero for real boxes) -- the
-   * finger link's hull fills only 51 % of its bounding box, and a held cube touched that box in 70 % of perturbed grasp states. */
-  double obb_center[48][3];
+  int collide_extra[48];         /* ... plus pairs of one geom flagged 1 (static: ground plane, table) and one flagged 2 (finger pad) */
+  /* Convex-mesh collision (mycobot280_main.xml:105-247): MuJoCo collides a mesh geom's convex hull (libccd MPR, one
+   * contact per pair).  Restated here for mesh <-> ground plane / static box / the scope geom (the cube) on the mesh's COLLISION
+   * POLYTOPE (mycobotgym_amd/model/polytope.py: a vertex subset of the hull within 1 mm of it, the whole hull for the gripper's small
+   * parts) by an EXACT separating-axis test -- the box's face axes, the polytope's face normals and the edge x edge directions that
+   * are facet normals of the Minkowski difference -- one contact along the axis of least penetration (mco_collision.c).
+   * geom_poly[g] = the geom's polytope (0 .. MCO_NMESH-1) or -1; poly = the table blob in geom coordinates (shared, not owned). */
+  int geom_poly[48];
+  const double* poly;
+  int maxentry;                  /* the contact list is cut after this many ENTRIES (a primitive contact, or the identical contacts of a
+                                    mesh's twin geoms: one entry); the HIP kernels hold 16 (MAXCON in csrc/mcg_cube.hpp).  MuJoCo has no cap. */
   /* Study switches (oracle/rule_study.py): alternatives to [RECALL] rules the reference's keyframes can discriminate.
    * All zero = the adopted rule set, which is what the HIP kernels implement and every parity test runs.
    *   rule[0] weld diagApprox   0 one common (translational) weight for the six rows | 1 translational rows 0-2, rotational rows 3-5
@@ -143,6 +142,7 @@ typedef struct mco_data {
   double efc_vel[MCO_MAXEFC], efc_aref[MCO_MAXEFC], efc_force[MCO_MAXEFC];
   double qfrc_constraint[MCO_MAXNV], qacc[MCO_MAXNV];
   int solver_iter, warning_badstate;
+  int nentry, ndrop;             /* entries of the contact list (see mco_model.maxentry); contacts the cap cut off */
   /* mocap bodies (kept last: pyoracle addresses the leading state members by offset) */
   double mocap_pos[MCO_MAXMOCAP][3], mocap_quat[MCO_MAXMOCAP][4];
 } mco_data;
@@ -153,6 +153,7 @@ int mco_data_sizeof(void);
 int mco_model_set_i(mco_model* m, const char* field, const int* v, int n);
 int mco_model_set_d(mco_model* m, const char* field, const double* v, int n);
 int mco_model_get_d(const mco_model* m, const char* field, double* v, int n);
+void mco_model_set_poly(mco_model* m, const double* blob);   /* the caller keeps the blob alive */
 int mco_data_get_d(const mco_data* d, const char* field, double* v, int n);
 int mco_data_get_i(const mco_data* d, const char* field, int* v, int n);
 int mco_data_set_d(mco_data* d, const char* field, const double* v, int n);

@@ -17,8 +17,6 @@ _LIB_PATH = os.path.join(_HERE, "_build", "libmco_oracle.so")
 _lib = None
 
 MAXNQ, MAXNV, MAXU = 24, 24, 8
-ARM_MESHES = ("link1", "link2", "link3", "link4", "link5", "link6", "flange", "gripper_base")     # SURVEY 8f-4, first stage
-FINGER_MESHES = ("right_finger_link", "left_finger_link", "gripper_base")                            # second stage: against the cube (round 3: the gripper base too)
 
 
 def build(force: bool = False) -> str:
@@ -82,9 +80,8 @@ def _ptr(a):
 class OracleModel:
     """An ``mco_model`` filled from one of ``mycobotgym_amd/assets/*.json``."""
 
-    def __init__(self, table: dict, enable_contact: bool = False, scope_geom: int = -1, mesh_collision: bool = True):
+    def __init__(self, table: dict, enable_contact: bool = False, scope_geom: int = -1, mesh_collision: bool = True, maxentry: int = 16):
         L = lib()
-        self.obb_size = {}
         self.table = table
         self.buf = C.create_string_buffer(L.mco_model_sizeof())
         self.nq, self.nv, self.nu = table["nq"], table["nv"], table["nu"]
@@ -100,21 +97,20 @@ class OracleModel:
                 if table["geom_type"][g] == 7: continue
                 if table["body_weldid"][table["geom_body"][g]] == 0: extra[g] = 1
                 elif table["geom_name"][g] in ("right_finger_layer", "left_finger_layer"): extra[g] = 2
-            # ... and the arm-side mesh geoms (links 1-6, flange, gripper_base; both copies of each) through their support polytopes
-            hn = [0] * 48; hv = np.zeros((48, 26, 3))
+            si("collide_extra", extra)
+        # the mesh geoms' collision polytopes (both twins of every mesh): ground, table, cube (mco_collision.c)
+        gp = [-1] * 48
+        if scope_geom >= 0 and mesh_collision:
+            from mycobotgym_amd.model import polytope as pt
+            blob, _ = pt.load_asset()
+            self._poly = np.ascontiguousarray(blob, dtype=np.float64)          # kept alive: the model holds the pointer
             for g in range(table["ngeom"]):
-                name = table["geom_mesh"][g] if table["geom_type"][g] == 7 else ""
-                sup = np.asarray(table.get("meshes", {}).get(name, {}).get("support", []), dtype=np.float64)
-                if mesh_collision and name in ARM_MESHES and len(sup):
-                    extra[g] = 3; hn[g] = len(sup); hv[g, :len(sup)] = sup
-            # second stage: the finger-link meshes against the cube, on the same support polytopes
-            obb = np.zeros((48, 3))
-            for g in range(table["ngeom"]):
-                name = table["geom_mesh"][g] if table["geom_type"][g] == 7 else ""
-                sup = np.asarray(table.get("meshes", {}).get(name, {}).get("support", []), dtype=np.float64)
-                if mesh_collision and name in FINGER_MESHES and len(sup):
-                    extra[g] = 5 if extra[g] == 3 else 4; hn[g] = len(sup); hv[g, :len(sup)] = sup
-            si("collide_extra", extra); si("hull_nvert", hn); sd("hull_vert", hv); sd("obb_center", obb)
+                if table["geom_type"][g] == 7 and table["geom_mesh"][g] in pt.MESH_NAMES and table["geom_contype"][g] and table["geom_conaffinity"][g]:
+                    assert np.allclose(table["geom_pos"][g], 0) and np.allclose(table["geom_quat"][g], [1, 0, 0, 0])
+                    gp[g] = pt.MESH_NAMES.index(table["geom_mesh"][g])
+            L.mco_model_set_poly.argtypes = [C.c_void_p, C.c_void_p]
+            L.mco_model_set_poly(self.buf, _ptr(self._poly))
+        si("geom_poly", gp); si("maxentry", [int(maxentry)])
         sd("timestep", [table["opt"]["timestep"]]); sd("gravity", table["opt"]["gravity"])
         for k in ("body_parent", "body_rootid", "body_weldid", "body_dofadr", "body_dofnum", "jnt_type", "jnt_body",
                   "jnt_qposadr", "jnt_dofadr", "dof_body", "dof_jnt", "dof_parent", "geom_type", "geom_body",
@@ -132,9 +128,6 @@ class OracleModel:
                   "geom_pos", "geom_quat", "geom_size", "geom_friction", "geom_solref", "geom_solimp",
                   "site_pos", "site_quat"):
             v = table[k]
-            if k == "geom_size" and getattr(self, "obb_size", None):        # a colliding finger-link mesh: its bounding box's half extents
-                v = [list(x) for x in v]
-                for g, h in self.obb_size.items(): v[g] = list(h)
             sd(k, v)
         acts = table["actuators"]
         si("act_trntype", [0 if a["trntype"] == "joint" else 1 for a in acts])

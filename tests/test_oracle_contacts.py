@@ -39,7 +39,7 @@ def test_cube_on_table_four_face_contacts(po):
     d.forward()
     n, nefc = _contacts(d)
     assert n == 4 and nefc == 7 + 4 * 6                      # 7 equality rows + 4 condim-4 pyramids
-    pos = d.get("efc_pos", (224,))[7:31]
+    pos = d.get("efc_pos", (416,))[7:31]
     assert np.allclose(pos, -1e-4, atol=1e-12)               # dist = -penetration on every pyramid row
     # separated: no contact; cube over the table edge: fewer vertices inside
     tab, om, d = _scene(po, [-0.05, 0.0, 0.2101]); d.forward(); assert _contacts(d)[0] == 0
@@ -76,9 +76,9 @@ def test_nearly_parallel_edges_never_beat_the_faces(po):
         d.set_state(qpos=q, qvel=np.zeros(18)); d.forward()
         n, nefc = _contacts(d)
         assert n == 4 and nefc == 7 + 24, (trial, ang, n)
-        J = d.get("efc_J", (224, 24))[7:31, 12:15]
+        J = d.get("efc_J", (416, 24))[7:31, 12:15]
         assert np.abs(J[0::6, 2] - 1.0).max() < 1e-6, (trial, ang)       # first pyramid row: n + mu t1, z-component = n_z = 1
-        assert d.get("efc_pos", (224,))[7:31].max() < -1e-6
+        assert d.get("efc_pos", (416,))[7:31].max() < -1e-6
 
 
 def _rest_penetration(po, rules=None):
@@ -212,30 +212,48 @@ def test_finger_pads_never_reach_each_other(po):
     assert d.qpos[6] > 0.699 and 0.0024 < gaps[-1] < 0.0028 and min(gaps) > 0.0024
 
 
+def _contact_table(d):
+    """The oracle's contact list: (geom1, geom2, dim, dist, pos, normal, efc_address) per contact (mco_contact, exported raw)."""
+    n = int(d.get("ncon", (1,), np.int32)[0])
+    raw = d.get("contact", (64, 28))
+    out = []
+    for c in range(n):
+        ints = raw[c, 26:28].copy().view(np.int32)           # dim, geom1, geom2, efc_address
+        out.append((int(ints[1]), int(ints[2]), int(ints[0]), float(raw[c, 0]), raw[c, 1:4].copy(), raw[c, 4:7].copy(), int(ints[3])))
+    return out
+
+
 def test_finger_pad_on_the_table_is_a_contact(po):
-    """Scoped set (what the kernels implement): cube pairs + finger pad <-> table / ground plane."""
+    """Scoped set (what the kernels implement): cube pairs + finger pad <-> table / ground plane (+ the mesh polytopes, behind them)."""
     tab = load_json("mycobot280")
     om = po.OracleModel(tab, enable_contact=True, scope_geom=tab["geom_name"].index("object0")); d = po.OracleData(om)
     q = np.asarray(tab["qpos0"], dtype=float).copy()
     q[:7] = [0.417, -2.299, 1.057, 0.345, 1.63, 0.161, 0.569]; q[8] = q[6]            # a pose that presses a pad on the table top
     d.set_state(qpos=q, qvel=np.zeros(18)); d.forward()
-    n = int(d.get("ncon", (1,), np.int32)[0])
-    assert n > 4
-    J = d.get("efc_J", (224, 24))[7:7 + 6 * (n - 4), :18]         # pair order: (table, pads) before (table, cube): the cube's 4 contacts come last
-    assert np.abs(J[:, 12:18]).max() == 0.0 and np.abs(J[:, :10]).max() > 0           # rows of the pad contacts: robot dofs only
+    gn = tab["geom_name"]; pads = {gn.index("right_finger_layer"), gn.index("left_finger_layer")}
+    t = _contact_table(d)
+    padc = [c for c in t if c[1] in pads]
+    assert padc and all(c[0] == 1 and c[2] == 4 for c in padc)                          # the table is geom1; condim 4 (the pad's)
+    # pair order: the primitive pairs first -- (table, pads) before (table, cube) -- then the meshes
+    kinds = ["pad" if c[1] in pads else ("cube" if c[1] == gn.index("object0") and c[0] == 1 else "mesh") for c in t]
+    assert kinds == sorted(kinds, key=["pad", "cube", "mesh"].index)
+    J = d.get("efc_J", (416, 24))
+    for c in padc:
+        rows = J[c[6]:c[6] + 6, :18]
+        assert np.abs(rows[:, 12:18]).max() == 0.0 and np.abs(rows[:, :10]).max() > 0  # rows of the pad contacts: robot dofs only
 
 
 def test_arm_mesh_on_the_table_is_a_contact(po):
-    """SURVEY 8f-4, first stage: the arm-side mesh geoms collide with the table / ground through the support polytope of their convex
-    hull (26 directions), one contact per geom pair at the deepest vertex; every mesh is attached twice in the reference
-    (mycobot280_main.xml:105-175: a visual copy with density 0 and a default one, both colliding), so contacts come in identical pairs;
-    default geoms are condim 3: four pyramid rows, in the arm's dofs up to the link."""
+    """SURVEY 8f-4: the arm's mesh geoms collide with the table / ground through their collision polytopes, one contact per geom pair;
+    every mesh is attached twice in the reference (mycobot280_main.xml:105-175: a visual copy with density 0 and a default one, both
+    colliding), so contacts come in identical pairs (one ENTRY of the list); default geoms are condim 3: four pyramid rows, in the arm's
+    dofs up to the link."""
     tab = load_json("mycobot280")
     om = po.OracleModel(tab, enable_contact=True, scope_geom=tab["geom_name"].index("object0")); d = po.OracleData(om)
     q = np.asarray(tab["qpos0"], dtype=float).copy()
     d.set_state(qpos=q, qvel=np.zeros(18)); d.forward()
     assert int(d.get("ncon", (1,), np.int32)[0]) == 4                    # upright arm: only the cube on the table
-    # fold the arm forward until link4 / link5 press on the table top
+    # fold the arm forward until exactly one link presses on the table top
     rng = np.random.default_rng(3)
     found = None
     for _ in range(20000):
@@ -246,97 +264,65 @@ def test_arm_mesh_on_the_table_is_a_contact(po):
         if n == 6 and nefc == 7 + 2 * 4 + 4 * 6:                         # exactly one mesh pair (2 x condim 3) + the cube's four (condim 4)
             found = q.copy(); break
     assert found is not None
-    J = d.get("efc_J", (224, 24))[7:7 + 8, :18]
-    pos = d.get("efc_pos", (224,))[7:7 + 8]
+    assert int(d.get("nentry", (1,), np.int32)[0]) == 5                  # the twins are one entry
+    t = _contact_table(d)
+    assert [c[2] for c in t] == [4, 4, 4, 4, 3, 3] and t[5][0] == t[4][0] and t[5][1] == t[4][1] + 1
+    J = d.get("efc_J", (416, 24))[t[4][6]:t[4][6] + 8, :18]
+    pos = d.get("efc_pos", (416,))[t[4][6]:t[4][6] + 8]
     assert np.allclose(J[:4], J[4:8]) and np.allclose(pos[:4], pos[4:8]) and pos[0] < 0        # the two copies: identical contacts
     assert np.abs(J[:, 6:]).max() == 0.0 and np.abs(J[:, :6]).max() > 0                         # arm dofs only
-    # the mesh proxies: 26 support points, 78-89 % of the hull's volume
-    for name in ("link1", "link2", "link3", "link4", "link5", "link6", "flange", "gripper_base"):
-        mm = tab["meshes"][name]
-        assert len(mm["support"]) == 26 and 0.75 < mm["support_volume"] / mm["hull_volume"] < 0.92 and mm["hull_nvert"] > 500
 
 
-def _contact_table(d):
-    """The oracle's contact list: (geom1, geom2, dim, dist, pos, normal) per contact (mco_contact, exported raw)."""
-    n = int(d.get("ncon", (1,), np.int32)[0])
-    raw = d.get("contact", (12, 28))
-    out = []
-    for c in range(n):
-        ints = raw[c, 26:28].copy().view(np.int32)           # dim, geom1, geom2, efc_address
-        out.append((int(ints[1]), int(ints[2]), int(ints[0]), float(raw[c, 0]), raw[c, 1:4].copy(), raw[c, 4:7].copy()))
-    return out
+def test_collision_polytopes_are_within_a_millimetre_of_the_hulls():
+    """mycobotgym_amd/assets/polytopes.npz: every mesh's polytope within 1 mm (Hausdorff) of its convex hull, the gripper's small parts
+    exact; Euler's formula holds for the merged faces and edges; every vertex inside every face plane; the edges' cone vectors are
+    perpendicular to the edges."""
+    from mycobotgym_amd.model import polytope as pt
+    blob, stats = pt.load_asset()
+    polys = pt.unpack(blob)
+    assert len(polys) == 14
+    for name, P, st in zip(pt.MESH_NAMES, polys, stats):
+        V, F, E = P["verts"], P["faces"], P["edges"]
+        assert (len(V), len(F), len(E)) == tuple(int(x) for x in st[:3])
+        assert len(V) - len(E) + len(F) == 2, name
+        assert st[3] <= 1.0e-3 and (st[3] == 0.0 or st[4] > 64), (name, st[3])
+        assert (V @ F[:, :3].T - F[:, 3]).max() < 1e-12
+        assert np.abs(np.linalg.norm(F[:, :3], axis=1) - 1).max() < 1e-12 and np.abs(np.linalg.norm(E[:, 3:6], axis=1) - 1).max() < 1e-12
+        assert np.abs((E[:, 3:6] * E[:, 6:9]).sum(1)).max() < 1e-5 and np.abs((E[:, 3:6] * E[:, 9:12]).sum(1)).max() < 1e-5      # (merged faces: float32 STL noise)
+        assert st[5] > 0.95 or st[3] == 0.0                                 # volume against the hull's
+    assert np.array_equal(pt.pack(polys), blob)
 
 
 def test_gripper_meshes_against_the_cube(po):
-    """SURVEY 8f-4, second stage (oracle side): the finger-link meshes collide with the cube on their support polytopes.  The pads protrude beyond the links, so none of the scripted-grasp states holds such a contact; pushed sideways they
-    appear, condim 4, the mesh as geom1, one contact per geom, the twin geom's copy right after (the reference attaches every mesh twice)."""
+    """The mesh geoms against the cube (oracle side).  None of the scripted-grasp START states holds such a contact; with the gripper
+    pushed sideways they appear: condim 4, the mesh as geom1, one contact per geom, the twin geom's copy right after (the reference
+    attaches every mesh twice), behind the primitive pairs' contacts, which are what they are without the meshes."""
     from mycobotgym_amd.scenarios import grasp_state
     tab = load_json("mycobot280")
     scope = tab["geom_name"].index("object0")
     d1 = po.OracleData(po.OracleModel(tab, enable_contact=True, scope_geom=scope))
     d0 = po.OracleData(po.OracleModel(tab, enable_contact=True, scope_geom=scope, mesh_collision=False))
-    fingers = {g for g in range(tab["ngeom"]) if tab["geom_type"][g] == 7 and tab["geom_mesh"][g] in ("right_finger_link", "left_finger_link")}
-    assert len(fingers) == 4
+    meshes = {g for g in range(tab["ngeom"]) if tab["geom_type"][g] == 7}
     q0 = np.asarray(grasp_state(64, seed=0)["qpos"]); q0 = q0.T if q0.shape[0] == 19 else q0
     for q in q0:
         d1.set_state(qpos=q, qvel=np.zeros(18)); d1.forward()
-        assert not any(c[0] in fingers for c in _contact_table(d1))        # the pads hold the cube, not the links
+        assert not any(c[0] in meshes or c[1] in meshes for c in _contact_table(d1))
     rng = np.random.default_rng(0)
-    seen = 0
+    seen = 0; which = set()
     for trial in range(200):
         q = q0[rng.integers(64)].copy()
         q[:6] += rng.normal(0, 0.06, 6); q[6] = q[8] = np.clip(q[6] + rng.normal(0, 0.15), 0, 0.7)
         for d in (d0, d1): d.set_state(qpos=q, qvel=np.zeros(18)); d.forward()
         t0, t1 = _contact_table(d0), _contact_table(d1)
-        fin = [c for c in t1 if c[0] in fingers]
-        assert [c[:4] for c in t1 if c[0] not in fingers][:len(t0)] == [c[:4] for c in t0][:len([c for c in t1 if c[0] not in fingers])]   # the other pairs are untouched
-        if not fin: continue
+        if int(d1.get("ndrop", (1,), np.int32)[0]): continue
+        assert [c[:4] for c in t1[:len(t0)]] == [c[:4] for c in t0]                         # the primitive pairs are untouched, and in front
+        mc = [c for c in t1[len(t0):] if c[1] == scope]
+        assert all(c[0] in meshes for c in t1[len(t0):])
+        if not mc: continue
         seen += 1
-        assert all(c[1] == scope and c[2] == 4 and c[3] < 0 for c in fin)
-        if len(t1) < 12:                                                     # uncapped list: every contact comes with its twin right after
-            assert len(fin) % 2 == 0
-            for a, b in zip(fin[0::2], fin[1::2]):
-                assert b[0] == a[0] + 1 and a[3] == b[3] and np.array_equal(a[4], b[4]) and np.array_equal(a[5], b[5])
-    assert seen > 50
-
-
-def test_polytope_axes_remove_the_false_contacts_off_the_table_edges(po):
-    """The table test of the arm-side meshes: with the box's face axes alone (study switch rule[7]) a link diagonally off an edge of
-    the table counts as touching whenever its table-aligned extent overlaps the table; the polytope's own 13 canonical axes remove
-    most of those.  Every contact the 13 axes remove is checked to be a FALSE one -- the polytope and the table are a positive
-    distance apart (convex QP) -- and no contact is ever added."""
-    from scipy.optimize import minimize
-    tab = load_json("mycobot280")
-    scope = tab["geom_name"].index("object0")
-    m_new = po.OracleModel(tab, enable_contact=True, scope_geom=scope); d_new = po.OracleData(m_new)
-    m_old = po.OracleModel(tab, enable_contact=True, scope_geom=scope); m_old._set_i("rule", [0, 0, 0, 0, 0, 0, 0, 1]); d_old = po.OracleData(m_old)
-    gt = [g for g in range(tab["ngeom"]) if tab["body_name"][tab["geom_body"][g]] == "table"][0]
-    th = np.asarray(tab["geom_size"][gt]); tp = np.asarray(tab["body_pos"][tab["geom_body"][gt]]) + np.asarray(tab["geom_pos"][gt])
-    rng = np.random.default_rng(5)
-    removed = kept = 0
-    for trial in range(4000):
-        q = np.array(tab["qpos0"], float); q[:6] = rng.uniform(-2.9, 2.9, 6)
-        for d in (d_old, d_new): d.set_state(qpos=q, qvel=np.zeros(18)); d.forward()
-        old = {(c[0], c[1]) for c in _contact_table(d_old) if c[0] == gt and tab["geom_type"][c[1]] == 7}
-        new = {(c[0], c[1]) for c in _contact_table(d_new) if c[0] == gt and tab["geom_type"][c[1]] == 7}
-        if len(_contact_table(d_old)) >= 12: continue                      # capped lists cut differently
-        assert new <= old
-        kept += len(new)
-        for (_, g) in sorted(old - new)[:1]:
-            if removed >= 12: break                                         # a dozen QPs are enough
-            sup = np.asarray(tab["meshes"][tab["geom_mesh"][g]]["support"])
-            R = d_new.get("geom_xmat", (48, 9))[g].reshape(3, 3); pg = d_new.get("geom_xpos", (48, 3))[g]
-            V = pg + sup @ R.T
-            n = len(V)
-            def f(z):                     # |sum_i w_i V_i - y|^2, w on the simplex, y in the box
-                w, y = z[:n], z[n:]
-                r = w @ V - y
-                return r @ r
-            cons = [{"type": "eq", "fun": lambda z: z[:n].sum() - 1}]
-            bnds = [(0, 1)] * n + [(tp[k] - th[k], tp[k] + th[k]) for k in range(3)]
-            z0 = np.concatenate([np.full(n, 1.0 / n), np.clip(V.mean(0), tp - th, tp + th)])
-            res = minimize(f, z0, method="SLSQP", bounds=bnds, constraints=cons, options={"maxiter": 300, "ftol": 1e-14})
-            assert res.fun > 1e-8, (trial, g, res.fun)                      # separated: squared distance > (0.1 mm)^2
-            removed += 1
-    print(f"\nmesh-table contacts kept {kept}, removed as false {removed} (4000 random arm poses)")
-    assert removed >= 2 and kept > 100                                      # (rare for this table: the false region is a band along its edges)
+        assert all(c[2] == 4 and c[3] < 0 for c in mc) and len(mc) % 2 == 0
+        for a, b in zip(mc[0::2], mc[1::2]):
+            assert b[0] == a[0] + 1 and a[3] == b[3] and np.array_equal(a[4], b[4]) and np.array_equal(a[5], b[5])
+            which.add(tab["geom_mesh"][a[0]])
+    print("\nmeshes seen on the cube:", sorted(which))
+    assert seen > 50 and len(which) >= 3
