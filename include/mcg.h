@@ -32,7 +32,9 @@
 extern "C" {
 #endif
 
-#define MCG_ABI_VERSION 7
+#define MCG_ABI_VERSION 8
+#define MCG_MAXCON 16          /* entries of an environment's contact list (MuJoCo has no cap; see mcg_counters.contacts_dropped) */
+#define MCG_NMESH 14           /* collision polytopes of the mesh geoms */
 
 enum { MCG_OK = 0, MCG_ERR_ARG = 1, MCG_ERR_HIP = 2, MCG_ERR_UNSUPPORTED = 3 };
 enum { MCG_CTRL_JOINT = 0, MCG_CTRL_IK = 1, MCG_CTRL_MOCAP = 2 };   /* controller_type "joint" | "IK" | "mocap" */
@@ -45,7 +47,7 @@ typedef struct mcg_body {          /* 16 doubles = 128 B: one body's constants, 
   double mass, mc[3];               /* mass, mass * centre of mass (body frame, about the origin) */
   double inertia[6];                /* xx yy zz xy xz yz about the body origin */
   double armature, damping;         /* of the body's hinge (cube: unused, see cube_damping) */
-  double hull_rad;                  /* arm bodies: largest distance from the body origin to a vertex of the mesh polytopes riding on it */
+  double hull_rad;                  /* robot bodies: largest distance from the body origin to a vertex of the mesh polytopes riding on it */
 } mcg_body;
 
 typedef struct mcg_model {
@@ -62,29 +64,22 @@ typedef struct mcg_model {
   double site_eef[3];               /* EEF site in the link6 frame */
   /* PickAndPlace only */
   double cube_half[3], table_pos[3], table_half[3], pad_box[2][6];
-  double contact_par[7][15];        /* table-cube, right pad-cube, left pad-cube, table-right pad, table-left pad, table-arm mesh,
-                                       finger mesh-cube: the 10 solver numbers | friction[5].  The ground plane carries the table's
-                                       (default) parameters. */
+  double contact_par[7][15];        /* table-cube, right pad-cube, left pad-cube, table-right pad, table-left pad, table-mesh (condim 3),
+                                       mesh-cube: the 10 solver numbers | friction[5].  The ground plane carries the table's
+                                       (default) parameters; all mesh geoms are default geoms (asserted when the block is made). */
   double contact_diag[5][2];        /* summed body_invweight0 (translational, rotational) of the first five pairs */
-  /* Convex-mesh collision, first stage (mycobot280_main.xml:105-175): the arm-side mesh geoms -- link1..link6, flange,
-     gripper_base -- against the table and the ground plane, on the support polytope of each mesh's convex hull (its support points in
-     26 directions, mycobotgym_amd/model/mjcf.py:support_polytope), one contact per pair at the deepest vertex. */
-  double link_hull[8][26][3];       /* vertices in the frame of the engine body the geom rides on: polytope p on body min(p, 5) */
-  double link_hull_box[8][6];       /* centre and half extents of the vertices' bounding box in that frame (broad phase) */
-  double link_diag[8][2];           /* body_invweight0 of the geom's MJCF body (translational, rotational) */
-  double link_ext[8][13][2];        /* least and largest d . v over the polytope's vertices for the 13 canonical directions d of the body
-                                       frame (axes, face diagonals, space diagonals, integer components; order: MCG_DIR13 in
-                                       csrc/mcg_cube.hpp): extra separating axes of the table test */
-  double link_mult;                 /* identical colliding geoms per mesh (the reference attaches every mesh twice: 2) */
-  /* ... second stage: the two finger-link meshes (mycobot280_main.xml:195-199,222-225) against the cube, on
-     the same support polytopes: separating-axis test over the cube's three face axes and the polytope's 13 canonical axes, one contact
-     along the axis of least penetration.  The pads are welded to the finger links: same pair of bodies as the pad-cube contacts. */
-  double fin_hull[2][26][3];        /* right, left finger link: vertices in the finger-link frame */
-  double fin_ext[2][13][2];         /* least and largest d . v over those vertices for the 13 canonical directions (as link_ext) */
-  double fin_box[2][6];             /* centre and half extents of the vertices' bounding box in that frame (broad phase) */
-  double fin_par[4];                /* identical colliding geoms per mesh | the mesh geoms' own sliding friction (the cube's is
-                                       re-scaled under domain randomisation, the pair takes the larger) | summed translational
-                                       body_invweight0 of (right finger link, cube), (left finger link, cube) */
+  /* Convex-mesh collision (mycobot280_main.xml:105-247): the fourteen mesh geoms of the arm and the gripper -- link1..link6,
+     flange, gripper_base, right gear / finger link, left gear / finger link, right / left hinge link -- against the ground plane, the
+     table and the cube, on each mesh's collision polytope (within 1 mm of its convex hull; mycobotgym_amd/model/polytope.py), by an
+     exact separating-axis test, one contact per pair (csrc/mcg_mesh.hpp).  The polytopes' vertex / face / edge tables are a separate
+     block (mcg_create: `polytopes`). */
+  double mesh_box[MCG_NMESH][6];    /* centre and half extents of the polytope's bounding box in the frame of the robot body it rides on
+                                       (polytope m on body m for m < 6; flange, gripper_base on 5; then bodies 6..11): broad phase */
+  double mesh_mult;                 /* identical colliding geoms per mesh (the reference attaches every mesh twice: 2) */
+  double mesh_fric;                 /* the mesh geoms' own sliding friction (the cube's is re-scaled under domain randomisation, a pair
+                                       takes the larger) */
+  double pair_tran[5 + 2 * MCG_NMESH];   /* per pair type (csrc/mcg_cube.hpp: 0 static-cube, 1 / 2 pad-cube, 3 / 4 static-pad, 5 + m static-mesh m,
+                                       19 + m mesh m-cube) the summed translational body_invweight0 of the two geoms' bodies */
   double geom_friction0[3];         /* sliding friction of the table, pad and cube geoms (re-mixed under domain randomisation) */
   /* mocap variant only (mycobot280_mocap.xml): weld between the mocap body and gripper_tcp */
   double base_quat[4];              /* orientation of the arm's base body: start of the xquat chain */
@@ -163,7 +158,7 @@ typedef struct mcg_state {
 typedef struct mcg_counters {
   uint64_t reset_cap_hits;          /* a rejection loop of reset_model (mycobot.py:218-219, 232-233: unbounded `while`) gave up after 1000 draws */
   uint64_t bad_state_resets;        /* mj_checkPos / mj_checkVel / mj_checkAcc fired: a body's state was reset (per body, per event) */
-  uint64_t contacts_dropped;        /* contacts cut off by the build's cap of 12 contacts per environment (MuJoCo has no such cap) */
+  uint64_t contacts_dropped;        /* contacts cut off by the build's cap of MCG_MAXCON list entries per environment (MuJoCo has no such cap) */
   uint64_t coupled_env_substeps;    /* environment-sub-steps routed through the cooperative robot + cube solve (a contact reached the robot) */
 } mcg_counters;
 
@@ -174,7 +169,10 @@ const char* mcg_last_error(void);
 /* built-in model blocks: 0 = legacy mesh inertia (default), 1 = exact mesh inertia; 2, 3 = the same for the mocap variant */
 int mcg_default_model(int variant, mcg_model* out);
 
-int mcg_create(const mcg_config* cfg, const mcg_model* model /* NULL = variant 0 */, int device, mcg_env** out);
+/* polytopes: the mesh geoms' collision tables in the robot bodies' frames (layout: mycobotgym_amd/model/polytope.py: pack), n_polytopes
+   doubles, host memory; NULL = the built-in tables of the reference's meshes */
+int mcg_create(const mcg_config* cfg, const mcg_model* model /* NULL = variant 0 */, const double* polytopes, int64_t n_polytopes,
+               int device, mcg_env** out);
 void mcg_destroy(mcg_env* env);
 int mcg_obs_dim(const mcg_env* env);
 int mcg_action_dim(const mcg_env* env);
@@ -196,7 +194,7 @@ int mcg_compute_reward(const double* achieved /* [n,3] device */, const double* 
 int mcg_get_counters(mcg_env* env, mcg_counters* out, int clear);
 
 /* TEST / DEBUG: the collision pass (mj_collision restated, P4) of PickAndPlace on the CURRENT state, exported as the kernels see it.
-   All device pointers.  count [N]: list entries; dropped [N]: contacts cut by the cap (or NULL); data [N, 12, 10]: per entry dist,
+   All device pointers.  count [N]: list entries; dropped [N]: contacts cut by the cap (or NULL); data [N, MCG_MAXCON, 10]: per entry dist,
    pos[3] (midpoint between the surfaces), normal[3] (geom1 -> geom2), pair type (csrc/mcg_cube.hpp PAIR_*), multiplicity (identical
    geoms the entry stands for), D (weight of its pyramid rows). */
 int mcg_debug_contacts(mcg_env* env, int32_t* count, int32_t* dropped, double* data, void* stream);

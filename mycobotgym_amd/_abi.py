@@ -16,7 +16,8 @@ LIB_PATH = os.environ.get("MCG_LIB") or os.path.join(_HERE, "libmycobot_hip.so")
 
 MCG_OK, MCG_ERR_ARG, MCG_ERR_HIP, MCG_ERR_UNSUPPORTED = 0, 1, 2, 3
 CTRL_JOINT, CTRL_IK, CTRL_MOCAP = 0, 1, 2
-ABI_VERSION = 7
+ABI_VERSION = 8
+MAXCON, NMESH = 16, 14
 REWARD_SPARSE, REWARD_DENSE, REWARD_SHAPING = 0, 1, 2
 
 d = C.c_double
@@ -43,8 +44,7 @@ class McgModel(C.Structure):
         ("cube_half", d * 3), ("table_pos", d * 3), ("table_half", d * 3), ("pad_box", (d * 6) * 2),
         ("contact_par", (d * 15) * 7),
         ("contact_diag", (d * 2) * 5),
-        ("link_hull", ((d * 3) * 26) * 8), ("link_hull_box", (d * 6) * 8), ("link_diag", (d * 2) * 8), ("link_ext", ((d * 2) * 13) * 8), ("link_mult", d),
-        ("fin_hull", ((d * 3) * 26) * 2), ("fin_ext", ((d * 2) * 13) * 2), ("fin_box", (d * 6) * 2), ("fin_par", d * 4),
+        ("mesh_box", (d * 6) * NMESH), ("mesh_mult", d), ("mesh_fric", d), ("pair_tran", d * (5 + 2 * NMESH)),
         ("geom_friction0", d * 3),
         ("base_quat", d * 4), ("weld_on", d), ("weld_par", d * 10), ("weld_diag", d * 2), ("weld_anchor", d * 3),
         ("weld_relpos", d * 3), ("weld_relquat", d * 4), ("weld_torquescale", d),
@@ -119,7 +119,7 @@ def load():
     L.mcg_abi_version.restype = C.c_int
     L.mcg_last_error.restype = C.c_char_p
     L.mcg_default_model.argtypes = [C.c_int, C.POINTER(McgModel)]
-    L.mcg_create.argtypes = [C.POINTER(McgConfig), C.POINTER(McgModel), C.c_int, C.POINTER(C.c_void_p)]
+    L.mcg_create.argtypes = [C.POINTER(McgConfig), C.POINTER(McgModel), C.c_void_p, C.c_int64, C.c_int, C.POINTER(C.c_void_p)]
     L.mcg_destroy.argtypes = [C.c_void_p]
     L.mcg_destroy.restype = None
     for f in ("mcg_obs_dim", "mcg_action_dim", "mcg_nq", "mcg_nv"):

@@ -25,20 +25,20 @@
 // and no per-class accumulators (what kept the gripper base - cube pair out of round 2's lane-parallel solve: it is enabled now).
 #pragma once
 
-#include "mcg_cube.hpp"
+#include "mcg_mesh.hpp"
 
 namespace mcg {
 
 // ---- exchange slots of the four-wave kernel (all per-lane columns).
 // Clip-polygon area, first 32 slots (the collision pass clips there, before barrier S2; afterwards:) flags and the cube's hand-over.
-// XCH_FLAG: 0 = no contact reaches the robot | 1 = only static geoms touch the robot (pad / arm mesh on the table or the ground): robot
-// and cube still decouple | 2 = the cube touches the robot (pad / finger link): one coupled 18-dof problem.
+// XCH_FLAG: 0 = no contact reaches the robot | 2 = one does (a pad or a mesh on the cube, the table or the ground), or the cube alone
+// holds more contacts than its own solve has row slots for: the environment's 18 dofs go to the cooperative solve.
 constexpr int XCH_FLAG = LDS_POLY, XCH_T0 = LDS_POLY + 1, XCH_T1 = LDS_POLY + 2, XCH_NCON = LDS_POLY + 3;
 constexpr int XCH_CB = LDS_POLY + 4, XCH_QL7 = LDS_POLY + 23, XCH_DR = LDS_POLY + 30;      // cube: pos 3, quat 4, vel 6, warm 6; lagged pose 7; DR scales 2
 static_assert(XCH_DR + 2 <= LDS_POLY + 32, "exchange area exceeds the clip-polygon slots");
 // ... second 32 slots, which no pass writes: q(t), qd(t) of the robot for the other waves -- written at the end of a sub-step, read after
-// S1 by the M, RNE and cube waves and between S4 and S5 by the cooperative solves -- and the workgroup's hand-out counter of that phase
-// (an unsigned in the first word of lane 0's slot).
+// S1 by the M, RNE and cube waves and between S4 and S5 by the cooperative solves -- and the workgroup's hand-out counters: of that phase
+// (an unsigned in the first word of lane 0's slot) and of the mesh phase (lane 1's slot, mcg_mesh.hpp).
 constexpr int XCH_Q = LDS_POLY + 32, XCH_QD = XCH_Q + NB, COOP_CTR_SLOT = XCH_QD + NB;
 // XCH_T1 (robot wave -> cube wave, read after S1) / XCH_BADC (cube wave -> robot wave, read after S4): the other body failed mj_checkPos /
 // mj_checkVel, mj_resetData resets both
@@ -46,16 +46,15 @@ constexpr int XCH_BADC = COOP_CTR_SLOT + 1;
 // XCH_ACT0 / XCH_ACT1: the active set the environment's last cooperative solve ended with, as raw bits -- [signature of the contact list |
 // rows 0-31], [rows 32-63 | rows 64-95] -- cleared at the start of an env-step.  The next sub-step's solve starts from it (see coop_guess).
 constexpr int XCH_ACT0 = XCH_BADC + 1, XCH_ACT1 = XCH_ACT0 + 1;
-static_assert(XCH_ACT1 + 1 <= LDS_POLY + 60, "exchange area (slots 60, 61: the staging waves' flags, mcg_cube.hpp)");
+static_assert(XCH_ACT1 + 1 <= LDS_POLY + 62, "exchange area (slots 62, 63: a stage-clock census)");
 // Line-search row area (LDS_ROW .. LDS_ROW + 144 slot rows of PNP_LANES doubles):
 //   [0, 96)    the cube wave's own solves (12 slots per contact, list positions 0..7: a lane whose cube contacts sit higher is flagged 2);
 //              between barriers S4 and S5, when every lane-parallel solve is over: cooperative workspace, 768 doubles per wave
 //   [96, 140)  columns of the FLAGGED lanes only: inputs of their cooperative solve, parked by the robot wave after S2
 constexpr int PUB_G0 = LDS_ROW + 96, PUB_SD = PUB_G0 + NB, PUB_AREF = PUB_SD + 10, PUB_WARM = PUB_AREF + 10;
 constexpr int COOP_WS_ROW = LDS_ROW, COOP_WS_DOUBLES = 768;
-static_assert(PUB_WARM + NB <= LDS_ROW + MAXCON * 12, "publish area");
+static_assert(PUB_WARM + NB <= LDS_ROW + ROW_SLOTS, "publish area");
 static_assert(4 * COOP_WS_DOUBLES <= 96 * PNP_LANES, "cooperative workspace exceeds the first 96 rows of the row area");
-static_assert(ALONE_MAX_LIST * 12 <= 96, "a flagged-1 lane's own solve must stay below the parked inputs");
 constexpr int COOP_NV = 18, COOP_WIN = 16, COOP_WSTRIDE = 20;          // window: 16 active rows x (D, D aref, J[18])
 static_assert(COOP_WIN * COOP_WSTRIDE <= COOP_WS_DOUBLES && COOP_NV * COOP_NV + COOP_NV <= COOP_WS_DOUBLES, "window / matrix buffer");
 constexpr int COOP_ROWS = 10 + 6 * MAXCON, COOP_SETS = (COOP_ROWS + PNP_LANES - 1) / PNP_LANES;      // limits first, then the contacts
@@ -138,6 +137,80 @@ __device__ double g_coop_dbg[32 * 512];
 __device__ int g_coop_dbg_done[32];
 #endif
 
+// ---- one row of the coupled problem (shared by the two solvers).  Row r < 10: the limit of joint r (from the robot wave's parked numbers);
+// else pyramid row (r - 10) % 6 of contact (r - 10) / 6.  A contact's Jacobian row is built from its frame and the TWIST COLUMNS tc[j] of
+// the joints in the chain of the pair's robot body: J_r[j] = +- e_r . c_j, e_r = [d ; lever x d + tau n], c_j = [(anchor_j - p0) x axis_j ;
+// axis_j] (p0 = the cube's centre), and [d ; Rc^T (...)] in the cube's six dofs.  Any pair type is a row: there are no contact classes.
+template <class CSYS>
+MCG_DEV void coop_build_row(const PnpScratch ME, const CSYS& CS, const real* cpos, const real (*tc)[6], const real* qd, const real* vc, int r, int ncon,
+                            real* J, real& D, real& ar, int& rowcls) {
+  const bool is_lim = r < 10;
+  // limit row: J = sg e_j, D, aref from the robot wave
+  const int jl = sel(is_lim, r, 0);
+  const real sD = ME.ld(PUB_SD + jl), al = ME.ld(PUB_AREF + jl);
+  const real sgn = sel(sD > 0, 1.0, sel(sD < 0, -1.0, 0.0));
+  // contact row
+  const int rc = sel(is_lim, 0, r - 10);
+  const int c = sel(rc / 6 < MAXCON, rc / 6, MAXCON - 1), p = rc % 6;
+  const bool is_con = !is_lim && (rc / 6 < ncon);
+  const int b = LDS_CON + c * CON_STRIDE;
+  real lev[3], n[3], t1[3], t2[3];
+  _Pragma("unroll") for (int k = 0; k < 3; k++) { lev[k] = ME.ld(b + k) - cpos[k]; n[k] = ME.ld(b + 3 + k); }
+  const real Dc = ME.ld(b + CON_D), kterm = ME.ld(b + CON_KTERM), ftype = ME.ld(b + CON_TYPE);
+  MCG_FENCE();                                                                 // the row's loads are issued together
+  { const bool unit = is_con; real nn[3] = {sel(unit, n[0], 0.0), sel(unit, n[1], 0.0), sel(unit, n[2], 1.0)}; make_frame(nn, t1, t2); }      // (rows that are no contact: a defined frame)
+  const int type = sel(is_con, (int)ftype, 0);
+  const bool padc = type == PAIR_PADR_CUBE || type == PAIR_PADL_CUBE, mcube = pair_mesh_cube(type);
+  const bool mstat = pair_mesh_static(type), tabp = (type == PAIR_TABLE_PADR || type == PAIR_TABLE_PADL);
+  const bool has_cube = pair_has_cube(type);
+  const int rb = pair_robot_body(type);                                        // the robot body of the pair (-1: none)
+  const real rsign = sel(has_cube, -1.0, 1.0);                                 // robot geom is geom1 against the cube, geom2 against a static geom
+  real mu[3]; real Bc;
+  _Pragma("unroll") for (int k = 0; k < 3; k++)
+    mu[k] = sel(mstat, CS.mu_tl[k], sel(tabp, CS.mu_tp[k], sel(mcube, CS.mu_mc[k], sel(padc, CS.mu_pc[k], CS.mu_tc[k]))));
+  Bc = sel(mstat, CS.B_tl, sel(tabp, CS.B_tp, sel(mcube, CS.B_mc, sel(padc, CS.B_pc, CS.B_tc))));
+  const int kf = p >> 1;
+  const real m = sel((p & 1), -1.0, 1.0) * sel3(kf, mu[0], mu[1], mu[2]);
+  const bool absent = mstat && kf == 2;                                        // condim 3: no torsional pair of rows
+  real dlin[3], eang[3];
+  _Pragma("unroll") for (int k = 0; k < 3; k++) dlin[k] = n[k] + sel(kf == 0, m * t1[k], sel(kf == 1, m * t2[k], 0.0));
+  cross(lev, dlin, eang);
+  const real tau = sel(kf == 2, m, 0.0);
+  _Pragma("unroll") for (int k = 0; k < 3; k++) eang[k] = fma(tau, n[k], eang[k]);
+  const bool live = is_con && !absent;
+  // robot columns: joints of the chain
+  _Pragma("unroll") for (int j = 0; j < NB; j++) {
+    const bool member = live && joint_in_chain(j, rb);
+    const real dj = dlin[0] * tc[j][0] + dlin[1] * tc[j][1] + dlin[2] * tc[j][2] + eang[0] * tc[j][3] + eang[1] * tc[j][4] + eang[2] * tc[j][5];
+    J[j] = sel(member, rsign * dj, 0.0);
+  }
+  // cube columns: [dlin ; Rc^T eang]
+  _Pragma("unroll") for (int k = 0; k < 3; k++) {
+    J[12 + k] = sel(live && has_cube, dlin[k], 0.0);
+    J[15 + k] = sel(live && has_cube, CS.Rc[k] * eang[0] + CS.Rc[3 + k] * eang[1] + CS.Rc[6 + k] * eang[2], 0.0);
+  }
+  real vel = 0;
+  _Pragma("unroll") for (int j = 0; j < NB; j++) vel = fma(J[j], qd[j], vel);
+  _Pragma("unroll") for (int k = 0; k < 6; k++) vel = fma(J[12 + k], vc[k], vel);
+  D = sel(live, Dc, 0.0); ar = sel(live, -Bc * vel - kterm, 0.0);
+  // limit row over the top
+  _Pragma("unroll") for (int j = 0; j < NB; j++) J[j] = sel(is_lim, sel(j == jl, sgn, 0.0), J[j]);
+  D = sel(is_lim, fabs(sD), D); ar = sel(is_lim, al, ar);
+  rowcls = sel(is_lim, 0, sel(has_cube, 2, 1));
+}
+
+// the twist columns of the twelve joints about the cube's centre, from the world axes / anchors the collision pass left (LDS_WJ); the
+// gripper's six are posed only when the gripper is near something (stale LDS otherwise): `grip` = a contact of the list rides on them
+MCG_DEV void coop_twists(const PnpScratch ME, const real* cpos, bool grip, real (*tc)[6]) {
+  _Pragma("unroll") for (int j = 0; j < NB; j++) {
+    real ax[3], d[3], v[3];
+    _Pragma("unroll") for (int k = 0; k < 3; k++) { ax[k] = ME.ld(LDS_WJ + j * 6 + k); d[k] = ME.ld(LDS_WJ + j * 6 + 3 + k) - cpos[k]; }
+    cross(d, ax, v);
+    const bool ok = (j < 6) || grip;
+    _Pragma("unroll") for (int k = 0; k < 3; k++) { tc[j][k] = sel(ok, v[k], 0.0); tc[j][3 + k] = sel(ok, ax[k], 0.0); }
+  }
+}
+
 constexpr unsigned coop_row_mask(const Pattern& P, int i) { unsigned m = 0; for (int j = 0; j <= i; j++) m |= P.nz[i][j] ? (1u << j) : 0u; return m; }
 
 // One environment's coupled solve, by the 32 active lanes of the calling wave.  lds0 = slot 0 of lane 0 of the workgroup's array,
@@ -159,30 +232,23 @@ MCG_DEV void coop_solve(ModelPtr Pm, LdsPtr lds0, int e, LdsPtr ws, int ncon, Co
   CubeSys<PnpScratch> CS(ME, Cb, drs);          // (for its pair numbers only)
   CS.pm_bits = (unsigned long long)Pm;
   CS.derive(Pm);
-  // ---- which finger sides carry a contact (their gear / finger joint frames are posed), twist columns of the ten joints about the cube centre
-  bool side_any[2] = {false, false};
+  // ---- does a contact ride on the gripper's bodies (their joint frames are posed then); twist columns of the twelve joints about the cube centre
+  bool grip = false;
   unsigned sig = (unsigned)ncon;
   for (int c = 0; c < ncon; c++) {
-    const int type = (int)ME.ld(LDS_CON + c * CON_STRIDE + 15);
-    side_any[0] = side_any[0] || type == PAIR_PADR_CUBE || type == PAIR_TABLE_PADR || type == PAIR_FINR_CUBE;
-    side_any[1] = side_any[1] || type == PAIR_PADL_CUBE || type == PAIR_TABLE_PADL || type == PAIR_FINL_CUBE;
+    const int type = (int)ME.ld(LDS_CON + c * CON_STRIDE + CON_TYPE);
+    grip = grip || pair_robot_body(type) >= 6;
     sig = coop_sig_step(sig, type);
   }
   sig |= 0x80000000u;
-  unsigned guess[3]; bool have_guess;
+  unsigned guess[COOP_SETS]; bool have_guess;
   { const real p0 = ME.ld(XCH_ACT0), p1 = ME.ld(XCH_ACT1);
-    have_guess = MCG_COOP_GUESS && (unsigned)__double2hiint(p0) == sig;
-    guess[0] = (unsigned)__double2loint(p0); guess[1] = (unsigned)__double2hiint(p1); guess[2] = (unsigned)__double2loint(p1); }
-  unsigned fin[3] = {0u, 0u, 0u}; bool conv = false;
+    have_guess = MCG_COOP_GUESS && NSETS <= 3 && (unsigned)__double2hiint(p0) == sig;
+    guess[0] = (unsigned)__double2loint(p0); guess[1] = (unsigned)__double2hiint(p1); guess[2] = (unsigned)__double2loint(p1); guess[3] = 0u; }
+  unsigned fin[COOP_SETS] = {0u, 0u, 0u, 0u}; bool conv = false;
   COOP_COUNT(7, have_guess ? 1 : 0);
-  real tc[10][6];
-  _Pragma("unroll") for (int j = 0; j < 10; j++) {
-    real ax[3], d[3], v[3];
-    _Pragma("unroll") for (int k = 0; k < 3; k++) { ax[k] = ME.ld(LDS_WJ + j * 6 + k); d[k] = ME.ld(LDS_WJ + j * 6 + 3 + k) - Cb.pos[k]; }
-    cross(d, ax, v);
-    const bool ok = (j < 6) || side_any[(j - 6) >> 1];         // (a side without contacts: stale LDS)
-    _Pragma("unroll") for (int k = 0; k < 3; k++) { tc[j][k] = sel(ok, v[k], 0.0); tc[j][3 + k] = sel(ok, ax[k], 0.0); }
-  }
+  real tc[NB][6];
+  coop_twists(ME, Cb.pos, grip, tc);
   real qd[NB], vc[6];
   _Pragma("unroll") for (int j = 0; j < NB; j++) qd[j] = ME.ld(XCH_QD + j);
   _Pragma("unroll") for (int k = 0; k < 6; k++) vc[k] = Cb.vel[k];
@@ -195,63 +261,7 @@ MCG_DEV void coop_solve(ModelPtr Pm, LdsPtr lds0, int e, LdsPtr ws, int ncon, Co
   _Pragma("unroll") for (int s = 0; s < NSETS; s++) {
     _Pragma("unroll") for (int j = 0; j < COOP_NV; j++) J[s][j] = 0;
     Dr[s] = 0; aref[s] = 0;
-    if (s < nsets) {
-      const int r = PNP_LANES * s + L;
-      const bool is_lim = r < 10;
-      // limit row: J = sg e_j, D, aref from the robot wave
-      const int jl = sel(is_lim, r, 0);
-      const real sD = ME.ld(PUB_SD + jl), al = ME.ld(PUB_AREF + jl);
-      const real sgn = sel(sD > 0, 1.0, sel(sD < 0, -1.0, 0.0));
-      // contact row
-      const int rc = sel(is_lim, 0, r - 10);
-      const int c = sel(rc / 6 < MAXCON, rc / 6, MAXCON - 1), p = rc % 6;
-      const bool is_con = !is_lim && (rc / 6 < ncon);
-      const int b = LDS_CON + c * CON_STRIDE;
-      real lev[3], n[3], t1[3], t2[3];
-      _Pragma("unroll") for (int k = 0; k < 3; k++) { lev[k] = ME.ld(b + k) - Cb.pos[k]; n[k] = ME.ld(b + 3 + k); t1[k] = ME.ld(b + 6 + k); t2[k] = ME.ld(b + 9 + k); }
-      const real Dc = ME.ld(b + 13), kterm = ME.ld(b + 14), ftype = ME.ld(b + 15);
-      MCG_FENCE();                                                                 // the row's loads are issued together
-      const int type = sel(is_con, (int)ftype, 0);
-      const bool padc = type == PAIR_PADR_CUBE || type == PAIR_PADL_CUBE, finc = type >= PAIR_FINR_CUBE;
-      const bool link = type >= PAIR_TABLE_LINK0 && !finc, tabp = (type == PAIR_TABLE_PADR || type == PAIR_TABLE_PADL);
-      const bool has_cube = pair_has_cube(type);
-      const int side = sel((type == PAIR_PADL_CUBE || type == PAIR_TABLE_PADL || type == PAIR_FINL_CUBE), 1, 0);
-      const bool basec = type == PAIR_BASE_CUBE;                                   // gripper base (on link6) - cube: the arm's six joints
-      const bool finger = padc || (finc && !basec) || tabp;                        // the robot body is the finger body of `side`
-      const int lbody = sel(link, sel(type - PAIR_TABLE_LINK0 < 5, type - PAIR_TABLE_LINK0, 5), sel(finger || basec, 5, -1));      // last arm joint in the chain
-      const real rsign = sel(has_cube, -1.0, 1.0);                                 // robot geom is geom1 against the cube, geom2 against a static geom
-      real mu[3]; real Bc;
-      _Pragma("unroll") for (int k = 0; k < 3; k++)
-        mu[k] = sel(link, CS.mu_tl[k], sel(tabp, CS.mu_tp[k], sel(finc, CS.mu_mc[k], sel(padc, CS.mu_pc[k], CS.mu_tc[k]))));
-      Bc = sel(link, CS.B_tl, sel(tabp, CS.B_tp, sel(finc, CS.B_mc, sel(padc, CS.B_pc, CS.B_tc))));
-      const int kf = p >> 1;
-      const real m = sel((p & 1), -1.0, 1.0) * sel3(kf, mu[0], mu[1], mu[2]);
-      const bool absent = link && kf == 2;                                         // condim 3: no torsional pair of rows
-      real dlin[3], eang[3];
-      _Pragma("unroll") for (int k = 0; k < 3; k++) dlin[k] = n[k] + sel(kf == 0, m * t1[k], sel(kf == 1, m * t2[k], 0.0));
-      cross(lev, dlin, eang);
-      const real tau = sel(kf == 2, m, 0.0);
-      _Pragma("unroll") for (int k = 0; k < 3; k++) eang[k] = fma(tau, n[k], eang[k]);
-      const bool live = is_con && !absent;
-      // robot columns: joints of the chain
-      _Pragma("unroll") for (int j = 0; j < 10; j++) {
-        const bool member = live && ((j < 6) ? (j <= lbody) : (finger && ((j - 6) >> 1) == side));
-        const real dj = dlin[0] * tc[j][0] + dlin[1] * tc[j][1] + dlin[2] * tc[j][2] + eang[0] * tc[j][3] + eang[1] * tc[j][4] + eang[2] * tc[j][5];
-        J[s][j] = sel(member, rsign * dj, 0.0);
-      }
-      // cube columns: [dlin ; Rc^T eang]
-      _Pragma("unroll") for (int k = 0; k < 3; k++) {
-        J[s][12 + k] = sel(live && has_cube, dlin[k], 0.0);
-        J[s][15 + k] = sel(live && has_cube, CS.Rc[k] * eang[0] + CS.Rc[3 + k] * eang[1] + CS.Rc[6 + k] * eang[2], 0.0);
-      }
-      real vel = 0;
-      _Pragma("unroll") for (int j = 0; j < 10; j++) vel = fma(J[s][j], qd[j], vel);
-      _Pragma("unroll") for (int k = 0; k < 6; k++) vel = fma(J[s][12 + k], vc[k], vel);
-      Dr[s] = sel(live, Dc, 0.0); aref[s] = sel(live, -Bc * vel - kterm, 0.0);
-      // limit row over the top
-      _Pragma("unroll") for (int j = 0; j < 10; j++) J[s][j] = sel(is_lim, sel(j == jl, sgn, 0.0), J[s][j]);
-      Dr[s] = sel(is_lim, fabs(sD), Dr[s]); aref[s] = sel(is_lim, al, aref[s]);
-    }
+    if (s < nsets) { int cls; coop_build_row(ME, CS, Cb.pos, tc, qd, vc, PNP_LANES * s + L, ncon, J[s], Dr[s], aref[s], cls); (void)cls; }
   }
 
   MCG_TICK_PIN(Dr, NSETS); MCG_TICK_PIN(aref, NSETS);
@@ -497,7 +507,7 @@ MCG_DEV void coop_solve(ModelPtr Pm, LdsPtr lds0, int e, LdsPtr ws, int ncon, Co
   // ---- hand the accelerations back: robot part where the warm start was, cube part in the cube's warm-start slots
   if (L < NB) ME.st(PUB_WARM + L, al);
   else if (L < COOP_NV) ME.st(XCH_CB + 13 + (L - NB), al);
-  if (L == 0) { ME.st(XCH_ACT0, coop_pack(conv ? sig : 0u, fin[0])); ME.st(XCH_ACT1, coop_pack(fin[1], fin[2])); }
+  if (L == 0) { ME.st(XCH_ACT0, coop_pack((conv && NSETS <= 3) ? sig : 0u, fin[0])); ME.st(XCH_ACT1, coop_pack(fin[1], fin[2])); }      // (four sets do not fit the two slots: no set is carried)
   COOP_TICK(ST_CO_OUT);
 }
 
@@ -559,13 +569,12 @@ MCG_DEV void coop_solve_pair(ModelPtr Pm, LdsPtr lds0, LdsPtr wsw, int eA, int e
   CubeSys<PnpScratch> CS(ME, Cb, drs);
   CS.pm_bits = (unsigned long long)Pm;
   CS.derive(Pm);
-  bool side_any[2] = {false, false};
+  bool grip = false;
   unsigned sig = (unsigned)ncon;
   for (int c = 0; c < nconmax; c++) {
-    const int type = (int)ME.ld(LDS_CON + sel(c < ncon, c, 0) * CON_STRIDE + 15);
+    const int type = (int)ME.ld(LDS_CON + sel(c < ncon, c, 0) * CON_STRIDE + CON_TYPE);
     const bool in = c < ncon;
-    side_any[0] = side_any[0] || (in && (type == PAIR_PADR_CUBE || type == PAIR_TABLE_PADR || type == PAIR_FINR_CUBE));
-    side_any[1] = side_any[1] || (in && (type == PAIR_PADL_CUBE || type == PAIR_TABLE_PADL || type == PAIR_FINL_CUBE));
+    grip = grip || (in && pair_robot_body(type) >= 6);
     sig = sel(in, coop_sig_step(sig, type), sig);
   }
   sig |= 0x80000000u;
@@ -576,14 +585,8 @@ MCG_DEV void coop_solve_pair(ModelPtr Pm, LdsPtr lds0, LdsPtr wsw, int eA, int e
   unsigned fin[2] = {0u, 0u}; bool conv = false;
   static_assert(NSETS <= 2, "the pair solve carries two sets of rows");
   COOP_COUNT(7, __popcll(__ballot(hl == 0 && have && have_guess)));
-  real tc[10][6];
-  _Pragma("unroll") for (int j = 0; j < 10; j++) {
-    real ax[3], d[3], v[3];
-    _Pragma("unroll") for (int k = 0; k < 3; k++) { ax[k] = ME.ld(LDS_WJ + j * 6 + k); d[k] = ME.ld(LDS_WJ + j * 6 + 3 + k) - Cb.pos[k]; }
-    cross(d, ax, v);
-    const bool ok = (j < 6) || side_any[(j - 6) >> 1];
-    _Pragma("unroll") for (int k = 0; k < 3; k++) { tc[j][k] = sel(ok, v[k], 0.0); tc[j][3 + k] = sel(ok, ax[k], 0.0); }
-  }
+  real tc[NB][6];
+  coop_twists(ME, Cb.pos, grip, tc);
   real qd[NB], vc[6];
   _Pragma("unroll") for (int j = 0; j < NB; j++) qd[j] = ME.ld(XCH_QD + j);
   _Pragma("unroll") for (int k = 0; k < 6; k++) vc[k] = Cb.vel[k];
@@ -599,58 +602,10 @@ MCG_DEV void coop_solve_pair(ModelPtr Pm, LdsPtr lds0, LdsPtr wsw, int eA, int e
     _Pragma("unroll") for (int j = 0; j < NV; j++) J[s][j] = 0;
     aref[s] = 0; lv[s] = false;
     if (s < nsets) {
-      const int r = PNP_LANES * s + hl;
-      const bool is_lim = r < 10;
-      const int jl = sel(is_lim, r, 0);
-      const real sD = ME.ld(PUB_SD + jl), al = ME.ld(PUB_AREF + jl);
-      const real sgn = sel(sD > 0, 1.0, sel(sD < 0, -1.0, 0.0));
-      const int rc = sel(is_lim, 0, r - 10);
-      const int c = sel(rc / 6 < MAXCON, rc / 6, MAXCON - 1), p = rc % 6;
-      const bool is_con = !is_lim && (rc / 6 < ncon);
-      const int b = LDS_CON + c * CON_STRIDE;
-      real lev[3], n[3], t1[3], t2[3];
-      _Pragma("unroll") for (int k = 0; k < 3; k++) { lev[k] = ME.ld(b + k) - Cb.pos[k]; n[k] = ME.ld(b + 3 + k); t1[k] = ME.ld(b + 6 + k); t2[k] = ME.ld(b + 9 + k); }
-      const real Dc = ME.ld(b + 13), kterm = ME.ld(b + 14), ftype = ME.ld(b + 15);
-      MCG_FENCE();
-      const int type = sel(is_con, (int)ftype, 0);
-      const bool padc = type == PAIR_PADR_CUBE || type == PAIR_PADL_CUBE, finc = type >= PAIR_FINR_CUBE;
-      const bool link = type >= PAIR_TABLE_LINK0 && !finc, tabp = (type == PAIR_TABLE_PADR || type == PAIR_TABLE_PADL);
-      const bool has_cube = pair_has_cube(type);
-      const int side = sel((type == PAIR_PADL_CUBE || type == PAIR_TABLE_PADL || type == PAIR_FINL_CUBE), 1, 0);
-      const bool basec = type == PAIR_BASE_CUBE;
-      const bool finger = padc || (finc && !basec) || tabp;
-      const int lbody = sel(link, sel(type - PAIR_TABLE_LINK0 < 5, type - PAIR_TABLE_LINK0, 5), sel(finger || basec, 5, -1));
-      const real rsign = sel(has_cube, -1.0, 1.0);
-      real mu[3]; real Bc;
-      _Pragma("unroll") for (int k = 0; k < 3; k++)
-        mu[k] = sel(link, CS.mu_tl[k], sel(tabp, CS.mu_tp[k], sel(finc, CS.mu_mc[k], sel(padc, CS.mu_pc[k], CS.mu_tc[k]))));
-      Bc = sel(link, CS.B_tl, sel(tabp, CS.B_tp, sel(finc, CS.B_mc, sel(padc, CS.B_pc, CS.B_tc))));
-      const int kf = p >> 1;
-      const real m = sel((p & 1), -1.0, 1.0) * sel3(kf, mu[0], mu[1], mu[2]);
-      const bool absent = link && kf == 2;
-      real dlin[3], eang[3];
-      _Pragma("unroll") for (int k = 0; k < 3; k++) dlin[k] = n[k] + sel(kf == 0, m * t1[k], sel(kf == 1, m * t2[k], 0.0));
-      cross(lev, dlin, eang);
-      const real tau = sel(kf == 2, m, 0.0);
-      _Pragma("unroll") for (int k = 0; k < 3; k++) eang[k] = fma(tau, n[k], eang[k]);
-      const bool live = is_con && !absent;
-      _Pragma("unroll") for (int j = 0; j < 10; j++) {
-        const bool member = live && ((j < 6) ? (j <= lbody) : (finger && ((j - 6) >> 1) == side));
-        const real dj = dlin[0] * tc[j][0] + dlin[1] * tc[j][1] + dlin[2] * tc[j][2] + eang[0] * tc[j][3] + eang[1] * tc[j][4] + eang[2] * tc[j][5];
-        J[s][j] = sel(member, rsign * dj, 0.0);
-      }
-      _Pragma("unroll") for (int k = 0; k < 3; k++) {
-        J[s][12 + k] = sel(live && has_cube, dlin[k], 0.0);
-        J[s][15 + k] = sel(live && has_cube, CS.Rc[k] * eang[0] + CS.Rc[3 + k] * eang[1] + CS.Rc[6 + k] * eang[2], 0.0);
-      }
-      real vel = 0;
-      _Pragma("unroll") for (int j = 0; j < 10; j++) vel = fma(J[s][j], qd[j], vel);
-      _Pragma("unroll") for (int k = 0; k < 6; k++) vel = fma(J[s][12 + k], vc[k], vel);
-      real D = sel(live, Dc, 0.0), ar = sel(live, -Bc * vel - kterm, 0.0);
-      _Pragma("unroll") for (int j = 0; j < 10; j++) J[s][j] = sel(is_lim, sel(j == jl, sgn, 0.0), J[s][j]);
-      D = sel(is_lim, fabs(sD), D); ar = sel(is_lim, al, ar);
+      real D, ar; int cls;
+      coop_build_row(ME, CS, Cb.pos, tc, qd, vc, PNP_LANES * s + hl, ncon, J[s], D, ar, cls);
 #ifdef MCG_STAGE_CLOCKS
-      rowcls[s] = sel(is_lim, 0, sel(has_cube, 2, 1));
+      rowcls[s] = cls;
 #endif
       const real sd = sel(have && D > 0, sqrt(D), 0.0);            // (an idle half has no rows)
       _Pragma("unroll") for (int j = 0; j < NV; j++) J[s][j] *= sd;

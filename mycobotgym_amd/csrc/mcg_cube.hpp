@@ -1,49 +1,66 @@
-// mcg_cube.hpp -- the free cube of PickAndPlace: the collision pass of the whole scene, the cube's pyramidal contact rows, its own
-// (cube-alone) primal Newton solve, quaternion integration.  One env per lane.
+// mcg_cube.hpp -- the free cube of PickAndPlace: the lane-parallel part of the collision pass (the primitive geoms and the broad phase of
+// the mesh geoms), the cube's pyramidal contact rows, its own (cube-alone) primal Newton solve, quaternion integration.  One env per lane.
 //
 // Replaces for this scene what mujoco.mj_step does for the `object0` body and its contacts
-// (/root/reference/mycobotgym/envs/assets/mycobot280_main.xml:81,87,105-175,195-199,222-225,260-265; call sites
-// mycobot.py:170,193): mj_collision (P4) over the primitive geoms and, on support polytopes, the arm-side, finger-link and
-// gripper-base meshes (staged: DESIGN.md section 8); mj_makeConstraint / mj_projectConstraint for condim-4 pyramidal
-// contacts (P5); for an environment in which nothing touches the robot, the cube's part of mj_fwdConstraint (P9); mj_Euler for a free
-// joint (P10).  An environment in which a contact reaches the robot is solved by mcg_coop.hpp (one environment per wave).
+// (/root/reference/mycobotgym/envs/assets/mycobot280_main.xml:81,87,105-247,260-265; call sites mycobot.py:170,193): mj_collision (P4)
+// over the primitive geoms here and over the mesh geoms' collision polytopes in mcg_mesh.hpp (one pair per wave, lane = vertex / face /
+// edge); mj_makeConstraint / mj_projectConstraint for the pyramidal contacts (P5); for an environment in which nothing touches the robot,
+// the cube's part of mj_fwdConstraint (P9); mj_Euler for a free joint (P10).  An environment in which a contact reaches the robot is
+// solved by mcg_coop.hpp (one environment per 32 lanes).
 //
-// Contacts of one env live in LDS (runtime-indexed lists cannot live in registers): 16 slots per contact.
+// Contacts of one env live in LDS (runtime-indexed lists cannot live in registers): 10 slots per contact.
 #pragma once
 
 #include "mcg_dynamics.hpp"
 
 namespace mcg {
 
-constexpr int MAXCON = 12;           // contacts kept per env (the oracle is built with the same cap)
-constexpr int CON_STRIDE = 16;       // pos[3] n[3] t1[3] t2[3] dist D kterm type
+constexpr int MAXCON = 16;           // list ENTRIES kept per env (a mesh's twin geoms: one entry of double weight); the oracle cuts its list at the
+                                     // same entry (mco_model.maxentry).  MuJoCo has no cap; mcg_counters.contacts_dropped counts what this one cuts
+constexpr int CON_STRIDE = 10;       // pos[3] n[3] dist D kterm type   (the tangents are re-derived from n: make_frame)
+constexpr int CON_DIST = 6, CON_D = 7, CON_KTERM = 8, CON_TYPE = 9;
 constexpr int PNP_LANES = 32;        // envs per wave in the PickAndPlace kernels: twice the LDS per env; a wave costs the
                                      // same with 32 or 64 active lanes (measured), and 8192 envs then cover all 256 CUs
+constexpr int ROW_SLOTS = 144;       // the row area: line-search rows of the cube-alone solve, cooperative workspaces, parked inputs (mcg_coop.hpp)
+constexpr int NJW = 12;              // joints whose world axis + anchor are kept for the contact rows: all twelve
 constexpr int LDS_CON = LDS_SLOTS;
 constexpr int LDS_POLY = LDS_CON + MAXCON * CON_STRIDE;     // two clip polygons of 8 x 2 in the first 32 slots (a quadrilateral clipped by
                                                             // four half-planes has at most 8 vertices); the other 32: exchange slots of the four-wave kernel
 constexpr int LDS_ROW = LDS_POLY + 64;                      // per pyramid row: r0, dr (line search)
-constexpr int LDS_ACT = LDS_ROW + MAXCON * 12;              // per contact: active-row bit mask (as a double)
-constexpr int LDS_WJ = LDS_ACT + MAXCON;                    // world axis + anchor of the 10 joints in the pads' chains
-constexpr int PNP_SLOTS = LDS_WJ + 60;
+constexpr int LDS_ACT = LDS_ROW + ROW_SLOTS;                // per contact: active-row bit mask (as a double)
+constexpr int LDS_WJ = LDS_ACT + MAXCON;                    // world axis + anchor of the twelve joints
+constexpr int PNP_SLOTS = LDS_WJ + 6 * NJW;
 typedef LaneScratchT<PNP_LANES> PnpScratch;
 
-// rows of mcg_model.contact_par / contact_diag.  The ground plane carries the table's parameters (both are default geoms).
-// TABLE_PAD*: a finger pad on the table top or on the ground (mycobot280_main.xml:81,87-88,195-199,222-225): rows in the robot's
-// dofs only; they route the sub-step through the coupled solver like the pad-cube contacts do.
-// TABLE_LINK0 + p: the support polytope of arm-side mesh p (link1..6, flange, gripper_base; it rides on arm body min(p, 5)) on the
-// table or the ground: condim 3 (four pyramid rows), rows in the arm dofs up to that body only (first stage).
-enum { PAIR_TABLE_CUBE = 0, PAIR_PADR_CUBE = 1, PAIR_PADL_CUBE = 2, PAIR_TABLE_PADR = 3, PAIR_TABLE_PADL = 4, PAIR_TABLE_LINK0 = 5,
-       PAIR_FINR_CUBE = PAIR_TABLE_LINK0 + 8, PAIR_FINL_CUBE = PAIR_FINR_CUBE + 1,      // finger-link mesh - cube: bodies of pad-cube
-       PAIR_BASE_CUBE = PAIR_FINL_CUBE + 1,                                              // gripper-base mesh (rides on link6) - cube
-       PAR_FIN_CUBE = 6 };                                                               // ... with their own row of contact_par
-constexpr int ALONE_MAX_LIST = 8;   // four-wave kernel: list positions the cube wave's own solve may use in a lane whose row-area column also holds
-                                    // the parked inputs of a cooperative robot-only solve (mcg_coop.hpp)
-// the 13 canonical directions of a polytope's frame (axes, face diagonals, space diagonals): extra separating axes of the table test
-constexpr int MCG_DIR13[13][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}, {1, 1, 0}, {1, -1, 0}, {1, 0, 1}, {1, 0, -1}, {0, 1, 1}, {0, 1, -1}, {1, 1, 1}, {1, 1, -1}, {1, -1, 1}, {1, -1, -1}};
-// a contact that involves the cube (twist space in the coupled solve) / its class there: 0 table, 1 right finger body, 2 left
-MCG_DEV bool pair_has_cube(int type) { return type < PAIR_TABLE_PADR || type >= PAIR_FINR_CUBE; }
-MCG_DEV int pair_class(int type) { return (type == PAIR_PADR_CUBE || type == PAIR_FINR_CUBE) ? 1 : ((type == PAIR_PADL_CUBE || type == PAIR_FINL_CUBE) ? 2 : 0); }
+// Pair types (slot CON_TYPE of a list entry; rows of mcg_model.pair_tran).  The ground plane carries the table's parameters (both are
+// default geoms).  NMESH collision polytopes (mycobotgym_amd/model/polytope.py: MESH_NAMES): links 1-6, flange, gripper base, right gear /
+// finger link, left gear / finger link, right / left hinge link; polytope m rides on robot body mesh_body(m).
+//   0 static-cube | 1, 2 right / left pad-cube | 3, 4 static-right / left pad | 5 + m static-mesh m (condim 3) | 19 + m mesh m-cube
+constexpr int NMESH = 14;
+enum { PAIR_TABLE_CUBE = 0, PAIR_PADR_CUBE = 1, PAIR_PADL_CUBE = 2, PAIR_TABLE_PADR = 3, PAIR_TABLE_PADL = 4, PAIR_STATIC_MESH0 = 5,
+       PAIR_MESH0_CUBE = PAIR_STATIC_MESH0 + NMESH, NPAIR = PAIR_MESH0_CUBE + NMESH,
+       PAR_TABLE_MESH = 5, PAR_MESH_CUBE = 6 };                  // rows of mcg_model.contact_par of the two mesh classes
+constexpr int ALONE_MAX_LIST = 8;   // list positions the cube wave's own solve may use (12 row slots each in the first 96 of the row area)
+MCG_DEV bool pair_has_cube(int type) { return type < PAIR_TABLE_PADR || type >= PAIR_MESH0_CUBE; }
+MCG_DEV bool pair_mesh_static(int type) { return type >= PAIR_STATIC_MESH0 && type < PAIR_MESH0_CUBE; }
+MCG_DEV bool pair_mesh_cube(int type) { return type >= PAIR_MESH0_CUBE; }
+MCG_DEV int mesh_body(int m) { return m < 6 ? m : (m < 8 ? 5 : m - 2); }
+// the robot body of a pair (-1: none): pads ride on the finger links (bodies 7, 9)
+MCG_DEV int pair_robot_body(int type) {
+  const int m = type >= PAIR_MESH0_CUBE ? type - PAIR_MESH0_CUBE : type - PAIR_STATIC_MESH0;
+  return type == PAIR_TABLE_CUBE ? -1 : ((type == PAIR_PADR_CUBE || type == PAIR_TABLE_PADR) ? 7 : ((type == PAIR_PADL_CUBE || type == PAIR_TABLE_PADL) ? 9 : mesh_body(m)));
+}
+// joint j in the chain of robot body rb (the arm's six, then gear / finger right, gear / finger left, hinge right, hinge left)
+MCG_DEV bool joint_in_chain(int j, int rb) {
+  return rb >= 0 && (j < 6 ? j <= (rb < 5 ? rb : 5) : (j == 6 ? (rb == 6 || rb == 7) : (j == 8 ? (rb == 8 || rb == 9) : j == rb)));
+}
+
+// Row area between barriers S1 and S2 (its solves run after S2), columns of every lane: what the mesh phase (mcg_mesh.hpp) reads
+constexpr int MP_SN = LDS_ROW + 96, MP_CS = MP_SN + NB;          // sin / cos of AXS[i] q[i] (the M wave parks them)
+constexpr int MP_CUBE = MP_CS + NB;                              // the cube's position and (normalised) quaternion
+constexpr int MP_MASK = MP_CUBE + 7;                             // candidate pairs of the broad phases: M wave, RNE wave, cube wave (bit 3 m + o; o: ground, table, cube)
+constexpr int MP_NCON = MP_MASK + 3, MP_DROP = MP_NCON + 1;     // the list's length (the mesh phase appends); contacts the cap cut there
+static_assert(MP_DROP + 1 <= LDS_ROW + ROW_SLOTS, "mesh-phase slots");
 
 struct Cube {
   real pos[3], quat[4], vel[6], warm[6];     // vel = world linear velocity, body-frame angular velocity (MuJoCo free joint)
@@ -56,8 +73,8 @@ MCG_DEV void make_frame(const real* n, real* t1, real* t2) {
   real tmp[3] = {0.0, usey ? 1.0 : 0.0, usey ? 0.0 : 1.0};
   const real d = dot3(n, tmp);
   _Pragma("unroll") for (int k = 0; k < 3; k++) t1[k] = tmp[k] - d * n[k];
-  const real l = sqrt(dot3(t1, t1));
-  _Pragma("unroll") for (int k = 0; k < 3; k++) t1[k] /= l;
+  const real il = 1.0 / sqrt(dot3(t1, t1));
+  _Pragma("unroll") for (int k = 0; k < 3; k++) t1[k] *= il;
   cross(n, t1, t2);
 }
 
@@ -65,22 +82,16 @@ template <class LS>
 struct ContactList {
   const LS S;
   int n;              // entries stored
-  int ndrop = 0;      // contacts the cap of MAXCON cut off (as the oracle counts them)
-  int ncap = 0;       // contacts as the oracle (and MuJoCo) counts them: `mult` identical colliding geoms give `mult` identical contacts,
-                      // stored here as ONE entry whose rows carry `mult` times the weight (the same cost function); the cap of MAXCON
-                      // contacts cuts the list where the oracle's cuts it
-  MCG_DEV void add(const real* pos, const real* normal, real dist, int type, int mult = 1) {
-    const int take = sel(mult < MAXCON - ncap, mult, MAXCON - ncap);
-    const bool ok = (dist < 0) && (take > 0);
+  int ndrop = 0;      // contacts the cap of MAXCON entries cut off
+  MCG_DEV void add(const real* pos, const real* normal, real dist, int type) {
+    const bool hit = dist < 0, ok = hit && n < MAXCON;
     if (ok) {                           // plain LDS stores of live registers (no value is merged across this branch)
       const int b = LDS_CON + n * CON_STRIDE;
-      real t1[3], t2[3];
-      make_frame(normal, t1, t2);
-      _Pragma("unroll") for (int k = 0; k < 3; k++) { S.st(b + k, pos[k]); S.st(b + 3 + k, normal[k]); S.st(b + 6 + k, t1[k]); S.st(b + 9 + k, t2[k]); }
-      S.st(b + 12, dist); S.st(b + 13, (real)take); S.st(b + 15, (real)type);       // slot 13: multiplicity until prepare() turns it into D
+      _Pragma("unroll") for (int k = 0; k < 3; k++) { S.st(b + k, pos[k]); S.st(b + 3 + k, normal[k]); }
+      S.st(b + CON_DIST, dist); S.st(b + CON_D, 1.0); S.st(b + CON_TYPE, (real)type);       // slot CON_D: multiplicity until the solver numbers turn it into D
     }
-    n += sel(ok, 1, 0); ncap += sel(ok, take, 0);
-    ndrop += sel(dist < 0, mult - sel(take > 0, take, 0), 0);
+    n += sel(ok, 1, 0);
+    ndrop += sel(hit && !ok, 1, 0);
   }
 };
 
@@ -104,7 +115,7 @@ MCG_DEV void ground_box(ContactList<LS>& CL, const real* pb, const real* Rb, con
 static constexpr real EDGE_MIN_SIN = 1e-6;      // edges closer to parallel than this make no edge-edge axis: the face axes cover them
 template <class LS>
 MCG_DEV void box_box(ContactList<LS>& CL, bool live, const real* pa, const real* Ra, const real* ha,
-                     const real* pb, const real* Rb, const real* hb, int type, int mult = 1) {
+                     const real* pb, const real* Rb, const real* hb, int type) {
   const LS& S = CL.S;
   real A[3][3], B[3][3], p[3] = {pb[0] - pa[0], pb[1] - pa[1], pb[2] - pa[2]};
   _Pragma("unroll") for (int k = 0; k < 3; k++) for (int r = 0; r < 3; r++) { A[k][r] = Ra[3*r + k]; B[k][r] = Rb[3*r + k]; }
@@ -160,7 +171,7 @@ MCG_DEV void box_box(ContactList<LS>& CL, bool live, const real* pa, const real*
     const real s = dd <= 1e-12 ? 0.0 : (q1 + uaub*q2) / dd, t = dd <= 1e-12 ? 0.0 : (uaub*q1 + q2) / dd;
     real pos[3];
     _Pragma("unroll") for (int k = 0; k < 3; k++) pos[k] = 0.5 * ((ea[k] + s*Ai[k]) + (eb[k] + t*Bj[k]));
-    CL.add(pos, normal, (hit && code >= 6) ? best : 1.0, type, mult);
+    CL.add(pos, normal, (hit && code >= 6) ? best : 1.0, type);
   }
   if (!__any(hit && code < 6)) return;
 
@@ -230,7 +241,7 @@ MCG_DEV void box_box(ContactList<LS>& CL, bool live, const real* pa, const real*
     real pos[3];
     _Pragma("unroll") for (int k = 0; k < 3; k++) pos[k] = pr[k] + pt[k] + 0.5*depth*n2[k];
     const bool take = on && (depth > 0);
-    CL.add(pos, normal, take ? -depth : 1.0, type, mult);
+    CL.add(pos, normal, take ? -depth : 1.0, type);
     kept += sel(take, 1, 0);
   }
 }
@@ -244,7 +255,8 @@ template <class LS>
 MCG_DEV void cube_rows(const LS& S, int c, const real* Rc, const real* cpos, CubeRows& R) {
   const int b = LDS_CON + c * CON_STRIDE;
   real pos[3], n[3], t1[3], t2[3], arm[3], x[3];
-  _Pragma("unroll") for (int k = 0; k < 3; k++) { pos[k] = S.ld(b + k); n[k] = S.ld(b + 3 + k); t1[k] = S.ld(b + 6 + k); t2[k] = S.ld(b + 9 + k); arm[k] = pos[k] - cpos[k]; }
+  _Pragma("unroll") for (int k = 0; k < 3; k++) { pos[k] = S.ld(b + k); n[k] = S.ld(b + 3 + k); arm[k] = pos[k] - cpos[k]; }
+  make_frame(n, t1, t2);
   auto fill = [&](const real* d, real* J) {
     cross(arm, d, x);
     _Pragma("unroll") for (int k = 0; k < 3; k++) { J[k] = d[k]; J[3 + k] = Rc[k]*x[0] + Rc[3 + k]*x[1] + Rc[6 + k]*x[2]; }
@@ -260,206 +272,131 @@ MCG_DEV void pyramid_row(const CubeRows& R, int r, const real* mu, real* j) {
   _Pragma("unroll") for (int d = 0; d < 6; d++) { const real jk = sel3(k, R.J1[d], R.J2[d], R.Jt[d]); j[d] = R.Jn[d] + m * jk; }
 }
 
-// Arm-side mesh geoms (support polytopes) against the ground plane and the table, body by body as the chain is walked: the oracle's
-// rule (mco_collision.c: plane_polytope / box_polytope) -- separating-axis test over the table's face axes, ONE contact at the
-// deepest vertex along the face of least penetration; the deepest vertex below z = 0 for the ground.  Broad phase: the lowest
-// point of the vertices' bounding box in the body frame.
-#ifndef MESH_BATCH
-#define MESH_BATCH 13       // vertices per batch of scalar loads: two dependent round trips per mesh (4 per batch were seven; A/B of 4 / 7 / 13 / 26 in profiles/r03/ab_mesh_vertex_batch.log)
-#endif
-template <class SINK>
-MCG_DEV void mesh_table_ground(ModelPtr Pm, int pi, const real* Rio, const real* pio, const real* tp, const real* th, SINK& CL) {
-    ModelPtr H = launder(Pm);
-    real bx[6]; ldc<6>(H->link_hull_box[pi], bx);
-    const real cz = pio[2] + Rio[6] * bx[0] + Rio[7] * bx[1] + Rio[8] * bx[2];
-    const real ez = fabs(Rio[6]) * bx[3] + fabs(Rio[7]) * bx[4] + fabs(Rio[8]) * bx[5];
-    if (!__any(cz - ez < tp[2] + th[2])) return;                      // wave-uniform: nothing of it reaches the table top's height
-    real lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY}, wz[3] = {0, 0, 0};
-    // four vertices per batch of scalar loads: a wave alone on its SIMD pays every s_load round trip in full, and 26 dependent
-    // ones per mesh were most of this pass under a policy that keeps the arm near the table (the last batch repeats vertex 25:
-    // a repeated vertex changes neither the extremes nor the first lowest one)
-    for (int kb = 0; kb < 26; kb += MESH_BATCH) {
-      real v4[MESH_BATCH][3];
-      { ModelPtr Hb = launder(Pm);
-        _Pragma("unroll") for (int u = 0; u < MESH_BATCH; u++) { const int k = sel(kb + u < 26, kb + u, 25); ldc<3>(Hb->link_hull[pi][k], v4[u]); } }
-      _Pragma("unroll") for (int u = 0; u < MESH_BATCH; u++) {
-        real w[3];
-        _Pragma("unroll") for (int r = 0; r < 3; r++) w[r] = pio[r] + Rio[3*r]*v4[u][0] + Rio[3*r+1]*v4[u][1] + Rio[3*r+2]*v4[u][2];
-        const bool lower = w[2] < lo[2];                               // first occurrence of the minimum, as the oracle keeps it
-        _Pragma("unroll") for (int r = 0; r < 3; r++) { wz[r] = sel(lower, w[r], wz[r]); lo[r] = fmin(lo[r], w[r]); hi[r] = fmax(hi[r], w[r]); }
-      }
+// ---- broad phase of the mesh geoms (lane = env).  Every mesh carries the bounding box of its collision polytope in the frame of the body
+// it rides on (mcg_model.mesh_box: centre, half extents).  All three tests are CONSERVATIVE -- the box contains the polytope, a subset of
+// the separating axes is tried -- so a pair they reject is separated; a pair they pass goes to the exact narrow phase (mcg_mesh.hpp),
+// which decides.  Returns the pair's candidate bits: 1 ground, 2 table, 4 cube.
+MCG_DEV int mesh_broad(ModelPtr Pm, int m, const real* R, const real* p, const real* tp, const real* th, bool statics, bool cube, const real* cpos, real crad) {
+  ModelPtr H = launder(Pm);
+  real bx[6]; ldc<6>(H->mesh_box[m], bx);
+  real c[3], e[3];                                                      // the box's centre; its half extents along the world axes
+  _Pragma("unroll") for (int r = 0; r < 3; r++) {
+    c[r] = p[r] + R[3*r]*bx[0] + R[3*r+1]*bx[1] + R[3*r+2]*bx[2];
+    e[r] = fabs(R[3*r])*bx[3] + fabs(R[3*r+1])*bx[4] + fabs(R[3*r+2])*bx[5];
+  }
+  int bits = 0;
+  if (statics) {
+    bits |= sel(c[2] - e[2] < 0, 1, 0);                                  // ground: the box's lowest point
+    bool near = true;                                                    // table: its three face axes, then the box's own three
+    _Pragma("unroll") for (int r = 0; r < 3; r++) near = near && !(fabs(c[r] - tp[r]) > th[r] + e[r]);
+    _Pragma("unroll") for (int k = 0; k < 3; k++) {
+      const real rel = R[k]*(c[0] - tp[0]) + R[3 + k]*(c[1] - tp[1]) + R[6 + k]*(c[2] - tp[2]);
+      const real rad = fabs(R[k])*th[0] + fabs(R[3 + k])*th[1] + fabs(R[6 + k])*th[2];
+      near = near && !(fabs(rel) > bx[3 + k] + rad);
     }
-    const int mult = (int)H->link_mult;
-    {   // ground plane z = 0
-      const real n[3] = {0, 0, 1};
-      const real pos[3] = {wz[0], wz[1], wz[2] - 0.5 * lo[2]};
-      CL.add(pos, n, lo[2] < 0 ? lo[2] : 1.0, PAIR_TABLE_LINK0 + pi, mult);
-    }
-    {   // table (static, axis-aligned): faces +-x, +-y, +-z
-      bool sep = false; real depth = INFINITY; int axis = 0; bool plus = true;
-      _Pragma("unroll") for (int a = 0; a < 3; a++) {
-        const real l = lo[a] - tp[a], hgh = hi[a] - tp[a];
-        sep = sep || (l > th[a]) || (hgh < -th[a]);
-        const real dp = th[a] - l, dn = hgh + th[a];
-        const bool tp_ = dp < depth;                                   // selects, no lane-divergent branch (compiler hazard, mcg_dynamics.hpp)
-        depth = sel(tp_, dp, depth); axis = sel(tp_, a, axis); plus = sel(tp_, true, plus);
-        const bool tn_ = dn < depth;
-        depth = sel(tn_, dn, depth); axis = sel(tn_, a, axis); plus = sel(tn_, false, plus);
-      }
-      // ... or one of the polytope's own 13 canonical axes separates (mcg_model.link_ext): without them a link diagonally off an
-      // edge of the table counts as touching whenever its table-aligned extent overlaps the table
-      if (__any(!sep)) {
-        real ext[26]; ldc<26>(&H->link_ext[pi][0][0], ext);
-        static_for<13>([&](auto Kk) { constexpr int k = Kk;
-          real w[3];
-          _Pragma("unroll") for (int r = 0; r < 3; r++) w[r] = MCG_DIR13[k][0] * Rio[3*r] + MCG_DIR13[k][1] * Rio[3*r+1] + MCG_DIR13[k][2] * Rio[3*r+2];
-          const real rel = (pio[0] - tp[0]) * w[0] + (pio[1] - tp[1]) * w[1] + (pio[2] - tp[2]) * w[2];
-          const real rad = th[0] * fabs(w[0]) + th[1] * fabs(w[1]) + th[2] * fabs(w[2]);
-          sep = sep || (rel + ext[2*k] > rad) || (rel + ext[2*k + 1] < -rad); });
-      }
-      const bool topface = (axis == 2) && plus;
-      real wd[3] = {wz[0], wz[1], wz[2]};
-      if (__any(!sep && !topface)) {                                   // rare: a side or bottom face wins: find that face's deepest vertex
-        real best = INFINITY;
-        for (int k = 0; k < 26; k++) {
-          real v[3]; ldc<3>(H->link_hull[pi][k], v);
-          real w[3];
-          _Pragma("unroll") for (int r = 0; r < 3; r++) w[r] = pio[r] + Rio[3*r]*v[0] + Rio[3*r+1]*v[1] + Rio[3*r+2]*v[2];
-          const real c = sel3(axis, w[0], w[1], w[2]);
-          const real key = plus ? c : -c;                              // face +a: the smallest coordinate; face -a: the largest
-          const bool better = !topface && key < best;
-          best = sel(better, key, best);
-          _Pragma("unroll") for (int r = 0; r < 3; r++) wd[r] = sel(better, w[r], wd[r]);
-        }
-      }
-      real n[3] = {0, 0, 0};
-      _Pragma("unroll") for (int r = 0; r < 3; r++) n[r] = (r == axis) ? (plus ? 1.0 : -1.0) : 0.0;
-      const real pos[3] = {wd[0] + 0.5 * depth * n[0], wd[1] + 0.5 * depth * n[1], wd[2] + 0.5 * depth * n[2]};
-      CL.add(pos, n, sep ? 1.0 : -depth, PAIR_TABLE_LINK0 + pi, mult);
-    }
+    bits |= sel(near, 2, 0);
+  }
+  if (cube) {                                                            // the cube's bounding sphere against the box, in the box's frame
+    bool near = true;
+    _Pragma("unroll") for (int k = 0; k < 3; k++) near = near && !(fabs(R[k]*(cpos[0] - c[0]) + R[3 + k]*(cpos[1] - c[1]) + R[6 + k]*(cpos[2] - c[2])) > bx[3 + k] + crad);
+    bits |= sel(near, 4, 0);
+  }
+  return bits;
 }
 
-// ---- the arm-side mesh pass on the M / RNE waves of the four-wave kernel (round 3).  The cube wave's collision pass was the longest
-// stretch of a PickAndPlace-IK sub-step (92 k of ~215 k clocks, half of it the eight arm meshes against the table: stage clocks in
-// profiles/r03/stage_clocks_collision_split.log) while the M and RNE waves, done after ~10 k, waited for it at S2.  They now walk the arm
-// chain themselves (from the sines / cosines they hold anyway) and test four meshes each -- M: links 1-4, RNE: links 5, 6, flange,
-// gripper base -- leaving their contacts in a staging area (the row area, unused between S1 and S2); after barrier S1b the cube wave
-// puts them IN FRONT of its own entries (the oracle's pair order) and applies the cap of MAXCON to the merged list (CubeSys::merge_staged).
-constexpr int STAGE_STRIDE = 8, STAGE_A = LDS_ROW, STAGE_B = LDS_ROW + 8 * STAGE_STRIDE, STAGE_NA = LDS_ROW + 16 * STAGE_STRIDE, STAGE_NB = STAGE_NA + 1;
-static_assert(STAGE_NB + 1 <= LDS_ROW + MAXCON * 12, "staging area");
-template <class LS>
-struct MeshStage {        // pos[3] normal[3] dist type; a wave's four meshes give at most eight entries (ground and table each)
-  const LS S; int base; int n = 0;
-  MCG_DEV void add(const real* pos, const real* normal, real dist, int type, int) {
-    const bool ok = dist < 0;
-    if (ok) {
-      const int b = base + n * STAGE_STRIDE;
-      _Pragma("unroll") for (int k = 0; k < 3; k++) { S.st(b + k, pos[k]); S.st(b + 3 + k, normal[k]); }
-      S.st(b + 6, dist); S.st(b + 7, (real)type);
-    }
-    n += sel(ok, 1, 0);
-  }
-};
+// ---- the arm meshes' broad phase against the table and the ground, on the M / RNE waves of the four-wave kernel (they hold the arm's
+// sines / cosines anyway and are done long before the cube wave: round 3 had them run the whole 16-axis test here, ~27 k clocks; the
+// exact narrow phase now runs one pair per wave behind this filter).  M: meshes 0-3, RNE: 4-7 (links 5, 6, flange, gripper base).
 template <int P0, int P1, class LS>
-MCG_DEV void arm_mesh_stage(ModelPtr Pm, const LS S, const real* sn, const real* cs, int base, int count_slot) {
+MCG_DEV void arm_broad_stage(ModelPtr Pm, const LS S, const real* sn, const real* cs, int mask_slot) {
   ModelPtr Q = launder(Pm);
   real tp[3], th[3]; ldc<3>(Q->table_pos, tp); ldc<3>(Q->table_half, th);
   real R[9], p[3];
   _Pragma("unroll") for (int k = 0; k < 9; k++) R[k] = Q->base_mat[k];
   _Pragma("unroll") for (int k = 0; k < 3; k++) p[k] = Q->base_pos[k];
-  MeshStage<LS> ST{S, base};
-  constexpr int LASTB = P1 - 1 < 5 ? P1 - 1 : 5;                 // polytope p rides on arm body min(p, 5)
+  int bits = 0;
+  constexpr int LASTB = P1 - 1 < 5 ? P1 - 1 : 5;                 // polytope m rides on arm body min(m, 5)
   static_for<LASTB + 1>([&](auto I) { constexpr int i = I; constexpr int K = AXK[i]; constexpr int A = (K + 1) % 3, B = (K + 2) % 3;
     real r[3]; ldc<3>(Q->body[i].r, r);
     const real rad = Q->body[i].hull_rad;
     _Pragma("unroll") for (int k = 0; k < 3; k++) p[k] += R[3*k]*r[0] + R[3*k+1]*r[1] + R[3*k+2]*r[2];
-    const real sn_ = sn[i], cs_ = cs[i];                         // of AXS[i] * q[i], as the cube wave's own walk computes them
+    const real sn_ = sn[i], cs_ = cs[i];                         // of AXS[i] * q[i]
     _Pragma("unroll") for (int k = 0; k < 3; k++) {
       const real ca = R[3*k + A], cb = R[3*k + B];
       R[3*k + A] = cs_ * ca + sn_ * cb; R[3*k + B] = -sn_ * ca + cs_ * cb;
     }
     if constexpr (i >= (P0 < 5 ? P0 : 5)) {
       if (__any(p[2] - rad < tp[2] + th[2])) {                    // wave-uniform: the body's bounding sphere reaches the table top's height
-        if constexpr (i < 5) mesh_table_ground(Pm, i, R, p, tp, th, ST);
-        else { static_for<P1 - (P0 > 5 ? P0 : 5)>([&](auto Mm) { constexpr int m = (P0 > 5 ? P0 : 5) + Mm; mesh_table_ground(Pm, m, R, p, tp, th, ST); }); }
+        if constexpr (i < 5) bits |= mesh_broad(Pm, i, R, p, tp, th, true, false, p, 0.0) << (3 * i);
+        else { static_for<P1 - (P0 > 5 ? P0 : 5)>([&](auto Mm) { constexpr int m = (P0 > 5 ? P0 : 5) + Mm; bits |= mesh_broad(Pm, m, R, p, tp, th, true, false, p, 0.0) << (3 * m); }); }
       }
     } });
-  S.st(count_slot, (real)ST.n);
+  S.st(mask_slot, (real)bits);
 }
 
-// ---- P5 in the four-wave kernel: the solver numbers of list positions r, r + 3, r + 6, r + 9 of every lane -- the cube wave takes r = 0, the
-// M wave 1, the RNE wave 2, between barriers S1c (the merged list and its length are published) and S2.  The contact-at-a-time pass of the
-// cube wave alone sat on the workgroup's critical path with three waves waiting (profiles/r03/ab_critical_path_probes.log: executed twice it
-// cost PickAndPlace-IK 9 % and the resting cube 10 %).  The expressions are CubeSys::prepare's, operand for operand; the four contacts of a
-// wave's share are independent chains in one stretch of code.
-constexpr int STAGE_NCON = STAGE_NA;      // the staging area is consumed by then: its first count slot carries the merged list's length
+// ---- P5 in the four-wave kernel: the solver numbers of list positions r, r + 3, r + 6, ... of every lane -- the cube wave takes r = 0, the
+// M wave 1, the RNE wave 2, between barriers S1c (the list is complete: the mesh phase has appended its contacts) and S2.  The
+// contact-at-a-time pass of the cube wave alone sat on the workgroup's critical path with three waves waiting
+// (profiles/r03/ab_critical_path_probes.log).  The independent contacts of a wave's share are separate chains in one stretch of code.
+constexpr int NUM_SHARE = (MAXCON + 2) / 3;
 template <class LS>
 MCG_DEV void solver_numbers_share(ModelPtr Pm, const LS S, real dr1, int r0) {
   ModelPtr Q = launder(Pm);
-  const int ncon = (int)S.ld(STAGE_NCON);
+  const int ncon = (int)S.ld(MP_NCON);
   if (!__any(r0 < ncon)) return;                                                  // wave-uniform
-  real dist[4], mult[4]; int type[4]; bool in[4];
-  _Pragma("unroll") for (int u = 0; u < 4; u++) {
+  real dist[NUM_SHARE], mult[NUM_SHARE]; int type[NUM_SHARE]; bool in[NUM_SHARE];
+  _Pragma("unroll") for (int u = 0; u < NUM_SHARE; u++) {
     const int c = r0 + 3 * u; in[u] = c < ncon;
-    const int b = LDS_CON + c * CON_STRIDE;
-    dist[u] = S.ld(b + 12); mult[u] = S.ld(b + 13); type[u] = sel(in[u], (int)S.ld(b + 15), 0);
+    const int b = LDS_CON + sel(c < MAXCON, c, MAXCON - 1) * CON_STRIDE;
+    dist[u] = S.ld(b + CON_DIST); mult[u] = S.ld(b + CON_D); type[u] = sel(in[u], (int)S.ld(b + CON_TYPE), 0);
   }
-  bool afin = false, atp = false, alink = false;
-  _Pragma("unroll") for (int u = 0; u < 4; u++) {
-    const bool fincube = type[u] >= PAIR_FINR_CUBE, tabpad = type[u] >= PAIR_TABLE_PADR && !fincube, tablink = type[u] >= PAIR_TABLE_LINK0 && !fincube;
-    afin = afin || fincube; atp = atp || tabpad; alink = alink || tablink;
+  bool amc = false, atp = false, ams = false;
+  _Pragma("unroll") for (int u = 0; u < NUM_SHARE; u++) {
+    amc = amc || pair_mesh_cube(type[u]); atp = atp || type[u] == PAIR_TABLE_PADR || type[u] == PAIR_TABLE_PADL; ams = ams || pair_mesh_static(type[u]);
   }
-  afin = __any(afin); atp = __any(atp); alink = __any(alink);
+  amc = __any(amc); atp = __any(atp); ams = __any(ams);
   const real ft = Q->geom_friction0[0], fp = Q->geom_friction0[1] * dr1, fcb = Q->geom_friction0[2] * dr1;
   const real mu_tc0 = fmax(ft, fcb), mu_pc0 = fmax(fp, fcb), mu_tp0 = fmax(ft, fp);
   real par_t[10], par_p[10];
   ldc<10>(Q->contact_par[PAIR_TABLE_CUBE], par_t); ldc<10>(Q->contact_par[PAIR_PADR_CUBE], par_p);
-  const real cd0 = Q->contact_diag[PAIR_TABLE_CUBE][0], cd1 = Q->contact_diag[PAIR_PADR_CUBE][0], cd2 = Q->contact_diag[PAIR_PADL_CUBE][0], rpy = Q->contact_rpy;
-  real imp[4], kk[4], m0[4], tran[4];
-  _Pragma("unroll") for (int u = 0; u < 4; u++) {
+  const real rpy = Q->contact_rpy;
+  real imp[NUM_SHARE], kk[NUM_SHARE], m0[NUM_SHARE], tran[NUM_SHARE];
+  _Pragma("unroll") for (int u = 0; u < NUM_SHARE; u++) {
     const bool padcube = type[u] == PAIR_PADR_CUBE || type[u] == PAIR_PADL_CUBE;
     imp[u] = sel(padcube, impedance(par_p, dist[u]), impedance(par_t, dist[u]));
     kk[u] = sel(padcube, par_p[0], par_t[0]);
     m0[u] = sel(padcube, mu_pc0, mu_tc0);
-    tran[u] = sel(type[u] == PAIR_PADR_CUBE, cd1, sel(type[u] == PAIR_PADL_CUBE, cd2, cd0));
+    { const CRealPtr pt = &Pm->pair_tran[0]; tran[u] = pt[type[u]]; }                        // (a per-lane index: a vector load from the model block)
   }
-  if (afin) {
+  if (amc) {
     ModelPtr Qb = launder(Pm);
-    real par_mc[10]; ldc<10>(Qb->contact_par[PAR_FIN_CUBE], par_mc);
-    const real mu_mc0 = fmax(Qb->fin_par[1], fcb), fin2 = Qb->fin_par[2], fin3 = Qb->fin_par[3], base = Qb->link_diag[7][0] + cd0;
-    _Pragma("unroll") for (int u = 0; u < 4; u++) {
-      const bool fincube = type[u] >= PAIR_FINR_CUBE;
-      imp[u] = sel(fincube, impedance(par_mc, dist[u]), imp[u]); kk[u] = sel(fincube, par_mc[0], kk[u]); m0[u] = sel(fincube, mu_mc0, m0[u]);
-      tran[u] = sel(type[u] == PAIR_FINR_CUBE, fin2, sel(type[u] == PAIR_FINL_CUBE, fin3, tran[u]));
-      tran[u] = sel(type[u] == PAIR_BASE_CUBE, base, tran[u]);
+    real par_mc[10]; ldc<10>(Qb->contact_par[PAR_MESH_CUBE], par_mc);
+    const real mu_mc0 = fmax(Qb->mesh_fric, fcb);
+    _Pragma("unroll") for (int u = 0; u < NUM_SHARE; u++) {
+      const bool mc = pair_mesh_cube(type[u]);
+      imp[u] = sel(mc, impedance(par_mc, dist[u]), imp[u]); kk[u] = sel(mc, par_mc[0], kk[u]); m0[u] = sel(mc, mu_mc0, m0[u]);
     }
   }
   if (atp) {
     ModelPtr Qb = launder(Pm);
     real par_tp[10]; ldc<10>(Qb->contact_par[PAIR_TABLE_PADR], par_tp);
-    const real cd3 = Qb->contact_diag[PAIR_TABLE_PADR][0], cd4 = Qb->contact_diag[PAIR_TABLE_PADL][0];
-    _Pragma("unroll") for (int u = 0; u < 4; u++) {
-      const bool fincube = type[u] >= PAIR_FINR_CUBE, tablink = type[u] >= PAIR_TABLE_LINK0 && !fincube, tabp = (type[u] >= PAIR_TABLE_PADR && !fincube) && !tablink;
+    _Pragma("unroll") for (int u = 0; u < NUM_SHARE; u++) {
+      const bool tabp = type[u] == PAIR_TABLE_PADR || type[u] == PAIR_TABLE_PADL;
       imp[u] = sel(tabp, impedance(par_tp, dist[u]), imp[u]); kk[u] = sel(tabp, par_tp[0], kk[u]); m0[u] = sel(tabp, mu_tp0, m0[u]);
-      tran[u] = sel(type[u] == PAIR_TABLE_PADR, cd3, sel(type[u] == PAIR_TABLE_PADL, cd4, tran[u]));
     }
   }
-  if (alink) {
+  if (ams) {
     ModelPtr Qb = launder(Pm);
-    real par_tl[11], ldg[8]; ldc<11>(Qb->contact_par[PAIR_TABLE_LINK0], par_tl);
-    _Pragma("unroll") for (int k = 0; k < 8; k++) ldg[k] = Qb->link_diag[k][0];
-    _Pragma("unroll") for (int u = 0; u < 4; u++) {
-      const bool fincube = type[u] >= PAIR_FINR_CUBE, tablink = type[u] >= PAIR_TABLE_LINK0 && !fincube;
-      imp[u] = sel(tablink, impedance(par_tl, dist[u]), imp[u]); kk[u] = sel(tablink, par_tl[0], kk[u]); m0[u] = sel(tablink, par_tl[10], m0[u]);
-      real tl = tran[u];
-      static_for<8>([&](auto Pp) { constexpr int pp = Pp; tl = sel(type[u] == PAIR_TABLE_LINK0 + pp, ldg[pp], tl); });
-      tran[u] = tl;
+    real par_tl[11]; ldc<11>(Qb->contact_par[PAR_TABLE_MESH], par_tl);
+    _Pragma("unroll") for (int u = 0; u < NUM_SHARE; u++) {
+      const bool ms = pair_mesh_static(type[u]);
+      imp[u] = sel(ms, impedance(par_tl, dist[u]), imp[u]); kk[u] = sel(ms, par_tl[0], kk[u]); m0[u] = sel(ms, par_tl[10], m0[u]);
     }
   }
-  _Pragma("unroll") for (int u = 0; u < 4; u++) {
+  _Pragma("unroll") for (int u = 0; u < NUM_SHARE; u++) {
     const real Rn = fmax(MINVAL, (1 - imp[u]) * tran[u] * (1 + m0[u]*m0[u]) / imp[u]);
     const real Rpy = fmax(MINVAL, rpy * m0[u]*m0[u] * Rn);
-    if (in[u]) { const int b = LDS_CON + (r0 + 3 * u) * CON_STRIDE; S.st(b + 13, mult[u] / Rpy); S.st(b + 14, kk[u] * imp[u] * dist[u]); }
+    if (in[u]) { const int b = LDS_CON + (r0 + 3 * u) * CON_STRIDE; S.st(b + CON_D, mult[u] / Rpy); S.st(b + CON_KTERM, kk[u] * imp[u] * dist[u]); }
   }
 }
 
@@ -473,12 +410,10 @@ struct CubeSys {
   MCG_DEV CubeSys(const LS s_, const Cube& c, const real* d) : S(s_), Cb(c), pm_bits(0) { dr[0] = d[0]; dr[1] = d[1]; }
   real h, Rc[9], Md[6], damp[6], fs[6];
   real B_tc, B_pc, B_tp, B_tl, B_mc, mu_tc[3], mu_pc[3], mu_tp[3], mu_tl[3], mu_mc[3];
-  bool side_on[2];                             // a contact between the cube and the right / left finger body (pad or finger-link mesh)
-  bool tab_on, stat_on;                        // ... between the cube and a static geom; between a static geom and the robot alone
-  bool base_on;                                // ... between the cube and the gripper base (link6)
+  bool stat_on;                                // a contact between a static geom and the robot alone is in the list
   int ndropped = 0;                            // contacts of this pass that the cap cut off
   int cube_lo, cube_hi, c0 = 0;                // lowest / highest list position of a contact that involves the cube (hi -1: none); list offset of the cube-alone solve
-  int ncon; bool any_pad, solved, touch[2];    // touch: this forward pass has a right / left pad-cube contact; any_pad: any pad contact
+  int ncon; bool any_pad, solved, touch[2];    // touch: this forward pass has a right / left pad-cube contact; any_pad: a contact reaches the robot
   real a_c[6];
 
   // ------------------------------------------------------------------------------------------------- prepare
@@ -504,86 +439,35 @@ struct CubeSys {
     mu_pc[0] = mu_pc[1] = fmax(fp, fcb); mu_pc[2] = Q->contact_par[PAIR_PADR_CUBE][12];
     mu_tp[0] = mu_tp[1] = fmax(ft, fp); mu_tp[2] = Q->contact_par[PAIR_TABLE_PADR][12];
     B_tc = Q->contact_par[PAIR_TABLE_CUBE][1]; B_pc = Q->contact_par[PAIR_PADR_CUBE][1]; B_tp = Q->contact_par[PAIR_TABLE_PADR][1];
-    mu_tl[0] = mu_tl[1] = Q->contact_par[PAIR_TABLE_LINK0][10]; mu_tl[2] = 0; B_tl = Q->contact_par[PAIR_TABLE_LINK0][1];      // condim 3: no torsional rows
-    mu_mc[0] = mu_mc[1] = fmax(Q->fin_par[1], fcb); mu_mc[2] = Q->contact_par[PAR_FIN_CUBE][12]; B_mc = Q->contact_par[PAR_FIN_CUBE][1];
+    mu_tl[0] = mu_tl[1] = Q->contact_par[PAR_TABLE_MESH][10]; mu_tl[2] = 0; B_tl = Q->contact_par[PAR_TABLE_MESH][1];      // condim 3: no torsional rows
+    mu_mc[0] = mu_mc[1] = fmax(Q->mesh_fric, fcb); mu_mc[2] = Q->contact_par[PAR_MESH_CUBE][12]; B_mc = Q->contact_par[PAR_MESH_CUBE][1];
   }
 
   MCG_DEV ModelPtr model() const {                // wave-uniform pointer rebuilt as a scalar
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)pm_bits), hi = __builtin_amdgcn_readfirstlane((unsigned)(pm_bits >> 32));
     return (ModelPtr)(((unsigned long long)hi << 32) | lo);
   }
-  // The M / RNE waves' staged arm-mesh contacts go IN FRONT of this wave's entries (the oracle's pair order: arm meshes first), and the
-  // cap of MAXCON contacts is applied to the merged list as ContactList::add applies it entry by entry: a mesh entry stands for
-  // link_mult identical contacts, this wave's entries keep min(their take, what is left).
-  MCG_DEV void merge_staged(ModelPtr Pm, ContactList<LS>& CL) {
-    const int nA = (int)S.ld(STAGE_NA), nB = (int)S.ld(STAGE_NB), nM = nA + nB;
-    if (!__any(nM > 0)) return;                                          // wave-uniform
-    const int mult = (int)launder(Pm)->link_mult;
-    int ncap = 0, km = 0, drop = 0;
-    for (int e = 0; __any(e < nM); e++) {
-      const bool in = e < nM;
-      const int take = sel(mult < MAXCON - ncap, mult, MAXCON - ncap);
-      const bool ok = in && take > 0;
-      km += sel(ok, 1, 0); ncap += sel(ok, take, 0); drop += sel(in, mult - sel(take > 0, take, 0), 0);
-    }
-    const int nC = CL.n;
-    int kc = 0;
-    for (int c = 0; __any(c < nC); c++) {
-      const bool in = c < nC;
-      const int slot = LDS_CON + sel(in, c, 0) * CON_STRIDE + 13;
-      const int tl = sel(in, (int)S.ld(slot), 0);
-      const int take = sel(tl < MAXCON - ncap, tl, MAXCON - ncap);
-      const bool ok = in && take > 0;
-      if (ok && take != tl) S.st(slot, (real)take);
-      kc += sel(ok, 1, 0); ncap += sel(ok, take, 0); drop += sel(in, tl - sel(take > 0, take, 0), 0);
-    }
-    for (int c = MAXCON - 1; c >= 0; c--) {                              // this wave's kept entries move up by km, top down
-      const bool mv = c < kc && km > 0;
-      if (__any(mv)) {
-        if (mv) {
-          real v[CON_STRIDE];
-          _Pragma("unroll") for (int k = 0; k < CON_STRIDE; k++) v[k] = S.ld(LDS_CON + c * CON_STRIDE + k);
-          _Pragma("unroll") for (int k = 0; k < CON_STRIDE; k++) S.st(LDS_CON + (c + km) * CON_STRIDE + k, v[k]);
-        }
-      }
-    }
-    for (int e = 0; __any(e < km); e++) {
-      if (e < km) {
-        const int src = sel(e < nA, STAGE_A + e * STAGE_STRIDE, STAGE_B + (e - nA) * STAGE_STRIDE);
-        real pos[3], nrm[3], t1[3], t2[3];
-        _Pragma("unroll") for (int k = 0; k < 3; k++) { pos[k] = S.ld(src + k); nrm[k] = S.ld(src + 3 + k); }
-        const real dist = S.ld(src + 6), type = S.ld(src + 7);
-        make_frame(nrm, t1, t2);
-        const int take = sel(mult < MAXCON - e * mult, mult, MAXCON - e * mult);
-        const int b = LDS_CON + e * CON_STRIDE;
-        _Pragma("unroll") for (int k = 0; k < 3; k++) { S.st(b + k, pos[k]); S.st(b + 3 + k, nrm[k]); S.st(b + 6 + k, t1[k]); S.st(b + 9 + k, t2[k]); }
-        S.st(b + 12, dist); S.st(b + 13, (real)take); S.st(b + 15, type);
-      }
-    }
-    CL.n = km + kc; CL.ncap = ncap; CL.ndrop += drop;
-    // what the list now holds decides the flags (the cap may have cut an entry this wave had room for)
-    any_pad = false; touch[0] = touch[1] = false;
-    for (int c = 0; __any(c < CL.n); c++) {
-      const int type = sel(c < CL.n, (int)S.ld(LDS_CON + sel(c < CL.n, c, 0) * CON_STRIDE + 15), PAIR_TABLE_CUBE);
+
+  // what the completed list holds decides the routing: flags, the stretch of the list the cube-alone solve walks
+  MCG_DEV void scan_list() {
+    stat_on = false; cube_hi = -1; cube_lo = 0; any_pad = false; touch[0] = touch[1] = false;
+    for (int c = 0; __any(c < ncon); c++) {
+      const bool in = c < ncon;
+      const int type = sel(in, (int)S.ld(LDS_CON + sel(c < MAXCON, c, MAXCON - 1) * CON_STRIDE + CON_TYPE), PAIR_TABLE_CUBE);
       any_pad = any_pad || type != PAIR_TABLE_CUBE;
       touch[0] = touch[0] || type == PAIR_PADR_CUBE; touch[1] = touch[1] || type == PAIR_PADL_CUBE;
+      cube_lo = sel(in && pair_has_cube(type) && cube_hi < 0, c, cube_lo);
+      cube_hi = sel(in && pair_has_cube(type), c, cube_hi);
+      stat_on = stat_on || (in && !pair_has_cube(type));
     }
   }
 
-  MCG_DEV void scan_sides() {
-    side_on[0] = side_on[1] = tab_on = stat_on = base_on = false; cube_hi = -1; cube_lo = 0;
-    for (int c = 0; __any(c < ncon); c++) {
-      const int type = sel((c < ncon), (int)S.ld(LDS_CON + c * CON_STRIDE + 15), 0);
-      base_on = base_on || type == PAIR_BASE_CUBE;
-      cube_lo = sel((c < ncon) && pair_has_cube(type) && cube_hi < 0, c, cube_lo);
-      cube_hi = sel((c < ncon) && pair_has_cube(type), c, cube_hi);
-      side_on[0] = side_on[0] || pair_class(type) == 1; side_on[1] = side_on[1] || pair_class(type) == 2;
-      tab_on = tab_on || ((c < ncon) && pair_has_cube(type) && pair_class(type) == 0); stat_on = stat_on || ((c < ncon) && !pair_has_cube(type));
-    }
-  }
-  // SPLIT (the cube wave of the four-wave kernel): the arm meshes are tested by the M / RNE waves meanwhile and merged in after S1b
-  template <bool SPLIT = false>
-  MCG_DEV void prepare(ModelPtr Pm, const real* qr) {
+  // ---- P4, the lane-parallel part: the primitive geoms' contacts and the candidate pairs of the mesh geoms.
+  // qr: the robot's twelve joint angles.  MESHES: fill the mesh phase's slots (the cube's pose, this wave's candidate mask, the list's
+  // length); ARM: this wave also runs the arm meshes' broad phase against the table / the ground (the four-wave kernel leaves that to
+  // the M / RNE waves: arm_broad_stage).
+  template <bool MESHES, bool ARM>
+  MCG_DEV void collide_primitives(ModelPtr Pm, const real* qr) {
     pm_bits = (unsigned long long)Pm;
     {   // mj_kinematics normalises the stored quaternion
       const real nq = sqrt(Cb.quat[0]*Cb.quat[0] + Cb.quat[1]*Cb.quat[1] + Cb.quat[2]*Cb.quat[2] + Cb.quat[3]*Cb.quat[3]);
@@ -595,21 +479,20 @@ struct CubeSys {
     solved = false;
     _Pragma("unroll") for (int k = 0; k < 6; k++) a_c[k] = Cb.warm[k];
 
-    // ---- P4 collision, in the oracle's pair order (the cap of MAXCON contacts then cuts the same tail): arm-side meshes on the
-    // ground / the table (mesh by mesh), then the primitive geoms: ground-pads, ground-cube, table-pads, table-cube, pads-cube
     MCG_TICK2(ST_A_ENTRY);
     ContactList<LS> CL{S, 0};
     real hc[3]; ldc<3>(Q->cube_half, hc);
     real tp[3], th[3]; ldc<3>(Q->table_pos, tp); ldc<3>(Q->table_half, th);
+    const real crad = sqrt(dot3(hc, hc));
     any_pad = false; touch[0] = touch[1] = false;
-    // world frames of the arm joints and of the two gear / finger joints (mj_kinematics for the pads' chain)
-    real Rs[2][9], pc[2][3], ph[2][3], pf[2][3];      // finger frames (rotation, origin pf), pad centres and half sizes
+    long long mbits = 0;                               // candidate pairs: bit 3 m + o (o: 0 ground, 1 table, 2 cube)
+    // world frames of the arm joints and of the gripper's six joints (mj_kinematics; the contact rows' twist columns: LDS_WJ)
+    real Rs[2][9], pc[2][3], ph[2][3];                 // finger frames, pad centres and half sizes
     _Pragma("unroll") for (int sd = 0; sd < 2; sd++) {     // defined values for lanes / waves whose pads are not posed
       _Pragma("unroll") for (int k = 0; k < 9; k++) Rs[sd][k] = (k % 4 == 0) ? 1.0 : 0.0;
-      pc[sd][0] = pc[sd][1] = 0.0; pc[sd][2] = 1.0; ph[sd][0] = ph[sd][1] = ph[sd][2] = 0.0; pf[sd][0] = pf[sd][1] = 0.0; pf[sd][2] = 1.0;
+      pc[sd][0] = pc[sd][1] = 0.0; pc[sd][2] = 1.0; ph[sd][0] = ph[sd][1] = ph[sd][2] = 0.0;
     }
     bool reach, padlive;
-    real R6[9], p6[3];                              // frame of link6 (the gripper base's mesh rides on it)
     {
       const TrigC T = load_trig();
       real R[9], p[3];
@@ -625,28 +508,32 @@ struct CubeSys {
           Rio[3*k + A] = cs_ * ca + sn_ * cb; Rio[3*k + B] = -sn_ * ca + cs_ * cb;
         }
       };
-      auto hull = [&](int pi, const real* Rio, const real* pio) {
-        if constexpr (SPLIT) return;                                      // (the M / RNE waves test the arm meshes: arm_mesh_stage)
-        const int before = CL.n;
-        mesh_table_ground(Pm, pi, Rio, pio, tp, th, CL);
-        any_pad = any_pad || (CL.n > before);
+      // a mesh's candidate bits: against the cube always here; against the table / the ground here for the gripper's parts (and for the
+      // arm's when ARM)
+      auto broad = [&](int m, const real* Rio, const real* pio, bool statics, bool cube) {
+        if constexpr (MESHES) mbits |= (long long)mesh_broad(Pm, m, Rio, pio, tp, th, statics, cube, Cb.pos, crad) << (3 * m);
       };
       static_for<6>([&](auto I) { constexpr int i = I; real r[3]; ldc<3>(Q->body[i].r, r);
         const real rad = Q->body[i].hull_rad;                             // comes with the same batch of scalar loads as r
         joint(i, AXK[i], AXS[i], r, qr[i], R, p);
-        if (__any(p[2] - rad < tp[2] + th[2])) {                          // wave-uniform: the body's bounding sphere reaches the table top's height
-          hull(i, R, p);
-          if constexpr (i == 5) { hull(6, R, p); hull(7, R, p); }
+        if constexpr (MESHES) {
+          const real dx = p[0] - Cb.pos[0], dy = p[1] - Cb.pos[1], dz = p[2] - Cb.pos[2];
+          const bool ncube = dx*dx + dy*dy + dz*dz < (rad + crad) * (rad + crad);      // the body's bounding sphere reaches the cube's
+          const bool nstat = ARM && (p[2] - rad < tp[2] + th[2]);                      // ... the table top's height
+          if (__any(ncube || nstat)) {
+            broad(i, R, p, nstat, ncube);
+            if constexpr (i == 5) { broad(6, R, p, nstat, ncube); broad(7, R, p, nstat, ncube); }
+          }
         } });
       MCG_TICK2(ST_A_G);
       const real dxe = p[0] - Cb.pos[0], dye = p[1] - Cb.pos[1], dze = p[2] - Cb.pos[2];
       reach = dxe*dxe + dye*dye + dze*dze < 0.2 * 0.2;                  // link6 origin within 20 cm of the cube
-      _Pragma("unroll") for (int k = 0; k < 9; k++) R6[k] = R[k];
-      _Pragma("unroll") for (int k = 0; k < 3; k++) p6[k] = p[k];
-      // a pad's far corner is at most 0.16 m from the link6 origin: pads can only touch the table / the ground from within 0.17 m
+      // a pad's far corner is at most 0.16 m from the link6 origin (and so is every point of the gripper's links): the gripper can only
+      // touch the table / the ground from within 0.17 m
       real dtab = 0;
       _Pragma("unroll") for (int k = 0; k < 3; k++) { const real e = fmax(fabs(p[k] - tp[k]) - th[k], 0.0); dtab = fma(e, e, dtab); }
-      padlive = reach || dtab < 0.17 * 0.17 || p[2] < 0.17;
+      const bool nearstat = dtab < 0.17 * 0.17 || p[2] < 0.17;
+      padlive = reach || nearstat;
       if (__any(padlive)) {
         static_for<2>([&](auto Sd) {
           constexpr int sd = Sd; constexpr int g = 6 + 2 * sd, f = 7 + 2 * sd;
@@ -654,9 +541,17 @@ struct CubeSys {
           _Pragma("unroll") for (int k = 0; k < 9; k++) Rs[sd][k] = R[k];
           _Pragma("unroll") for (int k = 0; k < 3; k++) ps[k] = p[k];
           real r[3]; ldc<3>(Q->body[g].r, r); joint(g, 1, AXS[g], r, qr[g], Rs[sd], ps);
+          broad(8 + 2 * sd, Rs[sd], ps, nearstat, reach);                               // gear link
           ldc<3>(Q->body[f].r, r); joint(f, 1, AXS[f], r, qr[f], Rs[sd], ps);
+          broad(9 + 2 * sd, Rs[sd], ps, nearstat, reach);                               // finger link
           real pb[6]; ldc<6>(Q->pad_box[sd], pb);
-          _Pragma("unroll") for (int k = 0; k < 3; k++) { pc[sd][k] = ps[k] + Rs[sd][3*k]*pb[0] + Rs[sd][3*k+1]*pb[1] + Rs[sd][3*k+2]*pb[2]; ph[sd][k] = pb[3 + k]; pf[sd][k] = ps[k]; }
+          _Pragma("unroll") for (int k = 0; k < 3; k++) { pc[sd][k] = ps[k] + Rs[sd][3*k]*pb[0] + Rs[sd][3*k+1]*pb[1] + Rs[sd][3*k+2]*pb[2]; ph[sd][k] = pb[3 + k]; }
+          // the hinge link of this side (its joint hangs on link6)
+          real Rh[9], phg[3];
+          _Pragma("unroll") for (int k = 0; k < 9; k++) Rh[k] = R[k];
+          _Pragma("unroll") for (int k = 0; k < 3; k++) phg[k] = p[k];
+          ldc<3>(Q->body[10 + sd].r, r); joint(10 + sd, 1, AXS[10 + sd], r, qr[10 + sd], Rh, phg);
+          broad(12 + sd, Rh, phg, nearstat, reach);
         });
       }
     }
@@ -665,9 +560,7 @@ struct CubeSys {
       static_for<2>([&](auto Sd) { constexpr int sd = Sd;
         const bool low = padlive && pc[sd][2] < 0.02;
         const real far[3] = {pc[sd][0], pc[sd][1], low ? pc[sd][2] : 1.0};
-        const int before = CL.n;
-        ground_box(CL, far, Rs[sd], ph[sd], PAIR_TABLE_PADR + sd);
-        any_pad = any_pad || (CL.n > before); });
+        ground_box(CL, far, Rs[sd], ph[sd], PAIR_TABLE_PADR + sd); });
     }
     if (__any(Cb.pos[2] < 0.05)) {
       const bool low = Cb.pos[2] < 0.05;
@@ -684,15 +577,11 @@ struct CubeSys {
         const real ext = fabs(Rs[sd][3*k]) * ph[sd][0] + fabs(Rs[sd][3*k+1]) * ph[sd][1] + fabs(Rs[sd][3*k+2]) * ph[sd][2];
         near = near && !(fabs(pc[sd][k] - tp[k]) - (th[k] + ext) > 0);
       }
-      if (__any(near)) {
-        const int before = CL.n;
-        box_box(CL, near, tp, Rt, th, pc[sd], Rs[sd], ph[sd], PAIR_TABLE_PADR + sd);
-        any_pad = any_pad || (CL.n > before);
-      } });
+      if (__any(near)) box_box(CL, near, tp, Rt, th, pc[sd], Rs[sd], ph[sd], PAIR_TABLE_PADR + sd); });
     MCG_TICK2(ST_A_LOOP);
     {
       const real dx = Cb.pos[0] - tp[0], dy = Cb.pos[1] - tp[1], dz = Cb.pos[2] - tp[2];
-      const real rs = sqrt(dot3(th, th)) + sqrt(dot3(hc, hc));
+      const real rs = sqrt(dot3(th, th)) + crad;
       const bool near = dx*dx + dy*dy + dz*dz <= rs*rs;
       if (__any(near)) box_box(CL, near, tp, Rt, th, Cb.pos, Rc, hc, PAIR_TABLE_CUBE);
     }
@@ -700,184 +589,44 @@ struct CubeSys {
     if (__any(reach)) {
       static_for<2>([&](auto Sd) { constexpr int sd = Sd;
         const real dx = Cb.pos[0] - pc[sd][0], dy = Cb.pos[1] - pc[sd][1], dz = Cb.pos[2] - pc[sd][2];
-        const real rs = sqrt(dot3(ph[sd], ph[sd])) + sqrt(dot3(hc, hc));
+        const real rs = sqrt(dot3(ph[sd], ph[sd])) + crad;
         const bool near = reach && (dx*dx + dy*dy + dz*dz <= rs*rs);
-        const int before = CL.n;
-        if (__any(near)) box_box(CL, near, pc[sd], Rs[sd], ph[sd], Cb.pos, Rc, hc, PAIR_PADR_CUBE + sd);
-        touch[sd] = CL.n > before;
-        any_pad = any_pad || touch[sd]; });
+        if (__any(near)) box_box(CL, near, pc[sd], Rs[sd], ph[sd], Cb.pos, Rc, hc, PAIR_PADR_CUBE + sd); });
     }
     MCG_TICK2(ST_A_MAP);
-    // Finger-link meshes - cube (second stage; the oracle's box_polytope with full = 1, the mesh as geom1): right, left.  Separating-axis test over the cube's three face axes and the
-    // polytope's 13 canonical axes, ONE contact along the axis of least penetration: a cube face -> at the polytope's deepest vertex;
-    // a polytope axis -> at the cube's deepest corner along it.  Each entry stands for the two identical geoms the reference attaches.
-    if (__any(reach)) {
-      // mi 0 / 1: right / left finger link (its own frame); mi 2: the gripper base (arm-side polytope 7, link6 frame)
-      auto mesh_cube = [&](int mi, const real* Rf, const real* pfr, int type) {
-        ModelPtr H = launder(Pm);
-        const CRealPtr hullp = mi < 2 ? &H->fin_hull[mi][0][0] : &H->link_hull[7][0][0];
-        const CRealPtr extp = mi < 2 ? &H->fin_ext[mi][0][0] : &H->link_ext[7][0][0];
-        real fb[6]; ldc<6>(mi < 2 ? H->fin_box[mi] : H->link_hull_box[7], fb);
-        real cw[3];
-        _Pragma("unroll") for (int k = 0; k < 3; k++) cw[k] = pfr[k] + Rf[3*k]*fb[0] + Rf[3*k+1]*fb[1] + Rf[3*k+2]*fb[2] - Cb.pos[k];
-        const real rs = sqrt(fb[3]*fb[3] + fb[4]*fb[4] + fb[5]*fb[5]) + sqrt(dot3(hc, hc));
-        bool near = reach && dot3(cw, cw) <= rs * rs;                       // bounding spheres ...
-        {   // ... then the cube's bounding sphere against the polytope's bounding BOX, in the mesh frame (the meshes are elongated)
-          const real rc = sqrt(dot3(hc, hc));
-          _Pragma("unroll") for (int k = 0; k < 3; k++) near = near && fabs(Rf[k]*cw[0] + Rf[3 + k]*cw[1] + Rf[6 + k]*cw[2]) <= fb[3 + k] + rc;
-        }
-        if (!__any(near)) return;
-        real lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY}, wlo[3][3], whi[3][3];
-        _Pragma("unroll") for (int a = 0; a < 3; a++) { _Pragma("unroll") for (int r = 0; r < 3; r++) wlo[a][r] = whi[a][r] = 0; }
-        for (int k = 0; k < 26; k++) {
-          real v[3]; ldc<3>(hullp + 3 * k, v);
-          real w[3], rel[3];
-          _Pragma("unroll") for (int r = 0; r < 3; r++) { w[r] = pfr[r] + Rf[3*r]*v[0] + Rf[3*r+1]*v[1] + Rf[3*r+2]*v[2]; rel[r] = w[r] - Cb.pos[r]; }
-          _Pragma("unroll") for (int a = 0; a < 3; a++) {
-            const real c = rel[0]*Rc[a] + rel[1]*Rc[3 + a] + rel[2]*Rc[6 + a];          // along the cube's axis a
-            const bool lower = c < lo[a], higher = c > hi[a];                           // first occurrence of each extreme, as the oracle keeps it
-            lo[a] = sel(lower, c, lo[a]); hi[a] = sel(higher, c, hi[a]);
-            _Pragma("unroll") for (int r = 0; r < 3; r++) { wlo[a][r] = sel(lower, w[r], wlo[a][r]); whi[a][r] = sel(higher, w[r], whi[a][r]); }
-          }
-        }
-        bool sep = !near; real depth = INFINITY; int axis = 0; bool plus = true;
-        _Pragma("unroll") for (int a = 0; a < 3; a++) {
-          sep = sep || (lo[a] > hc[a]) || (hi[a] < -hc[a]);
-          const real dp = hc[a] - lo[a], dn = hi[a] + hc[a];
-          const bool tp_ = dp < depth;
-          depth = sel(tp_, dp, depth); axis = sel(tp_, a, axis); plus = sel(tp_, true, plus);
-          const bool tn_ = dn < depth;
-          depth = sel(tn_, dn, depth); axis = sel(tn_, a, axis); plus = sel(tn_, false, plus);
-        }
-        real nw[3] = {0, 0, 0};                                             // the normal when a polytope axis wins (cube -> mesh)
-        {
-          real ext[26]; ldc<26>(extp, ext);
-          static_for<13>([&](auto Kk) { constexpr int k = Kk;
-            constexpr real il = 1.0 / (MCG_DIR13[k][0]*MCG_DIR13[k][0] + MCG_DIR13[k][1]*MCG_DIR13[k][1] + MCG_DIR13[k][2]*MCG_DIR13[k][2] == 1 ? 1.0 :
-                                       (MCG_DIR13[k][0]*MCG_DIR13[k][0] + MCG_DIR13[k][1]*MCG_DIR13[k][1] + MCG_DIR13[k][2]*MCG_DIR13[k][2] == 2 ? 1.4142135623730951 : 1.7320508075688772));
-            real w[3];
-            _Pragma("unroll") for (int r = 0; r < 3; r++) w[r] = MCG_DIR13[k][0] * Rf[3*r] + MCG_DIR13[k][1] * Rf[3*r+1] + MCG_DIR13[k][2] * Rf[3*r+2];
-            const real rel = (pfr[0] - Cb.pos[0]) * w[0] + (pfr[1] - Cb.pos[1]) * w[1] + (pfr[2] - Cb.pos[2]) * w[2];
-            real rad = 0;
-            _Pragma("unroll") for (int a = 0; a < 3; a++) rad += hc[a] * fabs(Rc[a]*w[0] + Rc[3 + a]*w[1] + Rc[6 + a]*w[2]);
-            sep = sep || (rel + ext[2*k] > rad) || (rel + ext[2*k + 1] < -rad);
-            const real dp = (rad - (rel + ext[2*k])) * il, dn = ((rel + ext[2*k + 1]) + rad) * il;
-            const bool tp_ = dp < depth;
-            depth = sel(tp_, dp, depth); axis = sel(tp_, 3 + k, axis);
-            _Pragma("unroll") for (int r = 0; r < 3; r++) nw[r] = sel(tp_, w[r] * il, nw[r]);
-            const bool tn_ = dn < depth;
-            depth = sel(tn_, dn, depth); axis = sel(tn_, 3 + k, axis);
-            _Pragma("unroll") for (int r = 0; r < 3; r++) nw[r] = sel(tn_, -w[r] * il, nw[r]); });
-        }
-        const bool face = axis < 3;
-        real n[3], pos[3];
-        _Pragma("unroll") for (int r = 0; r < 3; r++) {
-          const real ax = sel3(axis, Rc[3*r], Rc[3*r + 1], Rc[3*r + 2]);                // (axis >= 3 picks the third: unused then)
-          n[r] = sel(face, plus ? ax : -ax, nw[r]);                                       // from the cube to the mesh
-        }
-        real xb[3] = {Cb.pos[0], Cb.pos[1], Cb.pos[2]};                                   // the cube's deepest corner along n
-        _Pragma("unroll") for (int a = 0; a < 3; a++) {
-          const real sg = (n[0]*Rc[a] + n[1]*Rc[3 + a] + n[2]*Rc[6 + a]) > 0 ? 1.0 : -1.0;
-          _Pragma("unroll") for (int r = 0; r < 3; r++) xb[r] += sg * hc[a] * Rc[3*r + a];
-        }
-        _Pragma("unroll") for (int r = 0; r < 3; r++) {
-          const real wv = plus ? sel3(axis, wlo[0][r], wlo[1][r], wlo[2][r]) : sel3(axis, whi[0][r], whi[1][r], whi[2][r]);
-          pos[r] = sel(face, wv + 0.5 * depth * n[r], xb[r] - 0.5 * depth * n[r]);
-        }
-        const real nm[3] = {-n[0], -n[1], -n[2]};                                         // the mesh is geom1: normal from the mesh to the cube
-        const int before = CL.n;
-        CL.add(pos, nm, sep ? 1.0 : -depth, type, mi < 2 ? (int)H->fin_par[0] : (int)H->link_mult);
-        any_pad = any_pad || (CL.n > before);
-      };
-      mesh_cube(2, R6, p6, PAIR_BASE_CUBE);          // geom order of the reference: gripper_base before the finger links
-      mesh_cube(0, Rs[0], pf[0], PAIR_FINR_CUBE);
-      mesh_cube(1, Rs[1], pf[1], PAIR_FINL_CUBE);
+    ncon = CL.n; ndropped = CL.ndrop;
+    if constexpr (MESHES) {
+      _Pragma("unroll") for (int k = 0; k < 3; k++) S.st(MP_CUBE + k, Cb.pos[k]);
+      _Pragma("unroll") for (int k = 0; k < 4; k++) S.st(MP_CUBE + 3 + k, Cb.quat[k]);
+      S.st(MP_MASK + 2, (real)mbits); S.st(MP_NCON, (real)ncon); S.st(MP_DROP, 0.0);
+      if constexpr (ARM) { S.st(MP_MASK, 0.0); S.st(MP_MASK + 1, 0.0); }
     }
     MCG_TICK2(ST_A_STORE);
-    if constexpr (SPLIT) { __syncthreads(); MCG_TICK2(ST_CUBE_FIN); merge_staged(Pm, CL); MCG_TICK2(ST_COLLIDE); }       // S1b
-    ncon = CL.n; ndropped = CL.ndrop;
-    if (__any(CL.ndrop > 0)) { if (CL.ndrop > 0 && cnt) atomicAdd(cnt + 2, (unsigned long long)CL.ndrop); }      // MAXCON cut the list (MuJoCo has no such cap)
-    scan_sides();
+  }
+
+  // ---- after the mesh phase (mcg_mesh.hpp) has appended the mesh geoms' contacts: the list as it now stands
+  MCG_DEV void collect_list() {
+    ncon = (int)S.ld(MP_NCON); ndropped += (int)S.ld(MP_DROP);
+    if (__any(ndropped > 0)) { if (ndropped > 0 && cnt) atomicAdd(cnt + 2, (unsigned long long)ndropped); }      // MAXCON cut the list (MuJoCo has no such cap)
+    scan_list();
 #ifdef MCG_STAGE_CLOCKS
     { int mx = 0; for (int c = 0; __any(c < ncon); c++) mx = c + 1; if ((threadIdx.x & 63) == 0) atomicAdd(&g_stage_clocks[ST_COUNT + CN_CONTACTS], (unsigned long long)mx); }   // wave-max contacts
 #endif
     // Lanes with fewer contacts than their wave-mates still walk the longer list with zero weights: give them clean
     // zeros to multiply (uninitialised LDS may hold NaN / inf, and 0 * NaN would poison the sums).  Only the contact entries here:
-    // the line-search rows and the masks are cleared by the solves that use them (clean_rows) -- in the four-wave kernel the start
-    // of the row area holds q(t), qd(t) for the other waves, which still read them while this pass runs.
+    // the line-search rows and the masks are cleared by the solves that use them (clean_rows).
     for (int c = 0; __any(c < ncon); c++) {
       if (c >= ncon) {
         for (int k = 0; k < CON_STRIDE; k++) S.st(LDS_CON + c * CON_STRIDE + k, 0.0);
       }
     }
     MCG_TICK2(ST_CUBE);
-    if constexpr (SPLIT) {      // the four-wave kernel: the pass is shared by the cube, M and RNE waves (solver_numbers_share)
-      S.st(STAGE_NCON, (real)ncon);
-      __syncthreads();                                                  // S1c
-      solver_numbers_share(Pm, S, dr[1], 0);
-      return;
-    }
-    // ---- P5 per-contact solver numbers (the 6 pyramid rows of a contact share D and the position term)
-#if MCG_DUP == 1
-    for (int dup = 0; dup < 2; dup++) {      // critical-path probe: the pass twice (the second from the first's multiplicities, restored)
-    if (dup == 1) { for (int c = 0; __any(c < ncon); c++) if (c < ncon) S.st(LDS_CON + c * CON_STRIDE + 13, S.ld(LDS_ACT + c)); }
-    else { for (int c = 0; __any(c < ncon); c++) if (c < ncon) S.st(LDS_ACT + c, S.ld(LDS_CON + c * CON_STRIDE + 13)); }
-#endif
-    real par_t[15], par_p[15];
-    ldc<15>(Q->contact_par[PAIR_TABLE_CUBE], par_t); ldc<15>(Q->contact_par[PAIR_PADR_CUBE], par_p);
-    const bool any_tp = __any(any_pad);      // wave-uniform: table / ground - pad contacts may exist
-    for (int c = 0; __any(c < ncon); c++) {
-      const int b = LDS_CON + c * CON_STRIDE;
-      const real dist = S.ld(b + 12);
-      const int type = sel((c < ncon), (int)S.ld(b + 15), 0);
-      const bool padcube = type == PAIR_PADR_CUBE || type == PAIR_PADL_CUBE, fincube = type >= PAIR_FINR_CUBE, tabpad = type >= PAIR_TABLE_PADR && !fincube;
-      real imp = sel(padcube, impedance(par_p, dist), impedance(par_t, dist));
-      real kk = sel(padcube, par_p[0], par_t[0]);
-      real m0 = sel(padcube, mu_pc[0], mu_tc[0]);
-      real tran = sel(type == PAIR_PADR_CUBE, Q->contact_diag[PAIR_PADR_CUBE][0],
-                      sel(type == PAIR_PADL_CUBE, Q->contact_diag[PAIR_PADL_CUBE][0], Q->contact_diag[PAIR_TABLE_CUBE][0]));
-      const real mult = S.ld(b + 13);                                     // identical contacts this entry stands for (ContactList::add)
-      if (__any(fincube)) {
-        real par_mc[10]; ldc<10>(Q->contact_par[PAR_FIN_CUBE], par_mc);
-        imp = sel(fincube, impedance(par_mc, dist), imp); kk = sel(fincube, par_mc[0], kk); m0 = sel(fincube, mu_mc[0], m0);
-        tran = sel(type == PAIR_FINR_CUBE, Q->fin_par[2], sel(type == PAIR_FINL_CUBE, Q->fin_par[3], tran));
-        tran = sel(type == PAIR_BASE_CUBE, Q->link_diag[7][0] + Q->contact_diag[PAIR_TABLE_CUBE][0], tran);      // gripper_base body + cube (the table's is 0)
-      }
-      if (any_tp) {
-        const bool tablink = type >= PAIR_TABLE_LINK0 && !fincube, tabp = tabpad && !tablink;
-        real par_tp[10]; ldc<10>(Q->contact_par[PAIR_TABLE_PADR], par_tp);
-        imp = sel(tabp, impedance(par_tp, dist), imp); kk = sel(tabp, par_tp[0], kk); m0 = sel(tabp, mu_tp[0], m0);
-        tran = sel(type == PAIR_TABLE_PADR, Q->contact_diag[PAIR_TABLE_PADR][0], sel(type == PAIR_TABLE_PADL, Q->contact_diag[PAIR_TABLE_PADL][0], tran));
-        if (__any(tablink)) {
-          real par_tl[10]; ldc<10>(Q->contact_par[PAIR_TABLE_LINK0], par_tl);
-          imp = sel(tablink, impedance(par_tl, dist), imp); kk = sel(tablink, par_tl[0], kk); m0 = sel(tablink, mu_tl[0], m0);
-          real tl = tran;
-          static_for<8>([&](auto Pp) { constexpr int pp = Pp; tl = sel(type == PAIR_TABLE_LINK0 + pp, Q->link_diag[pp][0], tl); });
-          tran = tl;
-        }
-      }
-      const real Rn = fmax(MINVAL, (1 - imp) * tran * (1 + m0*m0) / imp);
-      const real Rpy = fmax(MINVAL, Q->contact_rpy * m0*m0 * Rn);      // 2 mu^2 R [RECALL]; 4 mu^2 R under contact_rule = "keyframe" (include/mcg.h)
-      if (c < ncon) { S.st(b + 13, mult / Rpy); S.st(b + 14, kk * imp * dist); }
-    }
-#if MCG_DUP == 1
-    }
-#endif
-#ifdef MCG_DBG_PRINT
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-      printf("[prepare] ncon %d any_pad %d touch %d %d cube pos %.9g %.9g %.9g\n", ncon, (int)any_pad, (int)touch[0], (int)touch[1], Cb.pos[0], Cb.pos[1], Cb.pos[2]);
-      for (int c = 0; c < ncon; c++) { const int b = LDS_CON + c * CON_STRIDE;
-        printf("   contact %d type %d dist %.6e D %.6e kterm %.6e pos %.6f %.6f %.6f n %.3f %.3f %.3f\n", c, (int)S.ld(b + 15), S.ld(b + 12), S.ld(b + 13), S.ld(b + 14),
-               S.ld(b), S.ld(b + 1), S.ld(b + 2), S.ld(b + 3), S.ld(b + 4), S.ld(b + 5)); }
-    }
-#endif
   }
 
-  // identical geoms list entry c stands for (debug export): the mesh pairs carry the model's multiplicity unless the cap cut it
+  // identical geoms list entry c stands for (debug export)
   MCG_DEV real mult_of(int c) const {
-    ModelPtr Q = model();
-    const int type = (int)S.ld(LDS_CON + c * CON_STRIDE + 15);
-    return (type >= PAIR_FINR_CUBE) ? Q->fin_par[0] : ((type >= PAIR_TABLE_LINK0) ? Q->link_mult : 1.0);
+    const int type = (int)S.ld(LDS_CON + c * CON_STRIDE + CON_TYPE);
+    return (type >= PAIR_STATIC_MESH0) ? model()->mesh_mult : 1.0;
   }
   // rows of contact c in the cube's dofs / in the robot's dofs of the pad's side
   MCG_DEV void rows_cube(int c, CubeRows& R) const { cube_rows(S, c, Rc, Cb.pos, R); }
@@ -926,8 +675,8 @@ struct CubeSys {
   template <bool OFF> MCG_DEV real alone_D(int c) const {
     const int b = LDS_CON + li<OFF>(c) * CON_STRIDE;
     bool keep = c < ncon;
-    if constexpr (OFF) keep = keep && pair_has_cube((int)S.ld(b + 15));
-    return sel(keep, S.ld(b + 13), 0.0);
+    if constexpr (OFF) keep = keep && pair_has_cube((int)S.ld(b + CON_TYPE));
+    return sel(keep, S.ld(b + CON_D), 0.0);
   }
   template <bool OFF> MCG_DEV void solve_alone_impl() {
     derive(model());
@@ -952,7 +701,7 @@ struct CubeSys {
       for (int c = 0; __any(c < ncon); c++) {                    // pass A: mask (first iteration) + assembly
         CubeRows R; rows_cube(li<OFF>(c), R);
         const int b = LDS_CON + li<OFF>(c) * CON_STRIDE;
-        const real D = alone_D<OFF>(c), kterm = S.ld(b + 14);
+        const real D = alone_D<OFF>(c), kterm = S.ld(b + CON_KTERM);
         const int mask = (int)S.ld(LDS_ACT + c);
         real dv[4], da[4]; dots(R, Cb.vel, dv); dots(R, a, da);
         real W00 = 0, t0 = 0, W0[3], Wd[3], t[3];
@@ -989,7 +738,7 @@ struct CubeSys {
       for (int c = 0; __any(c < ncon); c++) {                    // pass B: consistency at x, line-search data
         CubeRows R; rows_cube(li<OFF>(c), R);
         const int b = LDS_CON + li<OFF>(c) * CON_STRIDE;
-        const real D = alone_D<OFF>(c), kterm = S.ld(b + 14);
+        const real D = alone_D<OFF>(c), kterm = S.ld(b + CON_KTERM);
         const bool mine = D != 0.0;                               // (an entry of this lane's list that is the cube's)
         const int mask = (int)S.ld(LDS_ACT + c);
         real dv[4], da[4], dp[4]; dots(R, Cb.vel, dv); dots(R, a, da); dots(R, p, dp);

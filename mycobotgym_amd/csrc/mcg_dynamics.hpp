@@ -386,7 +386,7 @@ typedef LaneScratchT<64> LaneScratch;
 // Coupling hook: PickAndPlace passes an object that, when a finger pad touches the cube, solves the robot and cube
 // accelerations together (the Euler step needs no constraint force: M a carries it).  Reach passes NoCoupling (compiled out).
 struct NoCoupling { static constexpr bool enabled = false, publishes = false; };
-struct NoSideWork { MCG_DEV void operator()(const real*, const real*) const {} MCG_DEV void numbers() const {} };      // what a helper / RNE wave does after its own share, before S1b
+struct NoSideWork { MCG_DEV void operator()(const real*, const real*) const {} };      // what a helper / RNE wave does after its own share
 // A hook with `publishes` (and not `enabled`) is handed the Newton system's smooth right-hand side and the limit rows once they are
 // complete: the four-wave PickAndPlace kernel parks them in LDS for the cooperative coupled solve (mcg_coop.hpp).
 
@@ -1092,7 +1092,6 @@ MCG_DEV bool robot_substep(ModelPtr Pm, Robot& S, real* qlag6, const LS MS, CPL*
 template <class SPL = SplitMain, class LS, class SIDE = NoSideWork>
 MCG_DEV void helper_substep(ModelPtr Pm, const LS MS, const SIDE& side = SIDE{}) {
   __syncthreads();                                                  // S1
-  if constexpr (SPL::mesh_split) MCG_TICK(ST_C_CHECK);
   real cs[NB], sn[NB];
   {
     const TrigC T = load_trig();
@@ -1101,9 +1100,9 @@ MCG_DEV void helper_substep(ModelPtr Pm, const LS MS, const SIDE& side = SIDE{})
   static_for<NB>([&](auto I) { constexpr int i = I; pin(sn[i]); pin(cs[i]); });
   MCG_FENCE();
   crb_to_lds(Pm, cs, sn, MS);
-  if constexpr (SPL::mesh_split) { MCG_TICK(ST_C_MASK); side(sn, cs); MCG_TICK(ST_C_ASSEMBLE); __syncthreads(); MCG_TICK(ST_C_SCHUR); __syncthreads(); side.numbers(); } // S1b, S1c, this wave's share of the solver numbers
+  static_assert(!SPL::mesh_split, "the four-wave PickAndPlace kernel drives its side waves itself: helper_pre / rne_pre");
+  (void)side;
   __syncthreads();                                                  // S2
-  if constexpr (SPL::mesh_split) MCG_TICK(ST_C_SOLVE);
   if constexpr (SPL::factor_remote) {
     const real h = launder(Pm)->timestep;
     real Mh[NB * (NB + 1) / 2], dinv[NB];
@@ -1121,7 +1120,6 @@ MCG_DEV void helper_substep(ModelPtr Pm, const LS MS, const SIDE& side = SIDE{})
 template <class SPL = SplitMain, class LS, class SIDE = NoSideWork>
 MCG_DEV void rne_substep(ModelPtr Pm, const LS MS, const SIDE& side = SIDE{}) {
   __syncthreads();                                                  // S1
-  if constexpr (SPL::mesh_split) MCG_TICK(ST_C_CHECK);
   real cs[NB], sn[NB], qd[NB], fs[NB];
   {
     const TrigC T = load_trig();
@@ -1131,10 +1129,47 @@ MCG_DEV void rne_substep(ModelPtr Pm, const LS MS, const SIDE& side = SIDE{}) {
   MCG_FENCE();
   rne_bias(Pm, cs, sn, qd, fs);
   static_for<NB>([&](auto I) { constexpr int i = I; MS.st(SPL::FS + i, fs[i]); });
-  if constexpr (SPL::mesh_split) { MCG_TICK(ST_C_MASK); side(sn, cs); MCG_TICK(ST_C_ASSEMBLE); __syncthreads(); MCG_TICK(ST_C_SCHUR); __syncthreads(); side.numbers(); } // S1b, S1c, this wave's share of the solver numbers
+  static_assert(!SPL::mesh_split, "the four-wave PickAndPlace kernel drives its side waves itself: helper_pre / rne_pre");
+  (void)side;
   __syncthreads();                                                  // S2
-  if constexpr (SPL::mesh_split) MCG_TICK(ST_C_SOLVE);
   if constexpr (SPL::factor_remote) __syncthreads();                // S3
+}
+
+// The same two shares for the four-wave PickAndPlace kernel, up to its barrier S1b: S1, the wave's own work (M into LDS / passive - bias
+// into LDS), then `side(sn, cs)` -- the broad phase of the arm meshes, from the sines / cosines the wave holds anyway.  The caller runs
+// the barriers S1b .. S5 and the phases between them (mcg_hip.hip: pnp_side_wave).
+template <class SPL, class LS, class SIDE>
+MCG_DEV void helper_pre(ModelPtr Pm, const LS MS, const SIDE& side) {
+  __syncthreads();                                                  // S1
+  MCG_TICK(ST_C_CHECK);
+  real cs[NB], sn[NB];
+  {
+    const TrigC T = load_trig();
+    static_for<NB>([&](auto I) { constexpr int i = I; sincos_cw(T, AXS[i] * MS.ld(SPL::QB + i), sn[i], cs[i]); });
+  }
+  static_for<NB>([&](auto I) { constexpr int i = I; pin(sn[i]); pin(cs[i]); });
+  MCG_FENCE();
+  crb_to_lds(Pm, cs, sn, MS);
+  MCG_TICK(ST_C_MASK);
+  side(sn, cs);
+  MCG_TICK(ST_C_ASSEMBLE);
+}
+template <class SPL, class LS, class SIDE>
+MCG_DEV void rne_pre(ModelPtr Pm, const LS MS, const SIDE& side) {
+  __syncthreads();                                                  // S1
+  MCG_TICK(ST_C_CHECK);
+  real cs[NB], sn[NB], qd[NB], fs[NB];
+  {
+    const TrigC T = load_trig();
+    static_for<NB>([&](auto I) { constexpr int i = I; sincos_cw(T, AXS[i] * MS.ld(SPL::QB + i), sn[i], cs[i]); qd[i] = MS.ld(SPL::QDB + i); });
+  }
+  static_for<NB>([&](auto I) { constexpr int i = I; pin(sn[i]); pin(cs[i]); });
+  MCG_FENCE();
+  rne_bias(Pm, cs, sn, qd, fs);
+  static_for<NB>([&](auto I) { constexpr int i = I; MS.st(SPL::FS + i, fs[i]); });
+  MCG_TICK(ST_C_MASK);
+  side(sn, cs);
+  MCG_TICK(ST_C_ASSEMBLE);
 }
 
 // ---------------------------------------------------------------------------------- world-frame arm kinematics

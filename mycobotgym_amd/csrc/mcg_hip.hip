@@ -18,6 +18,7 @@
 #include "mcg_cube.hpp"
 #include "mcg_coop.hpp"
 #include "model_gen.h"
+#include "polytopes_gen.h"
 
 using namespace mcg;
 
@@ -439,20 +440,26 @@ MCG_DEV void hide_object(real* obs, real* ag) {
 // The workgroup has four waves over the same 32 environments: ROBOT (the robot pipeline, speculatively: results held back), CUBE
 // (owns the cube for the whole env-step), M (composite rigid bodies) and RNE (bias forces), as in the Reach kernel.  Barriers per
 // sub-step:
-//   S1  q(t), qd(t) of the robot are published         (the cube wave needs the pads' pose for the collision pass)
-//   S1b the M / RNE waves have staged the arm-mesh contacts (they test the eight arm meshes against the table / the ground after their own
-//       share, four each, while the cube wave collides the primitive geoms); the cube wave merges them in front of its own
-//   S2  M, passive - bias, the collision results and each lane's FLAG (a contact reaches the robot) are published
+//   S1  q(t), qd(t) of the robot are published         (the cube wave needs the joint frames for the collision pass)
+//   S1b the lane-parallel part of the collision pass is done: the cube wave has the primitive geoms' contacts in the list and its share
+//       of the mesh geoms' candidate masks, the M / RNE waves theirs (the arm meshes against the table / the ground); M, bias forces
+//       are in LDS.  Then the MESH PHASE (mcg_mesh.hpp): the cube, M and RNE waves, 64 lanes each, take the environments that have
+//       candidates and run the exact narrow phase one pair at a time, appending to the lists
+//   S1c the lists are complete: the three waves share the per-contact solver numbers; the cube wave sets each lane's FLAG
+//   S2  M, passive - bias, the collision results and the flags are published
 //   S4  both sides are done; every wave reads the same flags
 //   S5  only when some lane is flagged: the cooperative coupled solves are done
 // Routing is PER ENVIRONMENT.  An unflagged lane commits: the robot wave its speculative sub-step, the cube wave its cube-alone solve.
 // A flagged lane's cube is left as it was and handed over in LDS, the robot wave parks the inputs of the coupled solve next to it
-// (PubHook, right after S2), and between S4 and S5 the four waves -- all idle at that point -- solve the flagged environments ONE
-// ENVIRONMENT PER WAVE (mcg_coop.hpp).  The robot wave then redoes the Euler step of its flagged lanes with the coupled acceleration,
-// the cube wave advances their cubes with theirs.  (Round 2 ran the whole wave through a lane-parallel coupled sub-step whenever one
-// lane was flagged: 17 contact-free sub-steps' worth of time for one touching environment.)
+// (PubHook, right after S2), and between S4 and S5 the four waves -- all idle at that point -- solve the flagged environments, one
+// environment per 32 lanes (mcg_coop.hpp).  The robot wave then redoes the Euler step of its flagged lanes with the coupled
+// acceleration, the cube wave advances their cubes with theirs.
+// mj_checkPos / mj_checkVel / mj_checkAcc (every mj_step: mycobot.py:170,189,193) ride on values the waves exchange anyway: the robot
+// wave leaves its verdict on the state it has just produced in XCH_T1 (the cube wave reads it with q(t) after S1 and resets the cube),
+// the cube wave adds its verdict on the cube as bit 3 of the flag it publishes before S2 (the robot wave reads the flag after S4 and
+// resets the robot's new state).  mj_resetData resets BOTH bodies; the other body follows one sub-step late here.
 // Exchange slots: mcg_coop.hpp.
-constexpr int XCH_FS = PNP_SLOTS;                 // 12 more slots: 640 x 32 lanes x 8 B = the CU's 160 KB exactly
+constexpr int XCH_FS = PNP_SLOTS;                 // + 12 slots
 constexpr int PNP_SLOTS_DUAL = PNP_SLOTS + NB;
 static_assert(PNP_SLOTS_DUAL * PNP_LANES * 8 <= 160 * 1024, "LDS of a CU");
 // robot-side split of the four-wave PickAndPlace kernel: M from the helper wave, passive - bias from the RNE wave, the constraint
@@ -460,12 +467,15 @@ static_assert(PNP_SLOTS_DUAL * PNP_LANES * 8 <= 160 * 1024, "LDS of a CU");
 struct SplitPnp { static constexpr bool enabled = true, rne_remote = true, factor_remote = false, early_heq = true, warm_lds = false, mesh_split = true;
                   static constexpr int QB = XCH_Q, QDB = XCH_QD, FS = XCH_FS, WARM = 0, QLAG = 0; };
 
+MCG_DEV bool flag_coupled(real f) { return (((int)f) & 2) != 0; }       // XCH_FLAG: bit 1 = the environment goes to the cooperative solve,
+MCG_DEV bool flag_cube_bad(real f) { return (((int)f) & 8) != 0; }      // bit 3 = the cube failed mj_checkPos / mj_checkVel / mj_checkAcc
+
 // the robot wave's hook into robot_substep: park a flagged lane's Newton inputs in its own column of the row area
 struct PubHook {
   static constexpr bool enabled = false, publishes = true;
   const PnpScratch S;
   MCG_DEV void publish(const real* g0, const real* Dl, const real* arefl, const real* sgl, const real* qd, const real* warm) const {
-    const bool flag = S.ld(XCH_FLAG) != 0.0;                         // the cube wave wrote it before S2
+    const bool flag = flag_coupled(S.ld(XCH_FLAG));                  // the cube wave wrote it before S2
     if (__any(flag)) {                                               // wave-uniform
       if (flag) {                                                    // plain LDS stores of live registers
         static_for<NB>([&](auto I) { constexpr int k = I; S.st(PUB_G0 + k, g0[k]); S.st(PUB_WARM + k, warm[k]); });      // (qd(t) is in its exchange slots)
@@ -485,14 +495,22 @@ MCG_DEV void cube_from_lds(const PnpScratch MS, Cube& Cb) {
   for (int k = 0; k < 4; k++) Cb.quat[k] = MS.ld(XCH_CB + 3 + k);
   for (int k = 0; k < 6; k++) { Cb.vel[k] = MS.ld(XCH_CB + 7 + k); Cb.warm[k] = MS.ld(XCH_CB + 13 + k); }
 }
-MCG_DEV unsigned flagged_lanes(const PnpScratch MS) { return (unsigned)__ballot(MS.ld(XCH_FLAG) != 0.0); }      // the same in all four waves
+// the flagged lanes, the same in all four waves; nvalid: the workgroup's real environments (a ragged last workgroup's surplus lanes
+// shadow the last environment: same arithmetic, but they are never handed out, counted or stored)
+MCG_DEV unsigned flagged_lanes(const PnpScratch MS, int nvalid) {
+  return (unsigned)__ballot(flag_coupled(MS.ld(XCH_FLAG))) & (nvalid >= 32 ? 0xFFFFFFFFu : ((1u << nvalid) - 1u));
+}
+MCG_DEV LdsCtrPtr mesh_counter(unsigned lds0) { return (LdsCtrPtr)(uintptr_t)(lds0 + (COOP_CTR_SLOT * PNP_LANES + MESH_CTR_LANE) * 8); }
+MCG_DEV LdsPtr wave_workspace(unsigned lds0, int w) { return (LdsPtr)(uintptr_t)lds0 + COOP_WS_ROW * PNP_LANES + w * COOP_WS_DOUBLES; }
 
-// the cube wave's whole env-step.  `lower`: lanes 0-31 carry the 32 environments; lanes 32-63 are alive for the cooperative phase only
-struct CubeWaveArgs { real qpos0_cube[7]; unsigned long long* cnt; int coop_pair; };
-// (inlined into the kernel, the cooperative phase inlined into it: the wave's own state across the phase is the cube, 30 numbers)
-MCG_DEV void cube_wave(const CubeWaveArgs& C, const View& V, ModelPtr P, const PnpScratch MS, unsigned lds0, int i, int total, bool lower) {
+// the cube wave's whole env-step.  `lower`: lanes 0-31 carry the 32 environments; lanes 32-63 are alive for the mesh phase and the
+// cooperative phase only
+struct CubeWaveArgs { real qpos0_cube[7]; unsigned long long* cnt; int coop_pair; int nvalid; };
+// (inlined into the kernel, the two phases inlined into it: the wave's own state across them is the cube system)
+MCG_DEV void cube_wave(const CubeWaveArgs& C, const View& V, ModelPtr P, const real* __restrict__ poly, const PnpScratch MS, unsigned lds0, int i, int total, bool lower) {
   Cube Cb; real dr[2], qlag7[7];
   bool touch = false;
+  const bool valid = (int)(threadIdx.x & (PNP_LANES - 1)) < C.nvalid;
   if (lower) {
     for (int k = 0; k < 3; k++) Cb.pos[k] = V.qpos(12 + k, i);
     for (int k = 0; k < 4; k++) Cb.quat[k] = V.qpos(15 + k, i);
@@ -504,40 +522,46 @@ MCG_DEV void cube_wave(const CubeWaveArgs& C, const View& V, ModelPtr P, const P
   for (int s = 0; s < total; s++) {
     CubeSys<PnpScratch> CS(MS, Cb, dr);
     int kind = 0;
+    bool cbad = false;
     if (lower) {
       __syncthreads();                                              // S1 (a wave passes a barrier once, whatever its lanes do)
       MCG_TICK2(ST_W2_WAIT1);
-      real q10[10];
-      static_for<10>([&](auto I) { constexpr int k = I; q10[k] = MS.ld(XCH_Q + k); });
-      if (s == 0) { // mj_checkPos / mj_checkVel for the cube on the state this env-step starts from; the robot wave reports its own verdict
-                    // (mj_resetData resets both bodies).  Per ENV-STEP here, per sub-step in the Reach kernels: in this kernel the two
-                    // checks and their exchange cost 6.5 % of the resting-cube step (A/B in one GPU call, 0.455 against 0.427 ms).
-        bool cbad = false;
+      real q12[NB];
+      static_for<NB>([&](auto I) { constexpr int k = I; q12[k] = MS.ld(XCH_Q + k); });
+      const bool rbad = MS.ld(XCH_T1) != 0.0;                       // the robot wave's verdict on the state it published (same batch of LDS reads)
+      {   // mj_checkPos / mj_checkVel / mj_checkAcc for the cube, every sub-step: the state this sub-step starts from (the acceleration the
+          // last one ended with is its warm start); the robot wave's verdict resets the cube with it (mj_resetData resets both bodies)
         for (int k = 0; k < 3; k++) cbad = cbad || bad_value(Cb.pos[k]);
         for (int k = 0; k < 4; k++) cbad = cbad || bad_value(Cb.quat[k]);
         for (int k = 0; k < 6; k++) cbad = cbad || bad_value(Cb.vel[k]) || bad_value(Cb.warm[k]);
-        const bool reset = cbad || MS.ld(XCH_T1) != 0.0;
+        const bool reset = cbad || rbad;
         if (__any(reset)) {                                         // wave-uniform; rare
           for (int k = 0; k < 3; k++) Cb.pos[k] = sel(reset, C.qpos0_cube[k], Cb.pos[k]);
           for (int k = 0; k < 4; k++) Cb.quat[k] = sel(reset, C.qpos0_cube[3 + k], Cb.quat[k]);
           for (int k = 0; k < 6; k++) { Cb.vel[k] = sel(reset, 0.0, Cb.vel[k]); Cb.warm[k] = sel(reset, 0.0, Cb.warm[k]); }
           CS.Cb = Cb;
+          if (__any(cbad)) { if (cbad && valid && C.cnt) atomicAdd(C.cnt + 1, 1ull); }
         }
-        MS.st(XCH_BADC, cbad ? 1.0 : 0.0);
-        if (__any(cbad)) { if (cbad && C.cnt) atomicAdd(C.cnt + 1, 1ull); }
       }
-      CS.cnt = C.cnt;
-      CS.template prepare<true>(P, q10);                           // S1b inside: the M / RNE waves' arm-mesh contacts are merged in
-      touch = CS.touch[0] && CS.touch[1];
+      CS.cnt = valid ? C.cnt : nullptr;
+      CS.template collide_primitives<true, false>(P, q12);          // the primitive geoms' contacts; candidate pairs of the mesh geoms
       MCG_TICK2(ST_W2_COLLIDE);
-      // 0: nothing reaches the robot | 2: a contact does (pad / finger link / gripper base on the cube, pad or arm mesh on the table or the
-      // ground): the environment's 18 dofs go to the cooperative solve.  (1 was round 3's opt-in robot-only routing: measured, no gain, removed.)
-      kind = CS.any_pad ? 2 : 0;
-      MS.st(XCH_FLAG, (real)kind);
+    }
+    __syncthreads();                                                // S1b
+    mesh_phase(P, poly, (LdsPtr)(uintptr_t)lds0, wave_workspace(lds0, 1), mesh_counter(lds0));
+    __syncthreads();                                                // S1c: every list is complete
+    if (lower) {
+      CS.collect_list();
+      touch = CS.touch[0] && CS.touch[1];
+      // 0: nothing reaches the robot | 2: a contact does (a pad or a mesh on the cube, the table or the ground), or the cube's own list is
+      // longer than its solve's row slots: the environment's 18 dofs go to the cooperative solve
+      kind = (CS.any_pad || CS.ncon > ROW_SLOTS / 12) ? 2 : 0;
+      MS.st(XCH_FLAG, (real)(kind + (cbad ? 8 : 0)));
       if (__any(kind != 0)) {
-        if ((threadIdx.x & 63) == 0 && C.cnt) atomicAdd(C.cnt + 3, (unsigned long long)__popc((unsigned)__ballot(kind != 0)));
+        if ((threadIdx.x & 63) == 0 && C.cnt) atomicAdd(C.cnt + 3, (unsigned long long)__popc((unsigned)__ballot(kind != 0 && valid)));
         if (kind != 0) { MS.st(XCH_NCON, (real)CS.ncon); MS.st(XCH_DR, dr[0]); MS.st(XCH_DR + 1, dr[1]); cube_to_lds(MS, CS.Cb); }      // hand the (normalised, not advanced) cube over
       }
+      solver_numbers_share(P, MS, dr[1], 0);
       __syncthreads();                                              // S2 (the robot side's "M and bias ready")
       CS.solve_alone(kind == 2, false);                             // flagged lanes walk an empty list, store nothing
       if (!__any(kind == 2)) { CS.finish(qlag7); Cb = CS.Cb; }
@@ -545,7 +569,7 @@ MCG_DEV void cube_wave(const CubeWaveArgs& C, const View& V, ModelPtr P, const P
     }
     __syncthreads();                                                // S4: end of the lane-parallel part
     MCG_TICK2(ST_W2_WAIT2);
-    const unsigned mask = flagged_lanes(MS);                        // all 64 lanes from here (the upper half reads the lower half's columns)
+    const unsigned mask = flagged_lanes(MS, C.nvalid);              // all 64 lanes from here (the upper half reads the lower half's columns)
     if (mask != 0u) {
       coop_phase_body(P, (LdsPtr)(uintptr_t)lds0, __builtin_amdgcn_readfirstlane(mask), 1, C.coop_pair != 0 ? 1 : 0);
       MCG_TICK2(ST_COUPLED);
@@ -567,16 +591,20 @@ MCG_DEV void cube_wave(const CubeWaveArgs& C, const View& V, ModelPtr P, const P
 
 // the robot wave's sub-step
 template <class WLD>
-MCG_DEV bool pnp_substep_robot(const Cfg& C, ModelPtr P, EnvP& E, const PnpScratch MS, unsigned lds0, const WLD& W, bool first) {
+MCG_DEV bool pnp_substep_robot(const Cfg& C, ModelPtr P, EnvP& E, const PnpScratch MS, unsigned lds0, const WLD& W, int nvalid) {
   Robot nx;
   PubHook hook{MS};
-  robot_substep<PnpScratch, PubHook, WLD, SplitPnp, false>(P, E.R, E.qlag6, MS, &hook, &W, &nx);     // S1, S2 inside
+  robot_substep<PnpScratch, PubHook, WLD, SplitPnp, false>(P, E.R, E.qlag6, MS, &hook, &W, &nx);     // S1, S1b, S1c, S2 inside
   MCG_TICK(ST_POST);
-  if ((threadIdx.x & 63) == 0) *(__attribute__((address_space(3))) unsigned*)(uintptr_t)(lds0 + COOP_CTR_SLOT * PNP_LANES * 8) = 0u;      // the cooperative phase's hand-out counter
+  if ((threadIdx.x & 63) == 0) {       // the hand-out counters of the cooperative phase (this sub-step) and of the mesh phase (the next)
+    *(LdsCtrPtr)(uintptr_t)(lds0 + COOP_CTR_SLOT * PNP_LANES * 8) = 0u;
+    *mesh_counter(lds0) = 0u;
+  }
   __syncthreads();                                                  // S4
   MCG_TICK(ST_W1_WAIT);
-  const bool flag = MS.ld(XCH_FLAG) != 0.0;
-  const unsigned mask = (unsigned)__ballot(flag);
+  const real fl = MS.ld(XCH_FLAG);
+  const bool flag = flag_coupled(fl);
+  const unsigned mask = (unsigned)__ballot(flag) & (nvalid >= 32 ? 0xFFFFFFFFu : ((1u << nvalid) - 1u));
   if (mask != 0u) {                                                 // wave-uniform, the same in all four waves
     // one environment at a time here, two in the other three waves; with fewer flagged environments than a round of the workgroup takes
     // this wave has no share (its rank-fixed share is every COOP_ROBOT_EVERY-th) and does not pay the call
@@ -594,48 +622,49 @@ MCG_DEV bool pnp_substep_robot(const Cfg& C, ModelPtr P, EnvP& E, const PnpScrat
       nx.qd[k] = sel(flag, qd_new, nx.qd[k]); nx.q[k] = sel(flag, q_new, nx.q[k]); nx.warm[k] = a[k]; });
     MCG_TICK(ST_EULER);
   }
-  // the cube wave's verdict on the cube this env-step started with (mj_resetData resets the robot with it; one sub-step late here),
-  // and mj_checkPos / mj_checkVel / mj_checkAcc on the robot's new state -- in the env-step's first sub-step only (see cube_wave)
+  // mj_checkPos / mj_checkVel / mj_checkAcc on the robot's new state, every sub-step (the state the next mj_step would check first), and
+  // the cube wave's verdict on the cube this sub-step started with (bit 3 of the flag: mj_resetData resets the robot with it)
   bool bad = false;
-  if (first) {
-  bad = MS.ld(XCH_BADC) != 0.0;
   static_for<NB>([&](auto I) { constexpr int k = I; bad = bad || bad_value(nx.q[k]) || bad_value(nx.qd[k]) || bad_value(nx.warm[k]); });
-  if (__any(bad)) {                                                 // wave-uniform; rare: mj_resetData
-    static_for<NB>([&](auto I) { constexpr int k = I; nx.q[k] = sel(bad, 0.0, nx.q[k]); nx.qd[k] = sel(bad, 0.0, nx.qd[k]); nx.warm[k] = sel(bad, 0.0, nx.warm[k]); });
-    static_for<7>([&](auto I) { constexpr int k = I; E.R.ctrl[k] = sel(bad, 0.0, E.R.ctrl[k]); });
+  const bool reset = bad || flag_cube_bad(fl);
+  if (__any(reset)) {                                               // wave-uniform; rare: mj_resetData
+    static_for<NB>([&](auto I) { constexpr int k = I; nx.q[k] = sel(reset, 0.0, nx.q[k]); nx.qd[k] = sel(reset, 0.0, nx.qd[k]); nx.warm[k] = sel(reset, 0.0, nx.warm[k]); });
+    static_for<7>([&](auto I) { constexpr int k = I; E.R.ctrl[k] = sel(reset, 0.0, E.R.ctrl[k]); });
   }
-  }
+  MS.st(XCH_T1, bad ? 1.0 : 0.0);                                   // for the cube wave, read after the next S1
   static_for<NB>([&](auto I) { constexpr int k = I; E.R.q[k] = nx.q[k]; E.R.qd[k] = nx.qd[k]; E.R.warm[k] = nx.warm[k];
                                MS.st(XCH_Q + k, nx.q[k]); MS.st(XCH_QD + k, nx.qd[k]); });
   (void)C;
-  return bad;
+  return reset;
 }
 
-// the helper / RNE waves of the four-wave PickAndPlace kernel: same barriers as the cube wave; lanes 32-63 are alive for the
-// cooperative phase only
-// (inlined into the kernel: these waves hold nothing across a sub-step, so the inlined cooperative phase spills nothing)
-// what a side wave does between S1 and S2 besides its own share: four arm meshes (staged for S1b), then its third of the solver numbers
-template <int P0, int P1> struct PnpSideWork {
-  ModelPtr P; const PnpScratch MS; int base, count_slot; real dr1; int share;
-  MCG_DEV void operator()(const real* sn, const real* cs) const { arm_mesh_stage<P0, P1>(P, MS, sn, cs, base, count_slot); }
-  MCG_DEV void numbers() const { solver_numbers_share(P, MS, dr1, share); }
+// the helper / RNE waves of the four-wave PickAndPlace kernel: same barriers as the cube wave; lanes 32-63 are alive for the mesh phase
+// and the cooperative phase only
+// (inlined into the kernel: these waves hold nothing across a sub-step, so the inlined phases spill nothing)
+// what a side wave does between S1 and S1b besides its own share: the broad phase of four arm meshes against the table / the ground;
+// the M wave also parks the sines / cosines for the mesh phase's forward kinematics
+template <int P0, int P1, bool PARK> struct PnpSideWork {
+  ModelPtr P; const PnpScratch MS; int mask_slot;
+  MCG_DEV void operator()(const real* sn, const real* cs) const {
+    if constexpr (PARK) static_for<NB>([&](auto I) { constexpr int k = I; MS.st(MP_SN + k, sn[k]); MS.st(MP_CS + k, cs[k]); });
+    arm_broad_stage<P0, P1>(P, MS, sn, cs, mask_slot);
+  }
 };
-MCG_DEV void pnp_side_wave(ModelPtr P, const PnpScratch MS, unsigned lds0, int total, bool rne, bool lower, bool pair, real dr1) {
+MCG_DEV void pnp_side_wave(ModelPtr P, const real* __restrict__ poly, const PnpScratch MS, unsigned lds0, int total, bool rne, bool lower, bool pair, real dr1, int nvalid) {
   MCG_TICK_INIT();
   for (int s = 0; s < total; s++) {
-    // S1, S1b, S2 inside; after its own share each wave tests four of the arm meshes against the table / the ground (mcg_cube.hpp)
-    if (lower) {
-#if MCG_DUP == 2      // critical-path probe: the four meshes twice (the second pass stores the same records again)
-      if (rne) rne_substep<SplitPnp>(P, MS, [&](const real* sn, const real* cs) { arm_mesh_stage<4, 8>(P, MS, sn, cs, STAGE_B, STAGE_NB); MCG_FENCE(); arm_mesh_stage<4, 8>(P, MS, sn, cs, STAGE_B, STAGE_NB); });
-      else helper_substep<SplitPnp>(P, MS, [&](const real* sn, const real* cs) { arm_mesh_stage<0, 4>(P, MS, sn, cs, STAGE_A, STAGE_NA); MCG_FENCE(); arm_mesh_stage<0, 4>(P, MS, sn, cs, STAGE_A, STAGE_NA); });
-#else
-      if (rne) rne_substep<SplitPnp>(P, MS, PnpSideWork<4, 8>{P, MS, STAGE_B, STAGE_NB, dr1, 2});
-      else helper_substep<SplitPnp>(P, MS, PnpSideWork<0, 4>{P, MS, STAGE_A, STAGE_NA, dr1, 1});
-#endif
+    if (lower) {                                                    // S1 inside; its own share, then the arm meshes' broad phase
+      if (rne) rne_pre<SplitPnp>(P, MS, PnpSideWork<4, 8, false>{P, MS, MP_MASK + 1});
+      else helper_pre<SplitPnp>(P, MS, PnpSideWork<0, 4, true>{P, MS, MP_MASK});
     }
+    __syncthreads();                                                // S1b
+    mesh_phase(P, poly, (LdsPtr)(uintptr_t)lds0, wave_workspace(lds0, rne ? 3 : 2), mesh_counter(lds0));
+    __syncthreads();                                                // S1c
+    if (lower) solver_numbers_share(P, MS, dr1, rne ? 2 : 1);
+    __syncthreads();                                                // S2
     __syncthreads();                                                // S4
     MCG_TICK(ST_C_LS);
-    const unsigned mask = flagged_lanes(MS);
+    const unsigned mask = flagged_lanes(MS, nvalid);
     if (mask != 0u) {
       coop_phase_body(P, (LdsPtr)(uintptr_t)lds0, __builtin_amdgcn_readfirstlane(mask), rne ? 3 : 2, pair ? 1 : 0);
       __syncthreads();                                              // S5
@@ -646,7 +675,7 @@ MCG_DEV void pnp_side_wave(ModelPtr P, const PnpScratch MS, unsigned lds0, int t
 }
 
 template <int CONTROLLER>
-__global__ __launch_bounds__(256) void step_pnp_kernel(Cfg C, View V, const mcg_model* __restrict__ Pg,
+__global__ __launch_bounds__(256) void step_pnp_kernel(Cfg C, View V, const mcg_model* __restrict__ Pg, const real* __restrict__ poly,
                                                        const float* __restrict__ actions, mcg_step_out O) {
   constexpr bool DUAL = true;                    // (the one-wave variant of rounds 1-2 went with the lane-parallel coupled solve)
   __shared__ __attribute__((aligned(16))) real lds[PNP_SLOTS_DUAL][PNP_LANES];
@@ -658,18 +687,20 @@ __global__ __launch_bounds__(256) void step_pnp_kernel(Cfg C, View V, const mcg_
   const PnpScratch MS(&lds[0][lane]);
   const ModelPtr P = as_model_ptr(Pg);
   const int i_raw = blockIdx.x * PNP_LANES + lane;
-  // every wave keeps its 32 lanes (the cooperative coupled solve works with all of them); in a ragged last workgroup the surplus
-  // lanes shadow the last environment: same inputs, same instruction stream, the same values stored to the same places
+  // every wave keeps its 32 lanes (the cooperative phases work with all of them); in a ragged last workgroup the surplus lanes shadow
+  // the last environment -- same inputs, same instruction stream -- but are never handed out, counted or stored (`valid`)
   const int i = (i_raw >= C.n) ? C.n - 1 : i_raw;
+  const bool valid = i_raw < C.n;
+  const int nvalid = min(PNP_LANES, C.n - (int)blockIdx.x * PNP_LANES);
   const unsigned lds0 = (unsigned)(uintptr_t)(LdsPtr)&lds[0][0];
   if constexpr (DUAL) {
     if (threadIdx.x >= 64) {
       const int total = (CONTROLLER == MCG_CTRL_IK ? C.control_steps : 1) * C.frame_skip;
       if (threadIdx.x < 128) {
         CubeWaveArgs A; for (int k = 0; k < 7; k++) A.qpos0_cube[k] = C.qpos0_cube[k];
-        A.cnt = C.cnt; A.coop_pair = C.coop_pair;
-        cube_wave(A, V, P, MS, lds0, i, total, lower);
-      } else pnp_side_wave(P, MS, lds0, total, threadIdx.x >= 192, lower, C.coop_pair != 0, lower ? V.dr(1, i) : 1.0);
+        A.cnt = C.cnt; A.coop_pair = C.coop_pair; A.nvalid = nvalid;
+        cube_wave(A, V, P, poly, MS, lds0, i, total, lower);
+      } else pnp_side_wave(P, poly, MS, lds0, total, threadIdx.x >= 192, lower, C.coop_pair != 0, lower ? V.dr(1, i) : 1.0, nvalid);
       return;
     }
   }
@@ -683,11 +714,12 @@ __global__ __launch_bounds__(256) void step_pnp_kernel(Cfg C, View V, const mcg_
   bool hadbad = bad0;
   if constexpr (DUAL) { static_for<NB>([&](auto I) { constexpr int k = I; MS.st(XCH_Q + k, E.R.q[k]); MS.st(XCH_QD + k, E.R.qd[k]); });   // q(0), qd(0) for the other waves
                         MS.st(XCH_T1, hadbad ? 1.0 : 0.0);
-                        MS.st(XCH_ACT0, 0.0); MS.st(XCH_ACT1, 0.0); }       // no active set carried into an env-step (mcg_coop.hpp: coop_guess)
+                        MS.st(XCH_ACT0, 0.0); MS.st(XCH_ACT1, 0.0);         // no active set carried into an env-step (mcg_coop.hpp: coop_guess)
+                        if (threadIdx.x == 0) *mesh_counter(lds0) = 0u; }
   MCG_TICK(ST_LOAD);
   E.touch = false;
   int nsub = 0;
-  auto substep = [&](const auto& W) { hadbad |= pnp_substep_robot(C, P, E, MS, lds0, W, nsub == 0); nsub++; };
+  auto substep = [&](const auto& W) { hadbad |= pnp_substep_robot(C, P, E, MS, lds0, W, nvalid); nsub++; };
   float act[8];
   _Pragma("unroll") for (int k = 0; k < 8; k++) {   // act_dim is 7, 4 (fetch) or 8 (mocap): static indices keep the array in registers
     const float x = (k < C.act_dim) ? actions[(size_t)i * C.act_dim + (k < C.act_dim ? k : 0)] : 0.f;
@@ -733,7 +765,7 @@ __global__ __launch_bounds__(256) void step_pnp_kernel(Cfg C, View V, const mcg_
     E.touch = MS.ld(XCH_T0) != 0.0;
   }
   hadbad |= guard_robot(E.R, E.qlag6);
-  count_event(C, 1, hadbad);
+  count_event(C, 1, hadbad && valid);
   int i_tail = i; asm volatile("" : "+v"(i_tail));      // recompute the state rows' addresses for the tail (see step_reach_kernel)
   load_episodep(V, i_tail, E);
   {   // same guard for the cube: back to its model pose at rest
@@ -749,7 +781,8 @@ __global__ __launch_bounds__(256) void step_pnp_kernel(Cfg C, View V, const mcg_
     E.R.q[7] = 0; E.R.q[9] = 0;
     for (int k = 0; k < 6; k++) E.qlag6[k] = E.R.q[k];
     CubeSys<PnpScratch> CS(MS, E.Cb, E.dr);
-    CS.prepare(P, E.R.q);
+    CS.template collide_primitives<false, false>(P, E.R.q);          // (stage_rewards reads the pads' contacts with the cube: primitive pairs)
+    CS.scan_list();
     E.Cb = CS.Cb;
     for (int k = 0; k < 3; k++) E.qlag7[k] = E.Cb.pos[k];
     for (int k = 0; k < 4; k++) E.qlag7[3 + k] = E.Cb.quat[k];
@@ -777,15 +810,17 @@ __global__ __launch_bounds__(256) void step_pnp_kernel(Cfg C, View V, const mcg_
   rew = sel(C.reward_type == MCG_REWARD_SHAPING, rew_shaped, rew);
   E.elapsed++; E.eplen++; E.epret += rew;
   const bool term = succ, trunc = succ || (E.elapsed >= C.max_episode_steps);
-  if (O.reward) O.reward[i] = rew;
-  if (O.terminated) O.terminated[i] = term;
-  if (O.truncated) O.truncated[i] = trunc;
-  if (O.is_success) O.is_success[i] = succ;
-  if (O.ep_return) O.ep_return[i] = E.epret;
-  if (O.ep_length) O.ep_length[i] = E.eplen;
+  if (valid) {                                                      // (a ragged last workgroup's shadow lanes store nothing)
+    if (O.reward) O.reward[i] = rew;
+    if (O.terminated) O.terminated[i] = term;
+    if (O.truncated) O.truncated[i] = trunc;
+    if (O.is_success) O.is_success[i] = succ;
+    if (O.ep_return) O.ep_return[i] = E.epret;
+    if (O.ep_length) O.ep_length[i] = E.eplen;
+  }
   const bool done = (term || trunc) && C.auto_reset;
   if (__any(done)) {
-    if (done) {
+    if (done && valid) {
       if (O.final_obs) for (int k = 0; k < 25; k++) if (k < D) O.final_obs[(size_t)i * D + k] = obs[k];
       if (O.final_achieved) for (int k = 0; k < 3; k++) O.final_achieved[(size_t)i * 3 + k] = ag[k];
       if (O.final_desired) for (int k = 0; k < 3; k++) O.final_desired[(size_t)i * 3 + k] = E.goal[k];
@@ -797,8 +832,7 @@ __global__ __launch_bounds__(256) void step_pnp_kernel(Cfg C, View V, const mcg_
     for (int k = 0; k < 25; k++) obs[k] = sel(done, obs2[k], obs[k]);
     for (int k = 0; k < 3; k++) ag[k] = sel(done, ag2[k], ag[k]);
   }
-  write_obs(O, i, D, obs, ag, E.goal);
-  store_envp(V, i_tail, E);
+  if (valid) { write_obs(O, i, D, obs, ag, E.goal); store_envp(V, i_tail, E); }
   MCG_TICK(ST_POST);
 #ifdef MCG_STAGE_CLOCKS
   if (threadIdx.x == 0) g_wg_stat[(blockIdx.x & 4095) * 4] += __builtin_readcyclecounter() - wg_t0;
@@ -823,34 +857,46 @@ __global__ __launch_bounds__(PNP_LANES) void reset_pnp_kernel(Cfg C, View V, con
   write_obs(O, i, C.obs_dim, obs, ag, E.goal);
 }
 
-// TEST / DEBUG (mcg_debug_contacts): the collision pass of the current state, exported as the step kernels see it
-__global__ __launch_bounds__(PNP_LANES) void contacts_pnp_kernel(Cfg C, View V, const mcg_model* __restrict__ Pg, int32_t* __restrict__ count,
-                                                                 int32_t* __restrict__ dropped, double* __restrict__ data) {
-  __shared__ real lds[PNP_SLOTS][PNP_LANES];
-  const int lane = threadIdx.x;
-  const int i = blockIdx.x * PNP_LANES + lane;
-  if (i >= C.n) return;
+// TEST / DEBUG (mcg_debug_contacts): the collision pass of the current state, exported as the step kernels see it.  One wave of 64 lanes
+// per 32 environments: lanes 0-31 the lane-parallel part (the cube wave's and the M / RNE waves' shares), all 64 the mesh phase.
+__global__ __launch_bounds__(64) void contacts_pnp_kernel(Cfg C, View V, const mcg_model* __restrict__ Pg, const real* __restrict__ poly, int32_t* __restrict__ count,
+                                                          int32_t* __restrict__ dropped, double* __restrict__ data) {
+  __shared__ real lds[PNP_SLOTS_DUAL][PNP_LANES];
+  const int lane = threadIdx.x & (PNP_LANES - 1);
+  const bool lower = threadIdx.x < PNP_LANES;
+  const int i_raw = blockIdx.x * PNP_LANES + lane;
+  const int i = i_raw >= C.n ? C.n - 1 : i_raw;
   const PnpScratch MS(&lds[0][lane]);
   const ModelPtr P = as_model_ptr(Pg);
+  const unsigned lds0 = (unsigned)(uintptr_t)(LdsPtr)&lds[0][0];
   EnvP E;
   load_envp(V, i, E);
-  // the multiplicities are replaced by D when prepare() ends: list them first from a pass of their own
   CubeSys<PnpScratch> CS(MS, E.Cb, E.dr);
-  unsigned long long drop_before = 0;
   CS.cnt = nullptr;
-  CS.prepare(P, E.R.q);
-  (void)drop_before;
+  if (lower) {
+    const TrigC T = load_trig();
+    static_for<NB>([&](auto I) { constexpr int k = I; real sn_, cs_; sincos_cw(T, AXS[k] * E.R.q[k], sn_, cs_); MS.st(MP_SN + k, sn_); MS.st(MP_CS + k, cs_); });
+    CS.template collide_primitives<true, true>(P, E.R.q);
+  }
+  __syncthreads();
+  mesh_phase(P, poly, (LdsPtr)(uintptr_t)lds0, wave_workspace(lds0, 0), (LdsCtrPtr)nullptr);
+  __syncthreads();
+  if (!lower || i_raw >= C.n) return;
+  CS.collect_list();
   count[i] = CS.ncon;
   if (dropped) dropped[i] = CS.ndropped;
+  real mult[MAXCON];
+  for (int c = 0; c < MAXCON; c++) mult[c] = c < CS.ncon ? MS.ld(LDS_CON + c * CON_STRIDE + CON_D) : 0.0;      // the multiplicities, before the numbers replace them
+  for (int r = 0; r < 3; r++) solver_numbers_share(P, MS, E.dr[1], r);
   for (int c = 0; c < MAXCON; c++) {
     const int b = LDS_CON + c * CON_STRIDE;
     double* o = data + ((size_t)i * MAXCON + c) * 10;
     const bool on = c < CS.ncon;
-    o[0] = on ? MS.ld(b + 12) : 0.0;
+    o[0] = on ? MS.ld(b + CON_DIST) : 0.0;
     for (int k = 0; k < 3; k++) { o[1 + k] = on ? MS.ld(b + k) : 0.0; o[4 + k] = on ? MS.ld(b + 3 + k) : 0.0; }
-    o[7] = on ? MS.ld(b + 15) : -1.0;
-    o[8] = on ? CS.mult_of(c) : 0.0;
-    o[9] = on ? MS.ld(b + 13) : 0.0;
+    o[7] = on ? MS.ld(b + CON_TYPE) : -1.0;
+    o[8] = mult[c];
+    o[9] = on ? MS.ld(b + CON_D) : 0.0;
   }
 }
 
@@ -886,6 +932,7 @@ struct mcg_env {
   Cfg cfg;
   View view;
   mcg_model* d_model;
+  double* d_poly;                 // the mesh geoms' collision tables (mcg_create: polytopes)
   unsigned long long* d_cnt;      // mcg_counters
   int device;
   int num_cu;
@@ -903,8 +950,9 @@ int mcg_default_model(int variant, mcg_model* out) {
   return MCG_OK;
 }
 
-int mcg_create(const mcg_config* c, const mcg_model* model, int device, mcg_env** out) {
+int mcg_create(const mcg_config* c, const mcg_model* model, const double* polytopes, int64_t n_polytopes, int device, mcg_env** out) {
   if (!c || !out) return fail(MCG_ERR_ARG, "mcg_create: null argument%s");
+  if (polytopes && n_polytopes < 8 * MCG_NMESH) return fail(MCG_ERR_ARG, "mcg_create: polytope block too short%s");
   if (c->n_envs <= 0) return fail(MCG_ERR_ARG, "mcg_create: n_envs must be positive%s");
   if (c->controller != MCG_CTRL_JOINT && c->controller != MCG_CTRL_IK && c->controller != MCG_CTRL_MOCAP) return fail(MCG_ERR_ARG, "mcg_create: controller must be joint, IK or mocap%s");
   {   // the mocap controller needs the model variant with the weld (and without arm actuators), the others the one without
@@ -975,6 +1023,21 @@ int mcg_create(const mcg_config* c, const mcg_model* model, int device, mcg_env*
   if (err == hipSuccess) err = hipMalloc(&e->view.i32, (size_t)3 * C.n * sizeof(int32_t));
   if (err == hipSuccess) err = hipMalloc(&e->d_model, sizeof(mcg_model));
   if (err == hipSuccess) err = hipMalloc(&e->d_cnt, sizeof(mcg_counters));
+  if (err == hipSuccess && C.has_object) {
+    const double* pb = polytopes ? polytopes : kDefaultPolytopes;
+    const size_t np = polytopes ? (size_t)n_polytopes : (size_t)MCG_DEFAULT_POLYTOPES_LEN;
+    // the block's own index must stay inside it (a kernel walks these offsets)
+    bool ok = true;
+    for (int m = 0; m < MCG_NMESH && ok; m++) {
+      const double* meta = pb + 8 * m;
+      const double end = meta[3] + 3 * meta[4] + 4 * meta[5] + 13 * meta[6];
+      ok = meta[0] >= 1 && meta[0] <= meta[4] && meta[1] <= meta[5] && meta[2] <= meta[6] && meta[3] >= 8 * MCG_NMESH && end <= (double)np
+           && ((long long)meta[4] % 64) == 0 && ((long long)meta[5] % 64) == 0 && ((long long)meta[6] % 64) == 0;
+    }
+    if (!ok) { mcg_destroy(e); return fail(MCG_ERR_ARG, "mcg_create: inconsistent polytope block%s"); }
+    err = hipMalloc(&e->d_poly, np * sizeof(double));
+    if (err == hipSuccess) err = hipMemcpy(e->d_poly, pb, np * sizeof(double), hipMemcpyHostToDevice);
+  }
   if (err == hipSuccess) err = hipMemset(e->d_cnt, 0, sizeof(mcg_counters));
   if (err == hipSuccess) C.cnt = e->d_cnt;
   if (err == hipSuccess) err = hipMemset(e->view.d, 0, nd * sizeof(double));
@@ -1000,6 +1063,7 @@ void mcg_destroy(mcg_env* e) {
   if (e->view.d) (void)hipFree(e->view.d);
   if (e->view.i32) (void)hipFree(e->view.i32);
   if (e->d_model) (void)hipFree(e->d_model);
+  if (e->d_poly) (void)hipFree(e->d_poly);
   if (e->d_cnt) (void)hipFree(e->d_cnt);
   delete e;
 }
@@ -1045,9 +1109,9 @@ static int launch_step(mcg_env* e, const float* actions, const mcg_step_out& o, 
     // four waves (robot, cube, M, RNE) over 32 environments at every grid size: the 160 KB of LDS allow one workgroup per CU either way
     dim3 grid((e->cfg.n + PNP_LANES - 1) / PNP_LANES);
     const dim3 block(256);
-    if (e->cfg.controller == MCG_CTRL_IK) hipLaunchKernelGGL((step_pnp_kernel<MCG_CTRL_IK>), grid, block, 0, s, e->cfg, e->view, e->d_model, actions, o);
-    else if (e->cfg.controller == MCG_CTRL_MOCAP) hipLaunchKernelGGL((step_pnp_kernel<MCG_CTRL_MOCAP>), grid, block, 0, s, e->cfg, e->view, e->d_model, actions, o);
-    else hipLaunchKernelGGL((step_pnp_kernel<MCG_CTRL_JOINT>), grid, block, 0, s, e->cfg, e->view, e->d_model, actions, o);
+    if (e->cfg.controller == MCG_CTRL_IK) hipLaunchKernelGGL((step_pnp_kernel<MCG_CTRL_IK>), grid, block, 0, s, e->cfg, e->view, e->d_model, e->d_poly, actions, o);
+    else if (e->cfg.controller == MCG_CTRL_MOCAP) hipLaunchKernelGGL((step_pnp_kernel<MCG_CTRL_MOCAP>), grid, block, 0, s, e->cfg, e->view, e->d_model, e->d_poly, actions, o);
+    else hipLaunchKernelGGL((step_pnp_kernel<MCG_CTRL_JOINT>), grid, block, 0, s, e->cfg, e->view, e->d_model, e->d_poly, actions, o);
     return hipGetLastError() == hipSuccess ? MCG_OK : MCG_ERR_HIP;
   }
   dim3 grid((e->cfg.n + 63) / 64);
@@ -1119,8 +1183,8 @@ int mcg_get_counters(mcg_env* e, mcg_counters* out, int clear) {
 int mcg_debug_contacts(mcg_env* e, int32_t* count, int32_t* dropped, double* data, void* stream) {
   if (!e || !count || !data) return fail(MCG_ERR_ARG, "mcg_debug_contacts: null argument%s");
   if (!e->cfg.has_object) return fail(MCG_ERR_UNSUPPORTED, "mcg_debug_contacts: Reach has no collision pass%s");
-  dim3 grid((e->cfg.n + PNP_LANES - 1) / PNP_LANES), block(PNP_LANES);
-  hipLaunchKernelGGL(contacts_pnp_kernel, grid, block, 0, (hipStream_t)stream, e->cfg, e->view, e->d_model, count, dropped, data);
+  dim3 grid((e->cfg.n + PNP_LANES - 1) / PNP_LANES), block(64);
+  hipLaunchKernelGGL(contacts_pnp_kernel, grid, block, 0, (hipStream_t)stream, e->cfg, e->view, e->d_model, e->d_poly, count, dropped, data);
   HIP_OK(hipGetLastError());
   return MCG_OK;
 }

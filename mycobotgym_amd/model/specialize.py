@@ -248,66 +248,47 @@ def specialize(m: dict, weld_rule: str = "common", contact_rule: str = "mujoco")
         # structural facts the cube kernels rely on: CoM at the body origin, principal axes = body axes
         assert np.allclose(mc[12], 0) and np.allclose(inertia[12][3:], 0), "cube: centred, axis-aligned inertia expected"
         out["geom_ids"] = {"table": gt, "cube": gc, "pad_r": gr, "pad_l": gl}
-        # --- convex-mesh collision, first stage: support polytopes of the arm-side mesh geoms, in engine body frames
-        names = ("link1", "link2", "link3", "link4", "link5", "link6", "flange", "gripper_base")
-        hull = np.zeros((8, 26, 3)); box = np.zeros((8, 6)); ldiag = np.zeros((8, 2)); mult = set()
-        dir13 = np.array([(1, 0, 0), (0, 1, 0), (0, 0, 1), (1, 1, 0), (1, -1, 0), (1, 0, 1), (1, 0, -1), (0, 1, 1), (0, 1, -1), (1, 1, 1), (1, 1, -1), (1, -1, 1), (1, -1, -1)], dtype=float)      # MCG_DIR13 (csrc/mcg_cube.hpp), DIR13 (oracle/mco_collision.c)
-        lext = np.zeros((8, 13, 2))
-        mesh_sigs = set()
-        for p, nm in enumerate(names):
+        # --- convex-mesh collision: the fourteen mesh geoms' collision polytopes (model/polytope.py) in engine body frames
+        from . import polytope as pt
+        mbox = np.zeros((pt.NMESH, 6)); tran_mesh = np.zeros(pt.NMESH); mult = set(); mesh_sigs = set(); frames = []
+        for mi, nm in enumerate(pt.MESH_NAMES):
             gs = [g for g in range(m["ngeom"]) if m["geom_type"][g] == 7 and m["geom_mesh"][g] == nm
                   and m["geom_contype"][g] and m["geom_conaffinity"][g]]
-            sup = np.asarray(m["meshes"][nm]["support"], dtype=float)
-            assert gs and 4 <= len(sup) <= 26, nm
+            assert gs, nm
             g = gs[0]
             root, R, pw = weld_frames[m["geom_body"][g]]
-            assert root == min(p, 5), "arm-side meshes ride on links 1-6 (flange and gripper_base welded into link6)"
+            assert root == pt.MESH_BODY[mi], f"{nm}: rides on engine body {root}, the kernels expect {pt.MESH_BODY[mi]}"
             assert np.allclose(m["geom_pos"][g], 0) and np.allclose(m["geom_quat"][g], [1, 0, 0, 0])
-            v = pw + sup @ R.T
-            hull[p, :len(v)] = v; hull[p, len(v):] = v[0]                      # padded with a repeat: extremes and first occurrences unchanged
-            box[p] = np.concatenate([0.5 * (v.max(0) + v.min(0)), 0.5 * (v.max(0) - v.min(0))])
-            ldiag[p] = biw[m["geom_body"][g]]
-            proj = v @ dir13.T; lext[p, :, 0] = proj.min(0); lext[p, :, 1] = proj.max(0)
+            frames.append((R, pw))
+            tran_mesh[mi] = biw[m["geom_body"][g]][0]
             mult.add(len(gs))
-            condim, fri, solref, solimp = mix_contact(m, gt, g)
-            assert condim == 3
-            # ONE row of contact_par serves all eight meshes (and, for the gripper base against the cube, the finger-mesh row serves it
-            # too: csrc/mcg_cube.hpp): every mesh geom must mix to the same numbers, else the row of the last mesh would silently win
-            sig = (tuple(np.round(fri, 15)), tuple(np.round(solref, 15)), tuple(np.round(solimp, 15)), tuple(np.round(m["geom_friction"][g], 15)))
-            mesh_sigs.add(sig)
+            # ONE row of contact_par serves all meshes against the static geoms and one against the cube: every mesh geom must mix to the
+            # same numbers, else the row of the last mesh would silently win
+            c3, fri3, solref3, solimp3 = mix_contact(m, gt, g)
+            c4, fri4, solref4, solimp4 = mix_contact(m, g, gc)
+            assert c3 == 3 and c4 == 4
+            mesh_sigs.add((tuple(np.round(fri3, 15)), tuple(np.round(solref3, 15)), tuple(np.round(solimp3, 15)), tuple(np.round(fri4, 15)),
+                           tuple(np.round(solref4, 15)), tuple(np.round(solimp4, 15)), tuple(np.round(m["geom_friction"][g], 15))))
         assert len(mult) == 1
-        assert len(mesh_sigs) == 1, "the arm-side mesh geoms differ in friction / solref / solimp: one contact_par row per mesh would be needed"
-        cp.append(np.concatenate([_solparams(solref, solimp, h), fri]))
-        out["contact_par"] = np.array(cp)    # + row 5: table - arm mesh (condim 3)
-        out["link_hull"] = hull; out["link_hull_box"] = box; out["link_diag"] = ldiag; out["link_ext"] = lext; out["link_mult"] = float(mult.pop())
-        for p in range(8):                # mcg_body.hull_rad: the free broad-phase number that travels with the body's other constants
-            out["body"][min(p, 5), 15] = max(out["body"][min(p, 5), 15], float(np.linalg.norm(hull[p], axis=1).max()))
-        # --- second stage: the finger-link meshes against the cube, on their support polytopes.
-        # The pads are welded to the finger links (same rigid bodies as the pad-cube pairs), but the inverse weights are the LINK's own.
-        fbox = np.zeros((2, 6)); fhull = np.zeros((2, 26, 3)); fext = np.zeros((2, 13, 2)); fmult = set(); ffric = set(); ftran = []
-        for sd, (nm, fing, gp) in enumerate((("right_finger_link", 7, gr), ("left_finger_link", 9, gl))):
-            gs = [g for g in range(m["ngeom"]) if m["geom_type"][g] == 7 and m["geom_mesh"][g] == nm
-                  and m["geom_contype"][g] and m["geom_conaffinity"][g]]
-            sup = np.asarray(m["meshes"][nm]["support"], dtype=float)
-            assert gs and 4 <= len(sup) <= 26, nm
-            g = gs[0]
-            root, R, pw = weld_frames[m["geom_body"][g]]
-            assert root == fing and np.allclose(R, np.eye(3)), "mesh rides on its engine body (finger / link6) without rotation expected"
-            assert np.allclose(m["geom_pos"][g], 0) and np.allclose(m["geom_quat"][g], [1, 0, 0, 0])
-            if gp is not None:
-                assert m["body_weldid"][m["geom_body"][g]] == m["body_weldid"][m["geom_body"][gp]], "pad welded to its finger link expected"
-            v = pw + sup @ R.T
-            fhull[sd, :len(v)] = v; fhull[sd, len(v):] = v[0]                 # padded with a repeat: extremes and first occurrences unchanged
-            fbox[sd] = np.concatenate([0.5 * (v.max(0) + v.min(0)), 0.5 * (v.max(0) - v.min(0))])
-            proj = v @ dir13.T; fext[sd, :, 0] = proj.min(0); fext[sd, :, 1] = proj.max(0)
-            fmult.add(len(gs)); ffric.add(float(m["geom_friction"][g][0]))
-            ftran.append(float(biw[m["geom_body"][g]][0] + bt(gc)[0]))
-            condim, fri, solref, solimp = mix_contact(m, g, gc)
-            assert condim == 4
-        assert len(fmult) == 1 and len(ffric) == 1                  # (and one set of pair parameters: all three are default mesh geoms)
-        cp.append(np.concatenate([_solparams(solref, solimp, h), fri]))
-        out["contact_par"] = np.array(cp)    # + row 6: finger mesh - cube (condim 4)
-        out["fin_hull"] = fhull; out["fin_ext"] = fext; out["fin_box"] = fbox; out["fin_par"] = np.array([float(fmult.pop()), ffric.pop()] + ftran)
+        assert len(mesh_sigs) == 1, "the mesh geoms differ in friction / solref / solimp: one contact_par row per mesh would be needed"
+        cp.append(np.concatenate([_solparams(solref3, solimp3, h), fri3]))       # row 5: table - mesh (condim 3)
+        cp.append(np.concatenate([_solparams(solref4, solimp4, h), fri4]))       # row 6: mesh - cube (condim 4)
+        out["contact_par"] = np.array(cp)
+        out["mesh_mult"] = float(mult.pop()); out["mesh_fric"] = float(m["geom_friction"][g][0])
+        polys = pt.transform(pt.unpack(pt.load_asset()[0]), frames)
+        for mi, P in enumerate(polys):
+            v = P["verts"]
+            mbox[mi] = np.concatenate([0.5 * (v.max(0) + v.min(0)), 0.5 * (v.max(0) - v.min(0))])
+            bi = pt.MESH_BODY[mi]
+            out["body"][bi, 15] = max(out["body"][bi, 15], float(np.linalg.norm(v, axis=1).max()))      # mcg_body.hull_rad: the free broad-phase number
+        out["mesh_box"] = mbox
+        out["polytopes"] = pt.pack(polys)           # the table block of mcg_create (not a field of mcg_model)
+        # pair_tran: the summed translational inverse weights of a pair's two bodies (the static geoms' are zero)
+        ptn = np.zeros(5 + 2 * pt.NMESH)
+        ptn[0:5] = out["contact_diag"][:, 0]
+        ptn[5:5 + pt.NMESH] = tran_mesh + bt(gt)[0]
+        ptn[5 + pt.NMESH:] = tran_mesh + bt(gc)[0]
+        out["pair_tran"] = ptn
     return out
 
 

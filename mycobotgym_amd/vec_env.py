@@ -135,7 +135,7 @@ class MyCobotVecEnv:
         self._model = model
         self._h = C.c_void_p()
         dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
-        _abi.check(self._lib.mcg_create(C.byref(cfg), C.byref(model), dev_index, C.byref(self._h)), "mcg_create")
+        _abi.check(self._lib.mcg_create(C.byref(cfg), C.byref(model), None, 0, dev_index, C.byref(self._h)), "mcg_create")      # built-in polytope tables
         self.obs_dim = self._lib.mcg_obs_dim(self._h)
         self.action_dim = self._lib.mcg_action_dim(self._h)
         self.nq, self.nv = self._lib.mcg_nq(self._h), self._lib.mcg_nv(self._h)
@@ -296,7 +296,7 @@ class MyCobotVecEnv:
         list entries, the contacts the cap cut off, and per entry dist, pos[3], normal[3], pair type, multiplicity, D."""
         n = self.num_envs
         count = torch.zeros(n, dtype=torch.int32, device=self.device); dropped = torch.zeros_like(count)
-        data = torch.zeros(n, 12, 10, dtype=torch.float64, device=self.device)
+        data = torch.zeros(n, _abi.MAXCON, 10, dtype=torch.float64, device=self.device)
         _abi.check(self._lib.mcg_debug_contacts(self._h, count.data_ptr(), dropped.data_ptr(), data.data_ptr(), self._stream()), "mcg_debug_contacts")
         torch.cuda.synchronize(self.device)
         return {"count": count, "dropped": dropped, "dist": data[:, :, 0], "pos": data[:, :, 1:4], "normal": data[:, :, 4:7],

@@ -125,7 +125,7 @@ def test_mocap_needs_its_model_variant(torch_cuda):
     cfg.max_episode_steps = 50; cfg.reward_type = 1
     model = _abi.McgModel(); assert L.mcg_default_model(0, C.byref(model)) == 0        # no weld in variant 0
     h = C.c_void_p()
-    assert L.mcg_create(C.byref(cfg), C.byref(model), 0, C.byref(h)) != 0
+    assert L.mcg_create(C.byref(cfg), C.byref(model), None, 0, 0, C.byref(h)) != 0
     assert b"mocap" in L.mcg_last_error()
 
 

@@ -105,7 +105,8 @@ def MyCobotVecEnvRest(torch, rule):
 
 def _contact_poses(kind, count=128, seed=0):
     """Rejection-sampled arm poses (cube at rest on the table) with a SHALLOW contact of the wanted kind (a deep one is a violent
-    state).  kind "pad": a finger pad on the table / the ground; kind "mesh": an arm-side mesh (support polytope, condim 3: 4 rows)."""
+    state).  kind "pad": a finger pad on the table / the ground, no mesh contact; kind "mesh": a mesh geom of the arm or the gripper (collision
+    polytope, condim 3: 4 rows) on the table / the ground."""
     from tests.common import load_json
     from oracle import pyoracle as po
     tab = load_json("mycobot280")
@@ -119,36 +120,40 @@ def _contact_poses(kind, count=128, seed=0):
         d.set_state(qpos=q, qvel=np.zeros(18)); d.forward()
         n = int(d.get("ncon", (1,), np.int32)[0]); nefc = int(d.get("nefc", (1,), np.int32)[0])
         if n <= 4: continue
-        rows = d.get("efc_type", (224,), np.int32)[:nefc] == 2                      # contact rows (pyramid)
-        ids = d.get("efc_id", (224,), np.int32)[:nefc][rows]
+        rows = d.get("efc_type", (416,), np.int32)[:nefc] == 2                      # contact rows (pyramid)
+        ids = d.get("efc_id", (416,), np.int32)[:nefc][rows]
         per_contact = np.bincount(ids)
         has_mesh = bool((per_contact == 4).any())                                  # condim 3
         has_pad = int((per_contact == 6).sum()) > 4                                # condim 4 beyond the cube's four
-        if d.get("efc_pos", (224,))[:nefc][rows].min() <= -2e-3: continue
+        if d.get("efc_pos", (416,))[:nefc][rows].min() <= -2e-3: continue
+        if kind == "gripper_mesh":
+            raw = d.get("contact", (64, 28))
+            gm = {g for g in range(tab["ngeom"]) if tab["geom_type"][g] == 7 and ("finger" in tab["geom_mesh"][g] or "gear" in tab["geom_mesh"][g] or "hinge" in tab["geom_mesh"][g])}
+            if any(int(raw[c, 26:28].copy().view(np.int32)[2]) in gm for c in range(n)): poses.append(q)
+            continue
         if (kind == "mesh" and has_mesh) or (kind == "pad" and has_pad and not has_mesh): poses.append(q)
     return np.array(poses)
 
 
-def _cap_poses(count=64, seed=11, depth=-1e-2):
-    """Arm poses with an arm-side mesh contact AND a contact list at the cap of 12 (the oracle's count, duplicated mesh geoms counted
-    twice): the arm-mesh entries, first in the oracle's pair order, push entries of the tail off the list.  Such poses are deep ones
-    under uniform sampling (median penetration 7 cm); the shallowest 1 % are kept."""
+def _cap_poses(count=48, seed=11, depth=-2.5e-2):
+    """Arm poses whose contact list is cut by the cap of 16 entries (mesh entries come last in the pair order and are the ones cut).  Such
+    poses are deep ones under uniform sampling -- an arm folded into the table; the shallowest are kept."""
     from tests.common import load_json
     from oracle import pyoracle as po
     tab = load_json("mycobot280")
     m = po.OracleModel(tab, enable_contact=True, scope_geom=tab["geom_name"].index("object0"))
     d = po.OracleData(m)
     rng = np.random.default_rng(seed)
-    poses = []
-    while len(poses) < count:
+    poses = []; tries = 0
+    while len(poses) < count and tries < 400000:
+        tries += 1
         q = np.array(tab["qpos0"], float)
         q[:6] = rng.uniform(-2.5, 2.5, 6); q[6] = q[8] = rng.uniform(0, 0.7)
         d.set_state(qpos=q, qvel=np.zeros(18)); d.forward()
-        n = int(d.get("ncon", (1,), np.int32)[0]); nefc = int(d.get("nefc", (1,), np.int32)[0])
-        if n < 12: continue
-        rows = d.get("efc_type", (224,), np.int32)[:nefc] == 2
-        per_contact = np.bincount(d.get("efc_id", (224,), np.int32)[:nefc][rows])
-        if (per_contact == 4).any() and d.get("efc_pos", (224,))[:nefc][rows].min() > depth: poses.append(q)
+        if int(d.get("ndrop", (1,), np.int32)[0]) == 0: continue
+        nefc = int(d.get("nefc", (1,), np.int32)[0])
+        rows = d.get("efc_type", (416,), np.int32)[:nefc] == 2
+        if d.get("efc_pos", (416,))[:nefc][rows].min() > depth: poses.append(q)
     return np.array(poses)
 
 
@@ -171,20 +176,21 @@ def test_substeps_finger_pads_on_the_table_and_the_ground(torch_cuda):
 
 
 def test_substeps_arm_meshes_on_the_table_and_the_ground(torch_cuda):
-    """SURVEY 8f-4, first stage: the arm-side mesh geoms (their 26-direction support polytopes) against the table and the ground:
-    one condim-3 contact per mesh at the deepest vertex, duplicated visual/collision meshes as one entry of double weight."""
+    """the mesh geoms (their collision polytopes, exact separating-axis test) against the table and the ground: one condim-3
+    contact per mesh on the axis of least penetration, duplicated visual/collision meshes as one entry of double weight."""
     worst, ncon = _substep_run(torch_cuda, 128, 200, prepare=_pose_prepare(_contact_poses("mesh", seed=1)), hold_pose=True)
     print(f"\narm meshes on the table / ground, 200 sub-steps x 128 envs: {worst}, contact counts seen {sorted(ncon)}")
     assert max(ncon) > 4
     assert worst["obs"] < 1e-10 and worst["qpos"] < 1e-10 and worst["qvel"] < 1e-6
 
 
-def test_substeps_arm_meshes_with_the_cap_cutting_the_merged_list(torch_cuda):
-    """Round 3: the arm meshes are tested by the M / RNE waves and merged IN FRONT of the cube wave's entries after barrier S1b
-    (CubeSys::merge_staged); with the list at the cap of MAXCON = 12 contacts the merge decides which entries of the tail are cut, as the
-    oracle's pair order does.  Per-sub-step parity on such states (teacher-forced), and the kernels' own count of cut contacts."""
+def test_substeps_with_the_cap_cutting_the_list(torch_cuda):
+    """The list at the cap of MAXCON = 16 entries: the mesh phase appends behind the primitive pairs' contacts until the list is full and
+    counts what it cuts, as the oracle's pair order does.  Per-sub-step parity on such states (teacher-forced), and the kernels' own
+    count of cut contacts."""
     poses = _cap_poses()
     n = len(poses)
+    assert n >= 8, "too few capped poses found"
     from tests.common import make_pair, sync_oracle_to, step_errors
     kw = dict(has_object=True, controller_type="joint", reward_type="dense", seed=5, frame_skip=1, max_episode_steps=10 ** 9)
     envs, ora = make_pair(n, **kw)
@@ -192,12 +198,13 @@ def test_substeps_arm_meshes_with_the_cap_cutting_the_merged_list(torch_cuda):
     _pose_prepare(poses)(ora)
     sync_oracle_to(envs, ora)
     kc = envs.debug_contacts()
-    at_cap = int((kc["mult"].sum(dim=1) >= 12).sum()); cut = int((kc["dropped"] > 0).sum())
-    link = ((kc["type"] >= 5) & (kc["type"] < 13) & (torch_cuda.arange(12, device=kc["type"].device)[None, :] < kc["count"][:, None])).any(dim=1)
+    at_cap = int((kc["count"] >= 16).sum()); cut = int((kc["dropped"] > 0).sum())
+    odrop = sum(int(ora.data(i).get("ndrop", (1,), np.int32)[0]) for i in range(n))
+    assert int(kc["dropped"].sum()) == odrop, (int(kc["dropped"].sum()), odrop)
     envs.counters(clear=True)
     a = np.clip(ora.get_state()["ctrl"], -1, 1).astype(np.float32)
     worst = dict(obs=0.0, qpos=0.0)
-    for t in range(12):                                           # a dozen sub-steps: the deep ones among these states blow up soon after
+    for t in range(6):                                            # a few sub-steps: the deep ones among these states blow up soon after
         sync_oracle_to(envs, ora)
         e, flags_equal, o = step_errors(envs, ora, a)
         assert flags_equal
@@ -205,10 +212,9 @@ def test_substeps_arm_meshes_with_the_cap_cutting_the_merged_list(torch_cuda):
         worst["obs"] = max(worst["obs"], float(e.max()))
         worst["qpos"] = max(worst["qpos"], float(np.abs(st["qpos"].cpu().numpy().T - so["qpos"]).max()))
     dropped = envs.counters()["contacts_dropped"]
-    print(f"\narm meshes + list at the cap, 12 sub-steps x {n} envs: {worst}; envs at the cap {at_cap}, with cut contacts {cut}, with a link entry "
-          f"{int(link.sum())}; contacts cut over the run (mcg_counters) {dropped}")
-    assert at_cap >= n // 2 and int(link.sum()) >= n // 2 and cut > 0 and dropped > 0
-    assert worst["obs"] < 1e-10 and worst["qpos"] < 1e-10          # measured 1.5e-14, 1.0e-13 (14 of 64 envs with cut contacts)
+    print(f"\nlists at the cap, 6 sub-steps x {n} envs: {worst}; envs at the cap {at_cap}, with cut contacts {cut}; contacts cut over the run (mcg_counters) {dropped}")
+    assert at_cap >= n // 2 and cut > 0 and dropped > 0
+    assert worst["obs"] < 1e-9 and worst["qpos"] < 1e-9
     envs.close()
 
 
@@ -230,7 +236,7 @@ def test_whole_env_step_from_random_policy_states(torch_cuda):
     ty, cnt = kc["type"].cpu(), kc["count"].cpu()
     src.close()
     live = torch.arange(ty.shape[1])[None, :] < cnt[:, None]
-    arm = ((ty >= 5) & (ty < 13) & live).any(dim=1)
+    arm = ((ty >= 5) & (ty < 19) & live).any(dim=1)
     n = 128
     pick = torch.cat([arm.nonzero().flatten()[: n // 2], (~arm).nonzero().flatten()[: n - min(n // 2, int(arm.sum()))]])[:n]
     n = len(pick)
@@ -254,7 +260,7 @@ def test_whole_env_step_from_random_policy_states(torch_cuda):
 
 
 def _finger_mesh_poses(count=128, seed=2, meshes=("right_finger_link", "left_finger_link")):
-    """Gripper poses around the cube (the scripted-grasp states, perturbed) in which the bounding box of one of `meshes` touches the
+    """Gripper poses around the cube (the scripted-grasp states, perturbed) in which the polytope of one of `meshes` touches the
     cube (the oracle's contact list names the geoms); shallow contacts only (a deep one is a violent state)."""
     from tests.common import load_json
     from oracle import pyoracle as po
@@ -270,14 +276,88 @@ def _finger_mesh_poses(count=128, seed=2, meshes=("right_finger_link", "left_fin
         q = q0[rng.integers(len(q0))].copy()
         q[:6] += rng.normal(0, 0.04, 6); q[6] = q[8] = np.clip(q[6] + rng.normal(0, 0.1), 0, 0.7)
         d1.set_state(qpos=q, qvel=np.zeros(18)); d1.forward()
-        n1 = int(d1.get("ncon", (1,), np.int32)[0]); raw = d1.get("contact", (12, 28))
-        hit = any(int(raw[c, 26:28].copy().view(np.int32)[1]) in geoms for c in range(n1))
+        n1 = int(d1.get("ncon", (1,), np.int32)[0]); raw = d1.get("contact", (64, 28))
+        hit = any(int(raw[c, 26:28].copy().view(np.int32)[1]) in geoms and int(raw[c, 26:28].copy().view(np.int32)[2]) == scope for c in range(n1))
         if hit and raw[:n1, 0].min() > -3e-3: poses.append(q)
     return np.array(poses)
 
 
+def _link_cube_poses(count=128, seed=6, meshes=("link2", "link3", "link4", "link5", "link6", "flange")):
+    """Random arm poses with the cube put (in the air or on the table) where it just touches one of the arm's links: the pairs an arm
+    link sweeping the cube off the table goes through.  Shallow contacts only."""
+    from tests.common import load_json
+    from oracle import pyoracle as po
+    tab = load_json("mycobot280")
+    scope = tab["geom_name"].index("object0")
+    d1 = po.OracleData(po.OracleModel(tab, enable_contact=True, scope_geom=scope))
+    geoms = [g for g in range(tab["ngeom"]) if tab["geom_type"][g] == 7 and tab["geom_mesh"][g] in meshes]
+    gset = set(geoms)
+    rng = np.random.default_rng(seed)
+    poses = []
+    while len(poses) < count:
+        q = np.array(tab["qpos0"], float)
+        q[:6] = rng.uniform(-1.5, 1.5, 6); q[6] = q[8] = rng.uniform(0, 0.7)
+        d1.set_state(qpos=q, qvel=np.zeros(18)); d1.forward()
+        if int(d1.get("ncon", (1,), np.int32)[0]) > 4: continue             # the arm itself must be clear of the table
+        g = geoms[rng.integers(len(geoms))]
+        gx = d1.get("geom_xpos", (48, 3))[g]; gR = d1.get("geom_xmat", (48, 9))[g].reshape(3, 3)
+        ctr = gx + gR @ rng.uniform(-0.03, 0.06, 3)
+        dirn = rng.normal(size=3); dirn /= np.linalg.norm(dirn)
+        for r in np.linspace(0.09, 0.0, 46):                                    # walk the cube in until it touches
+            q[12:15] = ctr + r * dirn
+            quat = rng.normal(size=4); q[15:19] = quat / np.linalg.norm(quat)
+            if q[14] < 0.215: break
+            d1.set_state(qpos=q, qvel=np.zeros(18)); d1.forward()
+            n1 = int(d1.get("ncon", (1,), np.int32)[0])
+            if n1 == 0: continue
+            raw = d1.get("contact", (64, 28))
+            ids = [raw[c, 26:28].copy().view(np.int32) for c in range(n1)]
+            if all(int(i[1]) in gset and int(i[2]) == scope for i in ids) and raw[:n1, 0].min() > -2e-3: poses.append(q.copy())
+            break
+    return np.array(poses)
+
+
+def test_substeps_arm_link_meshes_on_the_cube(torch_cuda):
+    """the arm's links (2-6, flange) against the cube -- an arm link that sweeps the cube off the table no longer
+    passes through it.  The cube is put where it just touches a link; teacher-forced per sub-step."""
+    poses = _link_cube_poses()
+    def prepare(ora):
+        s = ora.get_state()
+        s["qpos"][:] = poses; s["qpos_lag"] = s["qpos"].copy()
+        s["ctrl"][:, :6] = poses[:, :6]; s["ctrl"][:, 6] = poses[:, 6] / 0.7
+        ora.set_state(**s)
+    worst, ncon = _substep_run(torch_cuda, 128, 100, prepare=prepare, hold_pose=True)
+    print(f"\narm-link meshes on the cube, 100 sub-steps x 128 envs: {worst}, contact counts seen {sorted(ncon)}")
+    assert max(ncon) >= 2
+    assert worst["obs"] < 1e-10 and worst["qpos"] < 1e-10 and worst["qvel"] < 1e-6
+
+
+def test_substeps_gear_and_hinge_link_meshes_on_the_cube(torch_cuda):
+    """the gripper's gear and hinge links (mycobot280_main.xml:176-184, 203-211, 229-247) against the cube: rows in
+    the arm's six dofs and the link's own joint (the hinge joints are dofs 10 and 11 of the robot)."""
+    poses = _finger_mesh_poses(count=128, seed=8, meshes=("right_gear_link", "left_gear_link", "right_hinge_link", "left_hinge_link"))
+    def prepare(ora):
+        s = ora.get_state()
+        s["qpos"][:] = poses; s["qpos_lag"] = s["qpos"].copy()
+        s["ctrl"][:, :6] = poses[:, :6]; s["ctrl"][:, 6] = poses[:, 6] / 0.7
+        ora.set_state(**s)
+    worst, ncon = _substep_run(torch_cuda, 128, 200, prepare=prepare, hold_pose=True)
+    print(f"\ngear / hinge link meshes on the cube, 200 sub-steps x 128 envs: {worst}, contact counts seen {sorted(ncon)}")
+    assert max(ncon) >= 2
+    assert worst["obs"] < 1e-10 and worst["qpos"] < 1e-10 and worst["qvel"] < 1e-6
+
+
+def test_substeps_gripper_meshes_on_the_table_and_the_ground(torch_cuda):
+    """the finger, gear and hinge links against the table / the ground (only the pads did in round 3)."""
+    poses = _contact_poses("gripper_mesh", seed=3)
+    worst, ncon = _substep_run(torch_cuda, 128, 200, prepare=_pose_prepare(poses), hold_pose=True)
+    print(f"\ngripper meshes on the table / ground, 200 sub-steps x 128 envs: {worst}, contact counts seen {sorted(ncon)}")
+    assert max(ncon) > 4
+    assert worst["obs"] < 1e-10 and worst["qpos"] < 1e-10 and worst["qvel"] < 1e-6
+
+
 def test_substeps_finger_link_meshes_on_the_cube(torch_cuda):
-    """SURVEY 8f-4, second stage: the two finger-link meshes (support polytopes, 16-axis separating-axis test, one contact each) against
+    """the two finger-link meshes (their full hulls, exact separating-axis test, one contact each) against
     the cube -- contacts between the same two bodies as the pad-cube contacts, with the mesh-cube pair's own parameters."""
     poses = _finger_mesh_poses()
     def prepare(ora):

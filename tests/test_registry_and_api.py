@@ -69,7 +69,7 @@ def test_library_exports_every_declared_symbol(built):
     assert set(names) == set(_abi.EXPORTS), (names, _abi.EXPORTS)
     for n in names:
         assert getattr(lib, n) is not None
-    assert lib.mcg_abi_version() == _abi.ABI_VERSION == 7
+    assert lib.mcg_abi_version() == _abi.ABI_VERSION == 8
 
 
 def test_ctypes_mirror_matches_header_layout(built, tmp_path):
@@ -107,11 +107,11 @@ def test_create_argument_errors_without_touching_the_gpu(built):
     lib = _abi.load()
     h = C.c_void_p()
     cfg = _abi.McgConfig(n_envs=0)
-    assert lib.mcg_create(C.byref(cfg), None, 0, C.byref(h)) == _abi.MCG_ERR_ARG
+    assert lib.mcg_create(C.byref(cfg), None, None, 0, 0, C.byref(h)) == _abi.MCG_ERR_ARG
     cfg = _abi.McgConfig(n_envs=4, controller=1, fetch_env=0, reward_type=7, frame_skip=20, control_steps=5, max_episode_steps=50)
-    assert lib.mcg_create(C.byref(cfg), None, 0, C.byref(h)) == _abi.MCG_ERR_ARG and b"reward_type" in lib.mcg_last_error()
+    assert lib.mcg_create(C.byref(cfg), None, None, 0, 0, C.byref(h)) == _abi.MCG_ERR_ARG and b"reward_type" in lib.mcg_last_error()
     cfg = _abi.McgConfig(n_envs=4, controller=0, fetch_env=1, frame_skip=20, control_steps=5, max_episode_steps=50)
-    assert lib.mcg_create(C.byref(cfg), None, 0, C.byref(h)) == _abi.MCG_ERR_ARG
+    assert lib.mcg_create(C.byref(cfg), None, None, 0, 0, C.byref(h)) == _abi.MCG_ERR_ARG
     assert b"Joint controller not supported for Fetch env" in lib.mcg_last_error()
 
 
