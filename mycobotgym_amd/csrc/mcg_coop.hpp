@@ -37,8 +37,8 @@ constexpr int XCH_FLAG = LDS_POLY, XCH_T0 = LDS_POLY + 1, XCH_T1 = LDS_POLY + 2,
 constexpr int XCH_CB = LDS_POLY + 4, XCH_QL7 = LDS_POLY + 23, XCH_DR = LDS_POLY + 30;      // cube: pos 3, quat 4, vel 6, warm 6; lagged pose 7; DR scales 2
 static_assert(XCH_DR + 2 <= LDS_POLY + 32, "exchange area exceeds the clip-polygon slots");
 // ... second 32 slots, which no pass writes: q(t), qd(t) of the robot for the other waves -- written at the end of a sub-step, read after
-// S1 by the M, RNE and cube waves and between S4 and S5 by the cooperative solves -- and the workgroup's hand-out counters: of that phase
-// (an unsigned in the first word of lane 0's slot) and of the mesh phase (lane 1's slot, mcg_mesh.hpp).
+// S1 by the M, RNE and cube waves and between S4 and S5 by the cooperative solves -- and the workgroup's hand-out counter of that phase
+// (an unsigned in the first word of lane 0's slot).
 constexpr int XCH_Q = LDS_POLY + 32, XCH_QD = XCH_Q + NB, COOP_CTR_SLOT = XCH_QD + NB;
 // XCH_T1 (robot wave -> cube wave, read after S1) / XCH_BADC (cube wave -> robot wave, read after S4): the other body failed mj_checkPos /
 // mj_checkVel, mj_resetData resets both

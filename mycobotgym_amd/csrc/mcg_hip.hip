@@ -500,7 +500,6 @@ MCG_DEV void cube_from_lds(const PnpScratch MS, Cube& Cb) {
 MCG_DEV unsigned flagged_lanes(const PnpScratch MS, int nvalid) {
   return (unsigned)__ballot(flag_coupled(MS.ld(XCH_FLAG))) & (nvalid >= 32 ? 0xFFFFFFFFu : ((1u << nvalid) - 1u));
 }
-MCG_DEV LdsCtrPtr mesh_counter(unsigned lds0) { return (LdsCtrPtr)(uintptr_t)(lds0 + (COOP_CTR_SLOT * PNP_LANES + MESH_CTR_LANE) * 8); }
 MCG_DEV LdsPtr wave_workspace(unsigned lds0, int w) { return (LdsPtr)(uintptr_t)lds0 + COOP_WS_ROW * PNP_LANES + w * COOP_WS_DOUBLES; }
 
 // the cube wave's whole env-step.  `lower`: lanes 0-31 carry the 32 environments; lanes 32-63 are alive for the mesh phase and the
@@ -548,7 +547,7 @@ MCG_DEV void cube_wave(const CubeWaveArgs& C, const View& V, ModelPtr P, const r
       MCG_TICK2(ST_W2_COLLIDE);
     }
     __syncthreads();                                                // S1b
-    mesh_phase(P, poly, (LdsPtr)(uintptr_t)lds0, wave_workspace(lds0, 1), mesh_counter(lds0));
+    mesh_phase(P, poly, (LdsPtr)(uintptr_t)lds0, wave_workspace(lds0, 1), 0, 3);
     __syncthreads();                                                // S1c: every list is complete
     if (lower) {
       CS.collect_list();
@@ -596,10 +595,7 @@ MCG_DEV bool pnp_substep_robot(const Cfg& C, ModelPtr P, EnvP& E, const PnpScrat
   PubHook hook{MS};
   robot_substep<PnpScratch, PubHook, WLD, SplitPnp, false>(P, E.R, E.qlag6, MS, &hook, &W, &nx);     // S1, S1b, S1c, S2 inside
   MCG_TICK(ST_POST);
-  if ((threadIdx.x & 63) == 0) {       // the hand-out counters of the cooperative phase (this sub-step) and of the mesh phase (the next)
-    *(LdsCtrPtr)(uintptr_t)(lds0 + COOP_CTR_SLOT * PNP_LANES * 8) = 0u;
-    *mesh_counter(lds0) = 0u;
-  }
+  if ((threadIdx.x & 63) == 0) *(__attribute__((address_space(3))) unsigned*)(uintptr_t)(lds0 + COOP_CTR_SLOT * PNP_LANES * 8) = 0u;      // the cooperative phase's hand-out counter
   __syncthreads();                                                  // S4
   MCG_TICK(ST_W1_WAIT);
   const real fl = MS.ld(XCH_FLAG);
@@ -658,7 +654,7 @@ MCG_DEV void pnp_side_wave(ModelPtr P, const real* __restrict__ poly, const PnpS
       else helper_pre<SplitPnp>(P, MS, PnpSideWork<0, 4, true>{P, MS, MP_MASK});
     }
     __syncthreads();                                                // S1b
-    mesh_phase(P, poly, (LdsPtr)(uintptr_t)lds0, wave_workspace(lds0, rne ? 3 : 2), mesh_counter(lds0));
+    mesh_phase(P, poly, (LdsPtr)(uintptr_t)lds0, wave_workspace(lds0, rne ? 3 : 2), rne ? 2 : 1, 3);
     __syncthreads();                                                // S1c
     if (lower) solver_numbers_share(P, MS, dr1, rne ? 2 : 1);
     __syncthreads();                                                // S2
@@ -715,7 +711,7 @@ __global__ __launch_bounds__(256) void step_pnp_kernel(Cfg C, View V, const mcg_
   if constexpr (DUAL) { static_for<NB>([&](auto I) { constexpr int k = I; MS.st(XCH_Q + k, E.R.q[k]); MS.st(XCH_QD + k, E.R.qd[k]); });   // q(0), qd(0) for the other waves
                         MS.st(XCH_T1, hadbad ? 1.0 : 0.0);
                         MS.st(XCH_ACT0, 0.0); MS.st(XCH_ACT1, 0.0);         // no active set carried into an env-step (mcg_coop.hpp: coop_guess)
-                        if (threadIdx.x == 0) *mesh_counter(lds0) = 0u; }
+                      }
   MCG_TICK(ST_LOAD);
   E.touch = false;
   int nsub = 0;
@@ -879,7 +875,7 @@ __global__ __launch_bounds__(64) void contacts_pnp_kernel(Cfg C, View V, const m
     CS.template collide_primitives<true, true>(P, E.R.q);
   }
   __syncthreads();
-  mesh_phase(P, poly, (LdsPtr)(uintptr_t)lds0, wave_workspace(lds0, 0), (LdsCtrPtr)nullptr);
+  mesh_phase(P, poly, (LdsPtr)(uintptr_t)lds0, wave_workspace(lds0, 0), 0, 1);
   __syncthreads();
   if (!lower || i_raw >= C.n) return;
   CS.collect_list();

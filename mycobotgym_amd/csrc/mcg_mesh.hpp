@@ -22,7 +22,6 @@
 
 namespace mcg {
 
-constexpr int MESH_CTR_LANE = 1;                                  // the mesh phase's hand-out counter: lane 1's word of slot COOP_CTR_SLOT (mcg_coop.hpp)
 constexpr real MESH_TIE = 1e-12, MESH_EDGE_MIN_SIN = 1e-6;
 
 // ---- cross-lane helpers, 64 lanes
@@ -295,30 +294,21 @@ MCG_DEV void mesh_env(ModelPtr Pm, const real* __restrict__ poly, LdsPtr lds0, i
 }
 
 // ---- the mesh phase of a sub-step: every wave that takes part calls it with all 64 lanes between barriers S1b and S1c.  The environments
-// that have candidates are handed out from a counter in LDS (a pair costs between 300 and 2000 instructions); WHICH wave takes an
-// environment does not change its result.  `ctr` null: one wave alone (the debug kernel) walks them all.
-typedef __attribute__((address_space(3))) unsigned* LdsCtrPtr;
-MCG_DEV void mesh_phase(ModelPtr Pm, const real* __restrict__ poly, LdsPtr lds0, LdsPtr ws, LdsCtrPtr ctr) {
+// that have candidates are dealt out by rank: the k-th of them (in lane order) goes to wave k mod nwaves -- a pair costs between 300 and
+// 2000 instructions, but a counter in LDS (as the cooperative solves use) bought nothing here: the phase is short, and which wave
+// takes an environment does not change its result either way.  (The first version did grab from a counter; that loop hung on the GPU
+// in this kernel and in no reduced copy of it, and was not understood: profiles/r04a/diag*.log.)
+MCG_DEV void mesh_phase(ModelPtr Pm, const real* __restrict__ poly, LdsPtr lds0, LdsPtr ws, int wave, int nwaves) {
   const int T = threadIdx.x & 63;
   bool cand = false;
   if (T < PNP_LANES) {
     const PnpScratch MS(lds0 + T);
     cand = (MS.ld(MP_MASK) != 0.0) || (MS.ld(MP_MASK + 1) != 0.0) || (MS.ld(MP_MASK + 2) != 0.0);
   }
-  const unsigned em = __builtin_amdgcn_readfirstlane((unsigned)__ballot(cand));
-  if (em == 0u) return;                                             // uniform: the usual case away from the table
-  const int total = __popc(em);
-  int k = 0;
-  for (;;) {
-    if (ctr) {
-      unsigned g = 0;
-      if (T == 0) g = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      k = (int)__builtin_amdgcn_readfirstlane(g);
-    }
-    if (k >= total) break;
-    unsigned mm = em; for (int q = 0; q < k; q++) mm &= mm - 1u;
-    mesh_env(Pm, poly, lds0, __builtin_ctz(mm), ws);
-    if (!ctr) k++;
+  unsigned em = __builtin_amdgcn_readfirstlane((unsigned)__ballot(cand));
+  for (int k = 0; em != 0u; k++) {                                  // uniform
+    const int e = __builtin_ctz(em); em &= em - 1u;
+    if (k % nwaves == wave) mesh_env(Pm, poly, lds0, e, ws);
   }
 }
 
