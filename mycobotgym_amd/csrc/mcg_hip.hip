@@ -556,8 +556,9 @@ MCG_DEV void cube_wave(const CubeWaveArgs& C, const View& V, ModelPtr P, const r
       // longer than its solve's row slots: the environment's 18 dofs go to the cooperative solve
       kind = (CS.any_pad || CS.ncon > ROW_SLOTS / 12) ? 2 : 0;
       MS.st(XCH_FLAG, (real)(kind + (cbad ? 8 : 0)));
-      if (__any(kind != 0)) {
-        if ((threadIdx.x & 63) == 0 && C.cnt) atomicAdd(C.cnt + 3, (unsigned long long)__popc((unsigned)__ballot(kind != 0 && valid)));
+      const unsigned nflag = (unsigned)__popc((unsigned)__ballot(kind != 0 && valid));      // (the ballot OUTSIDE the one-lane branch: rounds 2-3 took it inside
+      if (nflag != 0u || __any(kind != 0)) {                                                 // and counted lane 0's flag only, 1/32 of the coupled env-sub-steps)
+        if ((threadIdx.x & 63) == 0 && C.cnt && nflag) atomicAdd(C.cnt + 3, (unsigned long long)nflag);
         if (kind != 0) { MS.st(XCH_NCON, (real)CS.ncon); MS.st(XCH_DR, dr[0]); MS.st(XCH_DR + 1, dr[1]); cube_to_lds(MS, CS.Cb); }      // hand the (normalised, not advanced) cube over
       }
       solver_numbers_share(P, MS, dr[1], 0);

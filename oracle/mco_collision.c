@@ -366,7 +366,15 @@ static int poly_far_from_box(const mco_model* m, const mco_data* d, int gb, int 
   return d2 > (rad + 1e-6) * (rad + 1e-6);
 }
 
+/* census of the list lengths an uncapped run would need (tools / tests: how often does the kernels' cap of 16 entries cut?) */
+long mco_entry_hist[MCO_MAXCON + 1];
+static void collide(const mco_model* m, mco_data* d);
 void mco_collision(const mco_model* m, mco_data* d) {
+  collide(m, d);
+  int k = d->nentry + d->ndrop; if (k > MCO_MAXCON) k = MCO_MAXCON;
+  __atomic_fetch_add(&mco_entry_hist[k], 1, __ATOMIC_RELAXED);
+}
+static void collide(const mco_model* m, mco_data* d) {
   d->ncon = 0; d->nentry = 0; d->ndrop = 0;
   /* the primitive geoms, in geom order: ground - pads, ground - cube, table - pads, table - cube, pads - cube (the order the kernels emit them in) */
   for (int g1 = 0; g1 < m->ngeom; g1++) for (int g2 = g1 + 1; g2 < m->ngeom; g2++) {
