@@ -47,13 +47,20 @@ constexpr int XCH_BADC = COOP_CTR_SLOT + 1;
 // rows 0-31], [rows 32-63 | rows 64-95] -- cleared at the start of an env-step.  The next sub-step's solve starts from it (see coop_guess).
 constexpr int XCH_ACT0 = XCH_BADC + 1, XCH_ACT1 = XCH_ACT0 + 1;
 static_assert(XCH_ACT1 + 1 <= LDS_POLY + 62, "exchange area (slots 62, 63: a stage-clock census)");
-// Line-search row area (LDS_ROW .. LDS_ROW + 144 slot rows of PNP_LANES doubles):
-//   [0, 96)    the cube wave's own solves (12 slots per contact, list positions 0..7: a lane whose cube contacts sit higher is flagged 2);
-//              between barriers S4 and S5, when every lane-parallel solve is over: cooperative workspace, 768 doubles per wave
-//   [96, 140)  columns of the FLAGGED lanes only: inputs of their cooperative solve, parked by the robot wave after S2
-constexpr int PUB_G0 = LDS_ROW + 96, PUB_SD = PUB_G0 + NB, PUB_AREF = PUB_SD + 10, PUB_WARM = PUB_AREF + 10;
+// Row area (LDS_ROW .. LDS_ROW + 144 slot rows of PNP_LANES doubles):
+//   between S1 and S1c: the frames of the bodies that carry candidate meshes (MP_FRAME, mcg_cube.hpp);
+//   after S2: [0, 144) the cube wave's own solves (12 slots per contact, list positions 0..11: a lane whose list is longer is flagged);
+//   between barriers S4 and S5, when every lane-parallel solve is over: [0, 96) cooperative workspace, 768 doubles per wave.
+// The inputs of a lane's cooperative solve, parked by the robot wave (PubHook) -- right after S1b when the workgroup has a mesh phase to
+// overlap with (then for every lane: the flags do not exist yet), else after S2 for the flagged lanes -- live in slots that are free from
+// S1b to S5: g0 in the robot's q(t) slots (read for the last time before S1b, rewritten when the sub-step ends), the warm start in the
+// bias-force slots (the robot wave has taken them; the RNE wave rewrites them after the next S1), the limit rows in the cube-alone
+// solve's mask slots (a flagged lane has no such solve; an unflagged lane's solve initialises its masks) and four slots of their own.
+constexpr int PUB_G0 = XCH_Q, PUB_WARM = PNP_SLOTS /* = XCH_FS */, PUB_SD = LDS_ACT, PUB_AREF_A = LDS_ACT + 10, PUB_AREF_B = PNP_SLOTS_ALL;
+MCG_DEV constexpr int pub_aref(int j) { return j < 6 ? PUB_AREF_A + j : PUB_AREF_B + (j - 6); }
+constexpr int PNP_SLOTS_LDS = PUB_AREF_B + 4;
+static_assert(MAXCON >= 16, "the limit rows borrow sixteen mask slots");
 constexpr int COOP_WS_ROW = LDS_ROW, COOP_WS_DOUBLES = 768;
-static_assert(PUB_WARM + NB <= LDS_ROW + ROW_SLOTS, "publish area");
 static_assert(4 * COOP_WS_DOUBLES <= 96 * PNP_LANES, "cooperative workspace exceeds the first 96 rows of the row area");
 constexpr int COOP_NV = 18, COOP_WIN = 16, COOP_WSTRIDE = 20;          // window: 16 active rows x (D, D aref, J[18])
 static_assert(COOP_WIN * COOP_WSTRIDE <= COOP_WS_DOUBLES && COOP_NV * COOP_NV + COOP_NV <= COOP_WS_DOUBLES, "window / matrix buffer");
@@ -147,7 +154,7 @@ MCG_DEV void coop_build_row(const PnpScratch ME, const CSYS& CS, const real* cpo
   const bool is_lim = r < 10;
   // limit row: J = sg e_j, D, aref from the robot wave
   const int jl = sel(is_lim, r, 0);
-  const real sD = ME.ld(PUB_SD + jl), al = ME.ld(PUB_AREF + jl);
+  const real sD = ME.ld(PUB_SD + jl), al = ME.ld(sel(jl < 6, PUB_AREF_A + jl, PUB_AREF_B + jl - 6));
   const real sgn = sel(sD > 0, 1.0, sel(sD < 0, -1.0, 0.0));
   // contact row
   const int rc = sel(is_lim, 0, r - 10);

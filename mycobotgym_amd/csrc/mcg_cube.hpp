@@ -55,12 +55,17 @@ MCG_DEV bool joint_in_chain(int j, int rb) {
   return rb >= 0 && (j < 6 ? j <= (rb < 5 ? rb : 5) : (j == 6 ? (rb == 6 || rb == 7) : (j == 8 ? (rb == 8 || rb == 9) : j == rb)));
 }
 
-// Row area between barriers S1 and S2 (its solves run after S2), columns of every lane: what the mesh phase (mcg_mesh.hpp) reads
-constexpr int MP_SN = LDS_ROW + 96, MP_CS = MP_SN + NB;          // sin / cos of AXS[i] q[i] (the M wave parks them)
-constexpr int MP_CUBE = MP_CS + NB;                              // the cube's position and (normalised) quaternion
+// What the mesh phase (mcg_mesh.hpp) reads, columns of every lane.  MP_FRAME: the row area, free between barriers S1 and S2 (its solves run
+// after S2): the world frame (rotation 9, origin 3) of each of the twelve robot bodies that carries a candidate mesh, parked by the wave
+// whose broad phase found it -- ONE producer per body (M wave: bodies 0-3, RNE wave: 4, 5, cube wave: 6-11), so that a frame is one
+// wave's arithmetic.  MP_*: twelve slots of their own behind the robot-side exchange slots.
+constexpr int MP_FRAME = LDS_ROW;
+static_assert(12 * NB <= ROW_SLOTS, "frames of the twelve bodies");
+constexpr int MP_CUBE = PNP_SLOTS + NB;                          // the cube's position (published when a sub-step ENDS: the M / RNE waves' broad phase reads it
+                                                                 // before S1b) and its normalised quaternion (written after S1, read in the mesh phase)
 constexpr int MP_MASK = MP_CUBE + 7;                             // candidate pairs of the broad phases: M wave, RNE wave, cube wave (bit 3 m + o; o: ground, table, cube)
 constexpr int MP_NCON = MP_MASK + 3, MP_DROP = MP_NCON + 1;     // the list's length (the mesh phase appends); contacts the cap cut there
-static_assert(MP_DROP + 1 <= LDS_ROW + ROW_SLOTS, "mesh-phase slots");
+constexpr int PNP_SLOTS_ALL = MP_DROP + 1;
 
 struct Cube {
   real pos[3], quat[4], vel[6], warm[6];     // vel = world linear velocity, body-frame angular velocity (MuJoCo free joint)
@@ -284,33 +289,37 @@ MCG_DEV int mesh_broad(ModelPtr Pm, int m, const real* R, const real* p, const r
     c[r] = p[r] + R[3*r]*bx[0] + R[3*r+1]*bx[1] + R[3*r+2]*bx[2];
     e[r] = fabs(R[3*r])*bx[3] + fabs(R[3*r+1])*bx[4] + fabs(R[3*r+2])*bx[5];
   }
-  int bits = 0;
-  if (statics) {
-    bits |= sel(c[2] - e[2] < 0, 1, 0);                                  // ground: the box's lowest point
-    bool near = true;                                                    // table: its three face axes, then the box's own three
-    _Pragma("unroll") for (int r = 0; r < 3; r++) near = near && !(fabs(c[r] - tp[r]) > th[r] + e[r]);
-    _Pragma("unroll") for (int k = 0; k < 3; k++) {
-      const real rel = R[k]*(c[0] - tp[0]) + R[3 + k]*(c[1] - tp[1]) + R[6 + k]*(c[2] - tp[2]);
-      const real rad = fabs(R[k])*th[0] + fabs(R[3 + k])*th[1] + fabs(R[6 + k])*th[2];
-      near = near && !(fabs(rel) > bx[3 + k] + rad);
-    }
-    bits |= sel(near, 2, 0);
+  // (per-lane selects, no lane-divergent branch: see the compiler hazard in mcg_dynamics.hpp)
+  const bool ground = c[2] - e[2] < 0;                                  // ground: the box's lowest point
+  bool table = true;                                                    // table: its three face axes, then the box's own three
+  _Pragma("unroll") for (int r = 0; r < 3; r++) table = table && !(fabs(c[r] - tp[r]) > th[r] + e[r]);
+  bool near = true;                                                     // the cube's bounding sphere against the box, in the box's frame
+  _Pragma("unroll") for (int k = 0; k < 3; k++) {
+    const real rel = R[k]*(c[0] - tp[0]) + R[3 + k]*(c[1] - tp[1]) + R[6 + k]*(c[2] - tp[2]);
+    const real rad = fabs(R[k])*th[0] + fabs(R[3 + k])*th[1] + fabs(R[6 + k])*th[2];
+    table = table && !(fabs(rel) > bx[3 + k] + rad);
+    near = near && !(fabs(R[k]*(cpos[0] - c[0]) + R[3 + k]*(cpos[1] - c[1]) + R[6 + k]*(cpos[2] - c[2])) > bx[3 + k] + crad);
   }
-  if (cube) {                                                            // the cube's bounding sphere against the box, in the box's frame
-    bool near = true;
-    _Pragma("unroll") for (int k = 0; k < 3; k++) near = near && !(fabs(R[k]*(cpos[0] - c[0]) + R[3 + k]*(cpos[1] - c[1]) + R[6 + k]*(cpos[2] - c[2])) > bx[3 + k] + crad);
-    bits |= sel(near, 4, 0);
-  }
-  return bits;
+  return sel(statics && ground, 1, 0) | sel(statics && table, 2, 0) | sel(cube && near, 4, 0);
 }
 
 // ---- the arm meshes' broad phase against the table and the ground, on the M / RNE waves of the four-wave kernel (they hold the arm's
 // sines / cosines anyway and are done long before the cube wave: round 3 had them run the whole 16-axis test here, ~27 k clocks; the
 // exact narrow phase now runs one pair per wave behind this filter).  M: meshes 0-3, RNE: 4-7 (links 5, 6, flange, gripper base).
+MCG_DEV void park_frame(const PnpScratch& S, int body, const real* R, const real* p, bool doit) {
+  if (__any(doit)) {                                               // wave-uniform
+    if (doit) {                                                    // plain LDS stores of live registers
+      _Pragma("unroll") for (int k = 0; k < 9; k++) S.st(MP_FRAME + body * 12 + k, R[k]);
+      _Pragma("unroll") for (int k = 0; k < 3; k++) S.st(MP_FRAME + body * 12 + 9 + k, p[k]);
+    }
+  }
+}
 template <int P0, int P1, class LS>
 MCG_DEV void arm_broad_stage(ModelPtr Pm, const LS S, const real* sn, const real* cs, int mask_slot) {
   ModelPtr Q = launder(Pm);
-  real tp[3], th[3]; ldc<3>(Q->table_pos, tp); ldc<3>(Q->table_half, th);
+  real tp[3], th[3], hc[3]; ldc<3>(Q->table_pos, tp); ldc<3>(Q->table_half, th); ldc<3>(Q->cube_half, hc);
+  const real crad = sqrt(dot3(hc, hc));
+  const real cpos[3] = {S.ld(MP_CUBE), S.ld(MP_CUBE + 1), S.ld(MP_CUBE + 2)};      // (published when the last sub-step ended)
   real R[9], p[3];
   _Pragma("unroll") for (int k = 0; k < 9; k++) R[k] = Q->base_mat[k];
   _Pragma("unroll") for (int k = 0; k < 3; k++) p[k] = Q->base_pos[k];
@@ -326,9 +335,15 @@ MCG_DEV void arm_broad_stage(ModelPtr Pm, const LS S, const real* sn, const real
       R[3*k + A] = cs_ * ca + sn_ * cb; R[3*k + B] = -sn_ * ca + cs_ * cb;
     }
     if constexpr (i >= (P0 < 5 ? P0 : 5)) {
-      if (__any(p[2] - rad < tp[2] + th[2])) {                    // wave-uniform: the body's bounding sphere reaches the table top's height
-        if constexpr (i < 5) bits |= mesh_broad(Pm, i, R, p, tp, th, true, false, p, 0.0) << (3 * i);
-        else { static_for<P1 - (P0 > 5 ? P0 : 5)>([&](auto Mm) { constexpr int m = (P0 > 5 ? P0 : 5) + Mm; bits |= mesh_broad(Pm, m, R, p, tp, th, true, false, p, 0.0) << (3 * m); }); }
+      const real dx = p[0] - cpos[0], dy = p[1] - cpos[1], dz = p[2] - cpos[2];
+      const bool ncube = dx*dx + dy*dy + dz*dz < (rad + crad) * (rad + crad);      // the body's bounding sphere reaches the cube's
+      const bool nstat = p[2] - rad < tp[2] + th[2];                               // ... the table top's height
+      if (__any(ncube || nstat)) {                                // wave-uniform
+        int bb = 0;
+        if constexpr (i < 5) bb = mesh_broad(Pm, i, R, p, tp, th, nstat, ncube, cpos, crad) << (3 * i);
+        else { static_for<P1 - (P0 > 5 ? P0 : 5)>([&](auto Mm) { constexpr int m = (P0 > 5 ? P0 : 5) + Mm; bb |= mesh_broad(Pm, m, R, p, tp, th, nstat, ncube, cpos, crad) << (3 * m); }); }
+        park_frame(S, i, R, p, bb != 0);
+        bits |= bb;
       }
     } });
   S.st(mask_slot, (real)bits);
@@ -338,20 +353,18 @@ MCG_DEV void arm_broad_stage(ModelPtr Pm, const LS S, const real* sn, const real
 // M wave 1, the RNE wave 2, between barriers S1c (the list is complete: the mesh phase has appended its contacts) and S2.  The
 // contact-at-a-time pass of the cube wave alone sat on the workgroup's critical path with three waves waiting
 // (profiles/r03/ab_critical_path_probes.log).  The independent contacts of a wave's share are separate chains in one stretch of code.
-constexpr int NUM_SHARE = (MAXCON + 2) / 3;
+constexpr int NUM_GROUP = 2;                                      // list positions per stretch of code: r0 + 3 u, u = 2 g .. 2 g + 1
 template <class LS>
-MCG_DEV void solver_numbers_share(ModelPtr Pm, const LS S, real dr1, int r0) {
+MCG_DEV void solver_numbers_group(ModelPtr Pm, const LS S, real dr1, int r0, int ncon) {
   ModelPtr Q = launder(Pm);
-  const int ncon = (int)S.ld(MP_NCON);
-  if (!__any(r0 < ncon)) return;                                                  // wave-uniform
-  real dist[NUM_SHARE], mult[NUM_SHARE]; int type[NUM_SHARE]; bool in[NUM_SHARE];
-  _Pragma("unroll") for (int u = 0; u < NUM_SHARE; u++) {
+  real dist[NUM_GROUP], mult[NUM_GROUP]; int type[NUM_GROUP]; bool in[NUM_GROUP];
+  _Pragma("unroll") for (int u = 0; u < NUM_GROUP; u++) {
     const int c = r0 + 3 * u; in[u] = c < ncon;
     const int b = LDS_CON + sel(c < MAXCON, c, MAXCON - 1) * CON_STRIDE;
     dist[u] = S.ld(b + CON_DIST); mult[u] = S.ld(b + CON_D); type[u] = sel(in[u], (int)S.ld(b + CON_TYPE), 0);
   }
   bool amc = false, atp = false, ams = false;
-  _Pragma("unroll") for (int u = 0; u < NUM_SHARE; u++) {
+  _Pragma("unroll") for (int u = 0; u < NUM_GROUP; u++) {
     amc = amc || pair_mesh_cube(type[u]); atp = atp || type[u] == PAIR_TABLE_PADR || type[u] == PAIR_TABLE_PADL; ams = ams || pair_mesh_static(type[u]);
   }
   amc = __any(amc); atp = __any(atp); ams = __any(ams);
@@ -360,19 +373,19 @@ MCG_DEV void solver_numbers_share(ModelPtr Pm, const LS S, real dr1, int r0) {
   real par_t[10], par_p[10];
   ldc<10>(Q->contact_par[PAIR_TABLE_CUBE], par_t); ldc<10>(Q->contact_par[PAIR_PADR_CUBE], par_p);
   const real rpy = Q->contact_rpy;
-  real imp[NUM_SHARE], kk[NUM_SHARE], m0[NUM_SHARE], tran[NUM_SHARE];
-  _Pragma("unroll") for (int u = 0; u < NUM_SHARE; u++) {
+  real imp[NUM_GROUP], kk[NUM_GROUP], m0[NUM_GROUP], tran[NUM_GROUP];
+  _Pragma("unroll") for (int u = 0; u < NUM_GROUP; u++) {
     const bool padcube = type[u] == PAIR_PADR_CUBE || type[u] == PAIR_PADL_CUBE;
     imp[u] = sel(padcube, impedance(par_p, dist[u]), impedance(par_t, dist[u]));
     kk[u] = sel(padcube, par_p[0], par_t[0]);
     m0[u] = sel(padcube, mu_pc0, mu_tc0);
-    { const CRealPtr pt = &Pm->pair_tran[0]; tran[u] = pt[type[u]]; }                        // (a per-lane index: a vector load from the model block)
+    { const CRealPtr pt = &Pm->pair_tran[0]; tran[u] = pt[type[u]]; }      // (a per-lane index: a vector load from the model block)
   }
   if (amc) {
     ModelPtr Qb = launder(Pm);
     real par_mc[10]; ldc<10>(Qb->contact_par[PAR_MESH_CUBE], par_mc);
     const real mu_mc0 = fmax(Qb->mesh_fric, fcb);
-    _Pragma("unroll") for (int u = 0; u < NUM_SHARE; u++) {
+    _Pragma("unroll") for (int u = 0; u < NUM_GROUP; u++) {
       const bool mc = pair_mesh_cube(type[u]);
       imp[u] = sel(mc, impedance(par_mc, dist[u]), imp[u]); kk[u] = sel(mc, par_mc[0], kk[u]); m0[u] = sel(mc, mu_mc0, m0[u]);
     }
@@ -380,7 +393,7 @@ MCG_DEV void solver_numbers_share(ModelPtr Pm, const LS S, real dr1, int r0) {
   if (atp) {
     ModelPtr Qb = launder(Pm);
     real par_tp[10]; ldc<10>(Qb->contact_par[PAIR_TABLE_PADR], par_tp);
-    _Pragma("unroll") for (int u = 0; u < NUM_SHARE; u++) {
+    _Pragma("unroll") for (int u = 0; u < NUM_GROUP; u++) {
       const bool tabp = type[u] == PAIR_TABLE_PADR || type[u] == PAIR_TABLE_PADL;
       imp[u] = sel(tabp, impedance(par_tp, dist[u]), imp[u]); kk[u] = sel(tabp, par_tp[0], kk[u]); m0[u] = sel(tabp, mu_tp0, m0[u]);
     }
@@ -388,16 +401,22 @@ MCG_DEV void solver_numbers_share(ModelPtr Pm, const LS S, real dr1, int r0) {
   if (ams) {
     ModelPtr Qb = launder(Pm);
     real par_tl[11]; ldc<11>(Qb->contact_par[PAR_TABLE_MESH], par_tl);
-    _Pragma("unroll") for (int u = 0; u < NUM_SHARE; u++) {
+    _Pragma("unroll") for (int u = 0; u < NUM_GROUP; u++) {
       const bool ms = pair_mesh_static(type[u]);
       imp[u] = sel(ms, impedance(par_tl, dist[u]), imp[u]); kk[u] = sel(ms, par_tl[0], kk[u]); m0[u] = sel(ms, par_tl[10], m0[u]);
     }
   }
-  _Pragma("unroll") for (int u = 0; u < NUM_SHARE; u++) {
+  _Pragma("unroll") for (int u = 0; u < NUM_GROUP; u++) {
     const real Rn = fmax(MINVAL, (1 - imp[u]) * tran[u] * (1 + m0[u]*m0[u]) / imp[u]);
     const real Rpy = fmax(MINVAL, rpy * m0[u]*m0[u] * Rn);
     if (in[u]) { const int b = LDS_CON + (r0 + 3 * u) * CON_STRIDE; S.st(b + CON_D, mult[u] / Rpy); S.st(b + CON_KTERM, kk[u] * imp[u] * dist[u]); }
   }
+}
+template <class LS>
+MCG_DEV void solver_numbers_share(ModelPtr Pm, const LS S, real dr1, int r0) {
+  const int ncon = (int)S.ld(MP_NCON);
+  for (int g = 0; __any(r0 + 3 * NUM_GROUP * g < ncon); g++)                      // wave-uniform: as many groups as the longest list needs
+    solver_numbers_group(Pm, S, dr1, r0 + 3 * NUM_GROUP * g, ncon);
 }
 
 // The cube and its contacts for one sub-step: prepared before the robot's Newton solve, finished after it.
@@ -508,21 +527,26 @@ struct CubeSys {
           Rio[3*k + A] = cs_ * ca + sn_ * cb; Rio[3*k + B] = -sn_ * ca + cs_ * cb;
         }
       };
-      // a mesh's candidate bits: against the cube always here; against the table / the ground here for the gripper's parts (and for the
-      // arm's when ARM)
-      auto broad = [&](int m, const real* Rio, const real* pio, bool statics, bool cube) {
-        if constexpr (MESHES) mbits |= (long long)mesh_broad(Pm, m, Rio, pio, tp, th, statics, cube, Cb.pos, crad) << (3 * m);
+      // a mesh's candidate bits and, with a candidate, its body's frame for the mesh phase.  The gripper's parts here; the arm's in the
+      // M / RNE waves (arm_broad_stage) unless ARM
+      auto broad = [&](int m, int body, const real* Rio, const real* pio, bool statics, bool cube) {
+        if constexpr (MESHES) {
+          const int bb = mesh_broad(Pm, m, Rio, pio, tp, th, statics, cube, Cb.pos, crad);
+          mbits |= (long long)bb << (3 * m);
+          return bb != 0;
+        } else return false;
       };
       static_for<6>([&](auto I) { constexpr int i = I; real r[3]; ldc<3>(Q->body[i].r, r);
         const real rad = Q->body[i].hull_rad;                             // comes with the same batch of scalar loads as r
         joint(i, AXK[i], AXS[i], r, qr[i], R, p);
-        if constexpr (MESHES) {
+        if constexpr (MESHES && ARM) {
           const real dx = p[0] - Cb.pos[0], dy = p[1] - Cb.pos[1], dz = p[2] - Cb.pos[2];
           const bool ncube = dx*dx + dy*dy + dz*dz < (rad + crad) * (rad + crad);      // the body's bounding sphere reaches the cube's
-          const bool nstat = ARM && (p[2] - rad < tp[2] + th[2]);                      // ... the table top's height
+          const bool nstat = p[2] - rad < tp[2] + th[2];                               // ... the table top's height
           if (__any(ncube || nstat)) {
-            broad(i, R, p, nstat, ncube);
-            if constexpr (i == 5) { broad(6, R, p, nstat, ncube); broad(7, R, p, nstat, ncube); }
+            bool any = broad(i, i, R, p, nstat, ncube);
+            if constexpr (i == 5) { any = broad(6, 5, R, p, nstat, ncube) || any; any = broad(7, 5, R, p, nstat, ncube) || any; }
+            park_frame(S, i, R, p, any);
           }
         } });
       MCG_TICK2(ST_A_G);
@@ -541,9 +565,9 @@ struct CubeSys {
           _Pragma("unroll") for (int k = 0; k < 9; k++) Rs[sd][k] = R[k];
           _Pragma("unroll") for (int k = 0; k < 3; k++) ps[k] = p[k];
           real r[3]; ldc<3>(Q->body[g].r, r); joint(g, 1, AXS[g], r, qr[g], Rs[sd], ps);
-          broad(8 + 2 * sd, Rs[sd], ps, nearstat, reach);                               // gear link
+          park_frame(S, g, Rs[sd], ps, broad(8 + 2 * sd, g, Rs[sd], ps, nearstat, reach));      // gear link
           ldc<3>(Q->body[f].r, r); joint(f, 1, AXS[f], r, qr[f], Rs[sd], ps);
-          broad(9 + 2 * sd, Rs[sd], ps, nearstat, reach);                               // finger link
+          park_frame(S, f, Rs[sd], ps, broad(9 + 2 * sd, f, Rs[sd], ps, nearstat, reach));      // finger link
           real pb[6]; ldc<6>(Q->pad_box[sd], pb);
           _Pragma("unroll") for (int k = 0; k < 3; k++) { pc[sd][k] = ps[k] + Rs[sd][3*k]*pb[0] + Rs[sd][3*k+1]*pb[1] + Rs[sd][3*k+2]*pb[2]; ph[sd][k] = pb[3 + k]; }
           // the hinge link of this side (its joint hangs on link6)
@@ -551,7 +575,7 @@ struct CubeSys {
           _Pragma("unroll") for (int k = 0; k < 9; k++) Rh[k] = R[k];
           _Pragma("unroll") for (int k = 0; k < 3; k++) phg[k] = p[k];
           ldc<3>(Q->body[10 + sd].r, r); joint(10 + sd, 1, AXS[10 + sd], r, qr[10 + sd], Rh, phg);
-          broad(12 + sd, Rh, phg, nearstat, reach);
+          park_frame(S, 10 + sd, Rh, phg, broad(12 + sd, 10 + sd, Rh, phg, nearstat, reach));
         });
       }
     }
@@ -596,7 +620,7 @@ struct CubeSys {
     MCG_TICK2(ST_A_MAP);
     ncon = CL.n; ndropped = CL.ndrop;
     if constexpr (MESHES) {
-      _Pragma("unroll") for (int k = 0; k < 3; k++) S.st(MP_CUBE + k, Cb.pos[k]);
+      if constexpr (ARM) { _Pragma("unroll") for (int k = 0; k < 3; k++) S.st(MP_CUBE + k, Cb.pos[k]); }      // (else: published when the last sub-step ended)
       _Pragma("unroll") for (int k = 0; k < 4; k++) S.st(MP_CUBE + 3 + k, Cb.quat[k]);
       S.st(MP_MASK + 2, (real)mbits); S.st(MP_NCON, (real)ncon); S.st(MP_DROP, 0.0);
       if constexpr (ARM) { S.st(MP_MASK, 0.0); S.st(MP_MASK + 1, 0.0); }

@@ -40,7 +40,8 @@ constexpr real MINVAL = 1e-15, MINIMP = 1e-4, MAXIMP = 0.9999;
 // accumulates shader-clock deltas per pipeline stage in LDS and adds them to a device-global table at kernel end.
 enum { ST_LOAD = 0, ST_CTRL, ST_TRIG, ST_RNE, ST_ACT, ST_CRB, ST_ROWS, ST_G0, ST_NEWTON, ST_EULER, ST_COLLIDE, ST_CUBE,
        ST_COUPLED, ST_CUBE_FIN, ST_POST, ST_N_BUILD, ST_N_FACTOR, ST_N_SOLVE, ST_N_CHECK, ST_E_RHS, ST_R_AX5, ST_R_CONNECT, ST_R_LIMITS, ST_C_MASK, ST_C_ASSEMBLE, ST_C_SCHUR, ST_C_SOLVE, ST_C_CHECK, ST_C_LS, ST_W2_WAIT1, ST_W2_COLLIDE, ST_W2_CUBE, ST_W2_WAIT2, ST_W1_WAIT, ST_A_ENTRY, ST_A_G, ST_A_TWIST, ST_A_LOOP, ST_A_MAP, ST_A_STORE,
-       ST_CO_SETUP, ST_CO_ROWS, ST_CO_H0, ST_CO_RESID, ST_CO_ASM, ST_CO_FACTOR, ST_CO_SOLVE, ST_CO_CHECK, ST_CO_LS, ST_CO_OUT, ST_CO_IDLE, ST_COUNT,
+       ST_CO_SETUP, ST_CO_ROWS, ST_CO_H0, ST_CO_RESID, ST_CO_ASM, ST_CO_FACTOR, ST_CO_SOLVE, ST_CO_CHECK, ST_CO_LS, ST_CO_OUT, ST_CO_IDLE,
+       ST_X_S1C, ST_X_NUMBERS, ST_X_S2, ST_S_S1B, ST_S_MESH, ST_S_S1C, ST_S_NUMBERS, ST_COUNT,
        CN_SUBSTEP = 0, CN_NEWTON_IT, CN_LINESEARCH, CN_CUBE_IT, CN_CUBE_LS, CN_COUPLED, CN_COUPLED_IT, CN_COUPLED_LS, CN_CONTACTS, CN_COOP_ROWS, CN_COOP_LSEVAL, CN_COOP_LONG, CN_COOP_CAP, CN_COOP_12, CN_G_FAILED, CN_G_LIM, CN_G_STAT, CN_G_CUBE, CN_G_MISSING, CN_G_EXTRA, CN_G_EQ1, CN_G_EQ2, CN_G_EQ2N1, CN_COUNT };
 #ifdef MCG_STAGE_CLOCKS
 __device__ unsigned long long g_stage_clocks[ST_COUNT + CN_COUNT];      // stage clocks, then event counts (summed over waves)
@@ -860,13 +861,21 @@ MCG_DEV bool robot_substep(ModelPtr Pm, Robot& S, real* qlag6, const LS MS, CPL*
 #if MCG_DUP == 3        // critical-path probe: the robot wave's assembly twice (same numbers to the same slots)
   if constexpr (SPL::early_heq && SPL::mesh_split) { MCG_FENCE(); static_for<2>([&](auto Sd) { constexpr int sd = Sd; pin(Dc[sd]); }); assemble_heq(std::false_type{}); }
 #endif
+  // Four-wave PickAndPlace kernel: M and passive - bias are in LDS at S1b already; S1c and S2 only fence the other three waves' mesh
+  // phase and solver numbers.  When the workgroup HAS a mesh phase (some lane's candidate mask is set: the same masks every wave reads)
+  // this wave runs its whole solve now, under it, and passes S1c / S2 when it is done; when it has none the solve stays behind S2, where
+  // it runs beside the cube wave's own solve as before.
+  bool ahead = false;
   if constexpr (SPL::enabled) {
-    if constexpr (SPL::mesh_split) { __syncthreads(); __syncthreads(); }      // S1b, S1c (four-wave PickAndPlace kernel: the M / RNE waves' arm-mesh contacts are staged; the merged list is published)
-    __syncthreads();                                                // S2: M and passive - bias are in LDS
+    if constexpr (SPL::mesh_split) {
+      __syncthreads();                                              // S1b
+      ahead = __any(MS.ld(SPL::MASK0) != 0.0 || MS.ld(SPL::MASK0 + 1) != 0.0 || MS.ld(SPL::MASK0 + 2) != 0.0);
+      if (!ahead) { __syncthreads(); __syncthreads(); }             // S1c, S2
+    } else __syncthreads();                                         // S2: M and passive - bias are in LDS
     if constexpr (SPL::rne_remote) static_for<NB>([&](auto I) { constexpr int i = I; fs[i] += MS.ld(SPL::FS + i); });
   }
   static_for<NB>([&](auto I) { constexpr int i = I; g0[i] += fs[i]; });
-  if constexpr (CPL::publishes) CP->publish(g0, Dl, arefl, sgl, S.qd, S.warm);
+  if constexpr (CPL::publishes) CP->publish(g0, Dl, arefl, sgl, S.qd, S.warm, !ahead);
   if constexpr (!SPL::early_heq) assemble_heq(std::true_type{});
   auto build_H = [&](real* H, const bool* act_) {
     static_for<NB>([&](auto I) { constexpr int i = I;
@@ -1085,6 +1094,7 @@ MCG_DEV bool robot_substep(ModelPtr Pm, Robot& S, real* qlag6, const LS MS, CPL*
     if constexpr (SPL::enabled && COMMIT) { MS.st(SPL::QB + i, q_new); MS.st(SPL::QDB + i, qd_new); } });
   MCG_TICK_PIN(S.q, NB); MCG_TICK_PIN(S.qd, NB);
   MCG_TICK(ST_EULER);
+  if constexpr (SPL::enabled && SPL::mesh_split) { if (ahead) { __syncthreads(); __syncthreads(); } }      // S1c, S2
   return bad;
 }
 

@@ -459,27 +459,29 @@ MCG_DEV void hide_object(real* obs, real* ag) {
 // the cube wave adds its verdict on the cube as bit 3 of the flag it publishes before S2 (the robot wave reads the flag after S4 and
 // resets the robot's new state).  mj_resetData resets BOTH bodies; the other body follows one sub-step late here.
 // Exchange slots: mcg_coop.hpp.
-constexpr int XCH_FS = PNP_SLOTS;                 // + 12 slots
-constexpr int PNP_SLOTS_DUAL = PNP_SLOTS + NB;
+constexpr int XCH_FS = PNP_SLOTS;                 // + 12 slots, then the mesh phase's twelve (MP_CUBE ..), then four of the parked limit rows
+constexpr int PNP_SLOTS_DUAL = PNP_SLOTS_LDS;
 static_assert(PNP_SLOTS_DUAL * PNP_LANES * 8 <= 160 * 1024, "LDS of a CU");
 // robot-side split of the four-wave PickAndPlace kernel: M from the helper wave, passive - bias from the RNE wave, the constraint
 // part of H_eq assembled before barrier S2; the Euler step stays with M a (no room for the factor in LDS)
 struct SplitPnp { static constexpr bool enabled = true, rne_remote = true, factor_remote = false, early_heq = true, warm_lds = false, mesh_split = true;
-                  static constexpr int QB = XCH_Q, QDB = XCH_QD, FS = XCH_FS, WARM = 0, QLAG = 0; };
+                  static constexpr int QB = XCH_Q, QDB = XCH_QD, FS = XCH_FS, WARM = 0, QLAG = 0, MASK0 = MP_MASK; };
 
 MCG_DEV bool flag_coupled(real f) { return (((int)f) & 2) != 0; }       // XCH_FLAG: bit 1 = the environment goes to the cooperative solve,
 MCG_DEV bool flag_cube_bad(real f) { return (((int)f) & 8) != 0; }      // bit 3 = the cube failed mj_checkPos / mj_checkVel / mj_checkAcc
 
-// the robot wave's hook into robot_substep: park a flagged lane's Newton inputs in its own column of the row area
+// the robot wave's hook into robot_substep: park a lane's Newton inputs for the cooperative solve (slots: mcg_coop.hpp).  flags_known: the
+// cube wave has published the flags (after S2): only the flagged lanes are parked; else (the robot wave runs ahead of the mesh phase)
+// every lane is
 struct PubHook {
   static constexpr bool enabled = false, publishes = true;
   const PnpScratch S;
-  MCG_DEV void publish(const real* g0, const real* Dl, const real* arefl, const real* sgl, const real* qd, const real* warm) const {
-    const bool flag = flag_coupled(S.ld(XCH_FLAG));                  // the cube wave wrote it before S2
+  MCG_DEV void publish(const real* g0, const real* Dl, const real* arefl, const real* sgl, const real* qd, const real* warm, bool flags_known) const {
+    const bool flag = !flags_known || flag_coupled(S.ld(XCH_FLAG));
     if (__any(flag)) {                                               // wave-uniform
       if (flag) {                                                    // plain LDS stores of live registers
         static_for<NB>([&](auto I) { constexpr int k = I; S.st(PUB_G0 + k, g0[k]); S.st(PUB_WARM + k, warm[k]); });      // (qd(t) is in its exchange slots)
-        static_for<10>([&](auto I) { constexpr int j = I; S.st(PUB_SD + j, sgl[j] * Dl[j]); S.st(PUB_AREF + j, arefl[j]); });
+        static_for<10>([&](auto I) { constexpr int j = I; S.st(PUB_SD + j, sgl[j] * Dl[j]); S.st(pub_aref(j), arefl[j]); });
       }
     }
   }
@@ -500,7 +502,6 @@ MCG_DEV void cube_from_lds(const PnpScratch MS, Cube& Cb) {
 MCG_DEV unsigned flagged_lanes(const PnpScratch MS, int nvalid) {
   return (unsigned)__ballot(flag_coupled(MS.ld(XCH_FLAG))) & (nvalid >= 32 ? 0xFFFFFFFFu : ((1u << nvalid) - 1u));
 }
-MCG_DEV LdsPtr wave_workspace(unsigned lds0, int w) { return (LdsPtr)(uintptr_t)lds0 + COOP_WS_ROW * PNP_LANES + w * COOP_WS_DOUBLES; }
 
 // the cube wave's whole env-step.  `lower`: lanes 0-31 carry the 32 environments; lanes 32-63 are alive for the mesh phase and the
 // cooperative phase only
@@ -516,6 +517,7 @@ MCG_DEV void cube_wave(const CubeWaveArgs& C, const View& V, ModelPtr P, const r
     for (int k = 0; k < 6; k++) { Cb.vel[k] = V.qvel(12 + k, i); Cb.warm[k] = V.warm(12 + k, i); }
     for (int k = 0; k < 7; k++) qlag7[k] = V.qlag(12 + k, i);
     dr[0] = V.dr(0, i); dr[1] = V.dr(1, i);
+    for (int k = 0; k < 3; k++) MS.st(MP_CUBE + k, Cb.pos[k]);        // for the M / RNE waves' broad phase (read after S1)
   }
   MCG_TICK2_INIT();
   for (int s = 0; s < total; s++) {
@@ -539,6 +541,7 @@ MCG_DEV void cube_wave(const CubeWaveArgs& C, const View& V, ModelPtr P, const r
           for (int k = 0; k < 4; k++) Cb.quat[k] = sel(reset, C.qpos0_cube[3 + k], Cb.quat[k]);
           for (int k = 0; k < 6; k++) { Cb.vel[k] = sel(reset, 0.0, Cb.vel[k]); Cb.warm[k] = sel(reset, 0.0, Cb.warm[k]); }
           CS.Cb = Cb;
+          if (reset) { for (int k = 0; k < 3; k++) MS.st(MP_CUBE + k, Cb.pos[k]); }      // (the M / RNE waves' broad phase of THIS sub-step may still see the old position)
           if (__any(cbad)) { if (cbad && valid && C.cnt) atomicAdd(C.cnt + 1, 1ull); }
         }
       }
@@ -547,8 +550,11 @@ MCG_DEV void cube_wave(const CubeWaveArgs& C, const View& V, ModelPtr P, const r
       MCG_TICK2(ST_W2_COLLIDE);
     }
     __syncthreads();                                                // S1b
-    mesh_phase(P, poly, (LdsPtr)(uintptr_t)lds0, wave_workspace(lds0, 1), 0, 3);
+    MCG_TICK2(ST_CUBE_FIN);
+    mesh_phase(P, poly, (LdsPtr)(uintptr_t)lds0, 0, 3);
+    MCG_TICK2(ST_COLLIDE);
     __syncthreads();                                                // S1c: every list is complete
+    MCG_TICK2(ST_X_S1C);
     if (lower) {
       CS.collect_list();
       touch = CS.touch[0] && CS.touch[1];
@@ -562,9 +568,11 @@ MCG_DEV void cube_wave(const CubeWaveArgs& C, const View& V, ModelPtr P, const r
         if (kind != 0) { MS.st(XCH_NCON, (real)CS.ncon); MS.st(XCH_DR, dr[0]); MS.st(XCH_DR + 1, dr[1]); cube_to_lds(MS, CS.Cb); }      // hand the (normalised, not advanced) cube over
       }
       solver_numbers_share(P, MS, dr[1], 0);
+      MCG_TICK2(ST_X_NUMBERS);
       __syncthreads();                                              // S2 (the robot side's "M and bias ready")
+      MCG_TICK2(ST_X_S2);
       CS.solve_alone(kind == 2, false);                             // flagged lanes walk an empty list, store nothing
-      if (!__any(kind == 2)) { CS.finish(qlag7); Cb = CS.Cb; }
+      if (!__any(kind == 2)) { CS.finish(qlag7); Cb = CS.Cb; for (int k = 0; k < 3; k++) MS.st(MP_CUBE + k, Cb.pos[k]); }
       MCG_TICK2(ST_W2_CUBE);
     }
     __syncthreads();                                                // S4: end of the lane-parallel part
@@ -578,6 +586,7 @@ MCG_DEV void cube_wave(const CubeWaveArgs& C, const View& V, ModelPtr P, const r
       if (lower) {
         _Pragma("unroll") for (int k = 0; k < 6; k++) CS.a_c[k] = sel(kind == 2, MS.ld(XCH_CB + 13 + k), CS.a_c[k]);
         CS.finish(qlag7); Cb = CS.Cb;
+        for (int k = 0; k < 3; k++) MS.st(MP_CUBE + k, Cb.pos[k]);
       }
     }
   }
@@ -638,27 +647,29 @@ MCG_DEV bool pnp_substep_robot(const Cfg& C, ModelPtr P, EnvP& E, const PnpScrat
 // the helper / RNE waves of the four-wave PickAndPlace kernel: same barriers as the cube wave; lanes 32-63 are alive for the mesh phase
 // and the cooperative phase only
 // (inlined into the kernel: these waves hold nothing across a sub-step, so the inlined phases spill nothing)
-// what a side wave does between S1 and S1b besides its own share: the broad phase of four arm meshes against the table / the ground;
-// the M wave also parks the sines / cosines for the mesh phase's forward kinematics
-template <int P0, int P1, bool PARK> struct PnpSideWork {
+// what a side wave does between S1 and S1b besides its own share: the broad phase of four arm meshes against the table, the ground and
+// the cube, parking the frames of the bodies that carry a candidate
+template <int P0, int P1> struct PnpSideWork {
   ModelPtr P; const PnpScratch MS; int mask_slot;
-  MCG_DEV void operator()(const real* sn, const real* cs) const {
-    if constexpr (PARK) static_for<NB>([&](auto I) { constexpr int k = I; MS.st(MP_SN + k, sn[k]); MS.st(MP_CS + k, cs[k]); });
-    arm_broad_stage<P0, P1>(P, MS, sn, cs, mask_slot);
-  }
+  MCG_DEV void operator()(const real* sn, const real* cs) const { arm_broad_stage<P0, P1>(P, MS, sn, cs, mask_slot); }
 };
 MCG_DEV void pnp_side_wave(ModelPtr P, const real* __restrict__ poly, const PnpScratch MS, unsigned lds0, int total, bool rne, bool lower, bool pair, real dr1, int nvalid) {
   MCG_TICK_INIT();
   for (int s = 0; s < total; s++) {
     if (lower) {                                                    // S1 inside; its own share, then the arm meshes' broad phase
-      if (rne) rne_pre<SplitPnp>(P, MS, PnpSideWork<4, 8, false>{P, MS, MP_MASK + 1});
-      else helper_pre<SplitPnp>(P, MS, PnpSideWork<0, 4, true>{P, MS, MP_MASK});
+      if (rne) rne_pre<SplitPnp>(P, MS, PnpSideWork<4, 8>{P, MS, MP_MASK + 1});
+      else helper_pre<SplitPnp>(P, MS, PnpSideWork<0, 4>{P, MS, MP_MASK});
     }
     __syncthreads();                                                // S1b
-    mesh_phase(P, poly, (LdsPtr)(uintptr_t)lds0, wave_workspace(lds0, rne ? 3 : 2), rne ? 2 : 1, 3);
+    MCG_TICK(ST_S_S1B);
+    mesh_phase(P, poly, (LdsPtr)(uintptr_t)lds0, rne ? 2 : 1, 3);
+    MCG_TICK(ST_S_MESH);
     __syncthreads();                                                // S1c
+    MCG_TICK(ST_S_S1C);
     if (lower) solver_numbers_share(P, MS, dr1, rne ? 2 : 1);
+    MCG_TICK(ST_S_NUMBERS);
     __syncthreads();                                                // S2
+    MCG_TICK(ST_C_SOLVE);
     __syncthreads();                                                // S4
     MCG_TICK(ST_C_LS);
     const unsigned mask = flagged_lanes(MS, nvalid);
@@ -870,13 +881,9 @@ __global__ __launch_bounds__(64) void contacts_pnp_kernel(Cfg C, View V, const m
   load_envp(V, i, E);
   CubeSys<PnpScratch> CS(MS, E.Cb, E.dr);
   CS.cnt = nullptr;
-  if (lower) {
-    const TrigC T = load_trig();
-    static_for<NB>([&](auto I) { constexpr int k = I; real sn_, cs_; sincos_cw(T, AXS[k] * E.R.q[k], sn_, cs_); MS.st(MP_SN + k, sn_); MS.st(MP_CS + k, cs_); });
-    CS.template collide_primitives<true, true>(P, E.R.q);
-  }
+  if (lower) CS.template collide_primitives<true, true>(P, E.R.q);
   __syncthreads();
-  mesh_phase(P, poly, (LdsPtr)(uintptr_t)lds0, wave_workspace(lds0, 0), 0, 1);
+  mesh_phase(P, poly, (LdsPtr)(uintptr_t)lds0, 0, 1);
   __syncthreads();
   if (!lower || i_raw >= C.n) return;
   CS.collect_list();
@@ -1029,7 +1036,8 @@ int mcg_create(const mcg_config* c, const mcg_model* model, const double* polyto
       const double* meta = pb + 8 * m;
       const double end = meta[3] + 3 * meta[4] + 4 * meta[5] + 13 * meta[6];
       ok = meta[0] >= 1 && meta[0] <= meta[4] && meta[1] <= meta[5] && meta[2] <= meta[6] && meta[3] >= 8 * MCG_NMESH && end <= (double)np
-           && ((long long)meta[4] % 64) == 0 && ((long long)meta[5] % 64) == 0 && ((long long)meta[6] % 64) == 0;
+           && ((long long)meta[4] % 64) == 0 && ((long long)meta[5] % 64) == 0 && ((long long)meta[6] % 64) == 0
+           && meta[4] <= 64 * MESH_VCH && meta[5] <= 64 * MESH_FCH;      // (the narrow phase holds a family's table in registers: csrc/mcg_mesh.hpp)
     }
     if (!ok) { mcg_destroy(e); return fail(MCG_ERR_ARG, "mcg_create: inconsistent polytope block%s"); }
     err = hipMalloc(&e->d_poly, np * sizeof(double));

@@ -12,8 +12,9 @@
 // whenever ONE lane's link came near the table (27 k clocks of the M / RNE waves per sub-step under a random policy), on axes that
 // reported contacts that did not exist (3.8 - 23 % of them).  Now a per-lane broad phase (mcg_cube.hpp: mesh_broad)
 // leaves a candidate mask per environment, and between barriers S1b and S1c the cube, M and RNE waves -- all 64 lanes -- take the
-// environments that have candidates from a counter in LDS: forward kinematics once per environment (uniform arithmetic), then per
-// candidate pair the box is carried into the mesh's frame and every lane evaluates its vertices / faces / edges from the tables
+// environments that have candidates (dealt out by their share of the candidate pairs); per candidate pair the body's frame -- parked in
+// LDS by the broad phase that found the candidate -- carries the box into the mesh's frame and every lane evaluates its vertices /
+// faces / edges from the tables
 // (struct-of-arrays in global memory, padded to the wave width: coalesced loads), DPP reductions pick the winner, and the contact is
 // appended to the environment's list.  A separated pair usually ends after the B and P families (~300 instructions).
 #pragma once
@@ -62,23 +63,32 @@ MCG_DEV MeshTab mesh_tab(const real* __restrict__ poly, int m) {
   return T;
 }
 
+// Table sizes the routines below rely on (asserted when a polytope block is accepted: mcg_create; polytope.py builds within them): at most
+// MESH_VCH x 64 vertices, MESH_FCH x 64 faces.  Every load of a family is issued before the first use: a pair's cost is a few L2
+// round trips, not one per 64 elements (the first version walked the tables chunk by chunk: 25 dependent round trips per true contact,
+// 27 k clocks per pair under a random policy, profiles/r04b/clocks--pnp-ik.log).
+constexpr int MESH_VCH = 2, MESH_FCH = 4, MESH_ECH = 5;
+
 // Ground plane z = 0 against the polytope in the frame (R, p): its lowest vertex (first occurrence).  dist < 0 = a contact.
 MCG_DEV bool mesh_ground(const MeshTab& T, int L, const real* R, const real* p, real* pos, real* nrm, real& dist) {
+  real vx[MESH_VCH], vy[MESH_VCH], vz[MESH_VCH]; int kk[MESH_VCH];
+  _Pragma("unroll") for (int c = 0; c < MESH_VCH; c++) {
+    kk[c] = sel(64 * c + L < T.vp, 64 * c + L, L);                 // (a chunk beyond the table repeats the first: same values, higher index)
+    vx[c] = T.v[kk[c]]; vy[c] = T.v[T.vp + kk[c]]; vz[c] = T.v[2 * T.vp + kk[c]];
+  }
   real best = INFINITY; int kb = 0x7fffffff;
-  for (int k0 = 0; k0 < T.vp; k0 += 64) {
-    const int k = k0 + L;
-    const real vx = T.v[k], vy = T.v[T.vp + k], vz = T.v[2 * T.vp + k];
-    const real hgt = p[2] + R[6]*vx + R[7]*vy + R[8]*vz;
+  _Pragma("unroll") for (int c = 0; c < MESH_VCH; c++) {
+    const real hgt = p[2] + R[6]*vx[c] + R[7]*vy[c] + R[8]*vz[c];
     const bool lower = hgt < best;                                  // (the padding repeats vertex 0: never lower than the first of its value)
-    best = sel(lower, hgt, best); kb = sel(lower, k, kb);
+    best = sel(lower, hgt, best); kb = sel(lower, kk[c], kb);
   }
   real lo; int kmin, lane;
   wave_argmax(-best, kb, lo, kmin, lane);
   lo = -lo;
   if (!(lo < 0)) return false;                                      // uniform
-  const real vx = T.v[kmin], vy = T.v[T.vp + kmin], vz = T.v[2 * T.vp + kmin];
+  const real wx = T.v[kmin], wy = T.v[T.vp + kmin], wz = T.v[2 * T.vp + kmin];
   real w[3];
-  _Pragma("unroll") for (int r = 0; r < 3; r++) w[r] = p[r] + R[3*r]*vx + R[3*r+1]*vy + R[3*r+2]*vz;
+  _Pragma("unroll") for (int r = 0; r < 3; r++) w[r] = p[r] + R[3*r]*wx + R[3*r+1]*wy + R[3*r+2]*wz;
   pos[0] = w[0]; pos[1] = w[1]; pos[2] = w[2] - 0.5 * lo;
   nrm[0] = 0; nrm[1] = 0; nrm[2] = 1;
   dist = lo;
@@ -89,19 +99,31 @@ MCG_DEV bool mesh_ground(const MeshTab& T, int L, const real* R, const real* p, 
 // the cube): the normal points from the mesh to the box; else from the box to the mesh (the static table is geom1).
 MCG_DEV bool mesh_box(const MeshTab& T, int L, const real* Rm, const real* pm, const real* Rb, const real* pb, const real* h, bool flip,
                       real* pos, real* nrm, real& dist) {
+  // ---- the tables of the B and P families and the first chunk of E: all loads in flight before anything is used
+  real vx[MESH_VCH], vy[MESH_VCH], vz[MESH_VCH]; int kv[MESH_VCH];
+  _Pragma("unroll") for (int cch = 0; cch < MESH_VCH; cch++) {
+    kv[cch] = sel(64 * cch + L < T.vp, 64 * cch + L, L);
+    vx[cch] = T.v[kv[cch]]; vy[cch] = T.v[T.vp + kv[cch]]; vz[cch] = T.v[2 * T.vp + kv[cch]];
+  }
+  real fn[MESH_FCH][4]; int kf[MESH_FCH];
+  _Pragma("unroll") for (int cch = 0; cch < MESH_FCH; cch++) {
+    kf[cch] = sel(64 * cch + L < T.fp, 64 * cch + L, L);
+    _Pragma("unroll") for (int q = 0; q < 4; q++) fn[cch][q] = T.f[q * T.fp + kf[cch]];
+  }
+  real eA[12];
+  _Pragma("unroll") for (int q = 0; q < 12; q++) eA[q] = T.e[q * T.ep + L];
+  MCG_FENCE();
   real c[3], b[3][3];                                               // the box in the mesh frame: centre, axes (rows)
   { const real rel[3] = {pb[0] - pm[0], pb[1] - pm[1], pb[2] - pm[2]};
     _Pragma("unroll") for (int k = 0; k < 3; k++) c[k] = Rm[k]*rel[0] + Rm[3 + k]*rel[1] + Rm[6 + k]*rel[2];
     _Pragma("unroll") for (int j = 0; j < 3; j++) { _Pragma("unroll") for (int k = 0; k < 3; k++) b[j][k] = Rm[k]*Rb[j] + Rm[3 + k]*Rb[3 + j] + Rm[6 + k]*Rb[6 + j]; } }
   // ---- B: the box's face axes; the polytope's extent along b_j from its vertices
   real mx[3] = {-INFINITY, -INFINITY, -INFINITY}, mn[3] = {INFINITY, INFINITY, INFINITY}; int kx[3] = {0, 0, 0}, kn[3] = {0, 0, 0};
-  for (int k0 = 0; k0 < T.vp; k0 += 64) {
-    const int k = k0 + L;
-    const real vx = T.v[k], vy = T.v[T.vp + k], vz = T.v[2 * T.vp + k];
+  _Pragma("unroll") for (int cch = 0; cch < MESH_VCH; cch++) {
     _Pragma("unroll") for (int j = 0; j < 3; j++) {
-      const real t = vx*b[j][0] + vy*b[j][1] + vz*b[j][2];
+      const real t = vx[cch]*b[j][0] + vy[cch]*b[j][1] + vz[cch]*b[j][2];
       const bool up = t > mx[j], dn = t < mn[j];
-      mx[j] = sel(up, t, mx[j]); kx[j] = sel(up, k, kx[j]); mn[j] = sel(dn, t, mn[j]); kn[j] = sel(dn, k, kn[j]);
+      mx[j] = sel(up, t, mx[j]); kx[j] = sel(up, kv[cch], kx[j]); mn[j] = sel(dn, t, mn[j]); kn[j] = sel(dn, kv[cch], kn[j]);
     }
   }
   real sB = -INFINITY; int cB = 0;
@@ -116,39 +138,51 @@ MCG_DEV bool mesh_box(const MeshTab& T, int L, const real* Rm, const real* pm, c
   if (sB > 0) return false;                                         // (uniform: every lane holds the same numbers)
   // ---- P: the polytope's face normals
   real sPl = -INFINITY; int cPl = 0x7fffffff;
-  for (int f0 = 0; f0 < T.fp; f0 += 64) {
-    const int f = f0 + L;
-    const real n[3] = {T.f[f], T.f[T.fp + f], T.f[2 * T.fp + f]}, d = T.f[3 * T.fp + f];
-    const real s = (dot3(n, c) - (h[0]*fabs(dot3(n, b[0])) + h[1]*fabs(dot3(n, b[1])) + h[2]*fabs(dot3(n, b[2])))) - d;
-    const bool up = s > sPl;                                        // (padding faces: d = 1e30, never the largest)
-    sPl = sel(up, s, sPl); cPl = sel(up, f, cPl);
+  _Pragma("unroll") for (int cch = 0; cch < MESH_FCH; cch++) {
+    const real* n = fn[cch];
+    const real s = (dot3(n, c) - (h[0]*fabs(dot3(n, b[0])) + h[1]*fabs(dot3(n, b[1])) + h[2]*fabs(dot3(n, b[2])))) - n[3];
+    const bool up = s > sPl || (s == sPl && kf[cch] < cPl);         // (padding faces: d = 1e30, never the largest; a repeated chunk: same value, higher index)
+    sPl = sel(up, s, sPl); cPl = sel(up, kf[cch], cPl);
   }
   real sP; int cP, lnP;
   wave_argmax(sPl, cPl, sP, cP, lnP);
   if (sP > 0) return false;
-  // ---- E: e_k x b_j inside the normal cone of edge k
+  // ---- E: e_k x b_j inside the normal cone of edge k; the next chunk's loads are in flight while one is evaluated (two buffers, the loop
+  // unrolled by two: no run-time index into a private array)
   real sEl = -INFINITY, nEl[3] = {0, 0, 0}; int cEl = 0x7fffffff;
-  for (int k0 = 0; k0 < T.ep; k0 += 64) {
-    const int k = k0 + L;
-    real ed[12];
-    _Pragma("unroll") for (int q = 0; q < 12; q++) ed[q] = T.e[q * T.ep + k];
-    MCG_FENCE();
+  auto edges = [&](const real* e12, int k) {
     _Pragma("unroll") for (int j = 0; j < 3; j++) {
       constexpr int I1[3] = {1, 2, 0}, I2[3] = {2, 0, 1};
       const int i1 = I1[j], i2 = I2[j];
-      real x[3]; cross(ed + 3, b[j], x);
-      const real len = sqrt(dot3(x, x));
-      const bool ok = len >= MESH_EDGE_MIN_SIN;                     // (padding edges: e = 0)
-      const real il = 1.0 / sel(ok, len, 1.0);
+      real x[3]; cross(e12 + 3, b[j], x);
+      const real l2 = dot3(x, x);
+      const bool ok = l2 >= MESH_EDGE_MIN_SIN * MESH_EDGE_MIN_SIN;  // (padding edges: e = 0)
+      // 1 / |x|: v_rsq_f64 and two Newton steps (the oracle's sqrt and division cost 25 issue slots per candidate, 900 candidates per
+      // pair; the results differ from its in the last bit)
+      const real l2s = sel(ok, l2, 1.0);
+      real il = __builtin_amdgcn_rsq(l2s);
+      il = il * fma(-0.5 * l2s * il, il, 1.5); il = il * fma(-0.5 * l2s * il, il, 1.5);
       x[0] *= il; x[1] *= il; x[2] *= il;
-      const real t1 = x[0]*ed[6] + x[1]*ed[7] + x[2]*ed[8], t2 = x[0]*ed[9] + x[1]*ed[10] + x[2]*ed[11];
+      const real t1 = x[0]*e12[6] + x[1]*e12[7] + x[2]*e12[8], t2 = x[0]*e12[9] + x[1]*e12[10] + x[2]*e12[11];
       const real sg = sel(t1 >= 0 && t2 >= 0, 1.0, sel(t1 <= 0 && t2 <= 0, -1.0, 0.0));
       const real n[3] = {sg*x[0], sg*x[1], sg*x[2]};
-      const real s = (dot3(n, c) - (h[i1]*fabs(dot3(n, b[i1])) + h[i2]*fabs(dot3(n, b[i2])))) - (n[0]*ed[0] + n[1]*ed[1] + n[2]*ed[2]);
+      const real s = (dot3(n, c) - (h[i1]*fabs(dot3(n, b[i1])) + h[i2]*fabs(dot3(n, b[i2])))) - (n[0]*e12[0] + n[1]*e12[1] + n[2]*e12[2]);
       const int id = j * T.ne + k;
       const bool up = ok && sg != 0.0 && (s > sEl || (s == sEl && id < cEl));
       sEl = sel(up, s, sEl); cEl = sel(up, id, cEl);
       _Pragma("unroll") for (int r = 0; r < 3; r++) nEl[r] = sel(up, n[r], nEl[r]);
+    }
+  };
+  real eB[12];
+  for (int k0 = 0; k0 < T.ep; k0 += 128) {                         // (uniform)
+    const bool second = k0 + 64 < T.ep;
+    if (second) { _Pragma("unroll") for (int q = 0; q < 12; q++) eB[q] = T.e[q * T.ep + k0 + 64 + L]; }
+    MCG_FENCE();
+    edges(eA, k0 + L);
+    if (second) {
+      if (k0 + 128 < T.ep) { _Pragma("unroll") for (int q = 0; q < 12; q++) eA[q] = T.e[q * T.ep + k0 + 128 + L]; }
+      MCG_FENCE();
+      edges(eB, k0 + 64 + L);
     }
   }
   real sE; int cE, lnE;
@@ -201,56 +235,15 @@ MCG_DEV bool mesh_box(const MeshTab& T, int L, const real* Rm, const real* pm, c
   return true;
 }
 
-// R <- R Rot(e_K, theta), from sin / cos of AXS * q (as every chain walk of the kernels does it)
-template <int K> MCG_DEV void mesh_turn(real* R, real sn_, real cs_) {
-  constexpr int A = (K + 1) % 3, B = (K + 2) % 3;
-  _Pragma("unroll") for (int k = 0; k < 3; k++) {
-    const real ca = R[3*k + A], cb = R[3*k + B];
-    R[3*k + A] = cs_ * ca + sn_ * cb; R[3*k + B] = -sn_ * ca + cs_ * cb;
-  }
-}
-
 // One environment's candidate pairs, by the 64 lanes of the calling wave.  lds0 = slot 0 of lane 0 of the workgroup's array, e = the
-// environment's lane (its LDS column), ws = this wave's workspace in the row area (the body frames: 12 x 12 doubles).
-MCG_DEV void mesh_env(ModelPtr Pm, const real* __restrict__ poly, LdsPtr lds0, int e, LdsPtr ws) {
+// environment's lane (its LDS column).  The frames of the bodies that carry a candidate were parked in the column by the lane-parallel
+// broad phases (MP_FRAME: one producer per body), the cube's pose by the cube wave.
+MCG_DEV void mesh_env(ModelPtr Pm, const real* __restrict__ poly, LdsPtr lds0, int e) {
   const int L = threadIdx.x & 63;
   const PnpScratch ME(lds0 + e);                   // env e's column: a uniform slot index is a broadcast read
-  ModelPtr Q = launder(Pm);
   unsigned long long bits = (unsigned long long)(long long)ME.ld(MP_MASK) | (unsigned long long)(long long)ME.ld(MP_MASK + 1) | (unsigned long long)(long long)ME.ld(MP_MASK + 2);
   bits = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(bits >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((unsigned)bits);
   int ncon = __builtin_amdgcn_readfirstlane((int)ME.ld(MP_NCON)), ndrop = 0;
-  // ---- forward kinematics (uniform arithmetic): the frames of the bodies that carry a candidate, into the workspace
-  const bool grip = (bits >> 24) != 0ull;                          // meshes 8 .. 13 ride on the gripper's bodies
-  int amax = grip ? 5 : 0;
-  for (int m = 0; m < 8; m++) if ((bits >> (3 * m)) & 7ull) amax = mesh_body(m) > amax ? mesh_body(m) : amax;
-  {
-    real R[9], p[3];
-    _Pragma("unroll") for (int k = 0; k < 9; k++) R[k] = Q->base_mat[k];
-    _Pragma("unroll") for (int k = 0; k < 3; k++) p[k] = Q->base_pos[k];
-    static_for<6>([&](auto I) { constexpr int i = I;
-      if (i <= amax) {                                              // uniform
-        real r[3]; ldc<3>(Q->body[i].r, r);
-        _Pragma("unroll") for (int k = 0; k < 3; k++) p[k] += R[3*k]*r[0] + R[3*k+1]*r[1] + R[3*k+2]*r[2];
-        mesh_turn<AXK[i]>(R, ME.ld(MP_SN + i), ME.ld(MP_CS + i));
-        real Rc_[9] = {R[0], R[1], R[2], R[3], R[4], R[5], R[6], R[7], R[8]}, pc_[3] = {p[0], p[1], p[2]};
-        // (per-lane select of one of twelve uniform numbers: a store by twelve lanes)
-        if (L < 12) { real v = pc_[0]; static_for<9>([&](auto Kk) { constexpr int k = Kk; v = sel(L == k, Rc_[k], v); }); v = sel(L == 10, pc_[1], sel(L == 11, pc_[2], v)); ws[i * 12 + L] = v; }
-      } });
-    if (grip) {
-      auto leaf = [&](int body, const real* Rin, const real* pin_, real* Ro, real* po) {
-        real r[3]; ldc<3>(Q->body[body].r, r);
-        _Pragma("unroll") for (int k = 0; k < 9; k++) Ro[k] = Rin[k];
-        _Pragma("unroll") for (int k = 0; k < 3; k++) po[k] = pin_[k] + Rin[3*k]*r[0] + Rin[3*k+1]*r[1] + Rin[3*k+2]*r[2];
-        mesh_turn<1>(Ro, ME.ld(MP_SN + body), ME.ld(MP_CS + body));
-        if (L < 12) { real v = po[0]; static_for<9>([&](auto Kk) { constexpr int k = Kk; v = sel(L == k, Ro[k], v); }); v = sel(L == 10, po[1], sel(L == 11, po[2], v)); ws[body * 12 + L] = v; }
-      };
-      real Rg[9], pg[3], Rf[9], pf[3];
-      leaf(6, R, p, Rg, pg); leaf(7, Rg, pg, Rf, pf);               // right gear, right finger
-      leaf(8, R, p, Rg, pg); leaf(9, Rg, pg, Rf, pf);               // left gear, left finger
-      leaf(10, R, p, Rg, pg); leaf(11, R, p, Rg, pg);               // hinge links
-    }
-  }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   // ---- the static box and the cube
   real tp[3], th[3], hc[3], Rc[9], cp[3];
   { ModelPtr Qb = launder(Pm); ldc<3>(Qb->table_pos, tp); ldc<3>(Qb->table_half, th); ldc<3>(Qb->cube_half, hc); }
@@ -264,8 +257,8 @@ MCG_DEV void mesh_env(ModelPtr Pm, const real* __restrict__ poly, LdsPtr lds0, i
     const int bit = (int)__builtin_ctzll(bits); bits &= bits - 1ull;
     const int m = bit / 3, o = bit - 3 * m, body = mesh_body(m);
     real Rm[9], pm[3];
-    _Pragma("unroll") for (int k = 0; k < 9; k++) Rm[k] = ws[body * 12 + k];
-    _Pragma("unroll") for (int k = 0; k < 3; k++) pm[k] = ws[body * 12 + 9 + k];
+    _Pragma("unroll") for (int k = 0; k < 9; k++) Rm[k] = ME.ld(MP_FRAME + body * 12 + k);
+    _Pragma("unroll") for (int k = 0; k < 3; k++) pm[k] = ME.ld(MP_FRAME + body * 12 + 9 + k);
     const MeshTab T = mesh_tab(poly, m);
     real pos[3], nrm[3], dist = 1.0; bool hit;
     if (o == 0) hit = mesh_ground(T, L, Rm, pm, pos, nrm, dist);
@@ -294,21 +287,30 @@ MCG_DEV void mesh_env(ModelPtr Pm, const real* __restrict__ poly, LdsPtr lds0, i
 }
 
 // ---- the mesh phase of a sub-step: every wave that takes part calls it with all 64 lanes between barriers S1b and S1c.  The environments
-// that have candidates are dealt out by rank: the k-th of them (in lane order) goes to wave k mod nwaves -- a pair costs between 300 and
-// 2000 instructions, but a counter in LDS (as the cooperative solves use) bought nothing here: the phase is short, and which wave
-// takes an environment does not change its result either way.  (The first version did grab from a counter; that loop hung on the GPU
-// in this kernel and in no reduced copy of it, and was not understood: profiles/r04a/diag*.log.)
-MCG_DEV void mesh_phase(ModelPtr Pm, const real* __restrict__ poly, LdsPtr lds0, LdsPtr ws, int wave, int nwaves) {
+// that have candidates are dealt out by their share of the candidate PAIRS: environment e (in lane order) goes to wave
+// floor(nwaves x (pairs before e + half of e's) / all pairs) -- one wave keeps an environment's pairs, so that its contacts are appended in pair order.
+// (The first version grabbed environments from a counter in LDS as the cooperative solves do; that loop hung on the GPU in this kernel
+// and in no reduced copy of it, and was not understood: gpurun_out logs of round 4.  Which wave takes an environment does not change its
+// result either way.)
+MCG_DEV void mesh_phase(ModelPtr Pm, const real* __restrict__ poly, LdsPtr lds0, int wave, int nwaves) {
   const int T = threadIdx.x & 63;
-  bool cand = false;
+  int cnt = 0;
   if (T < PNP_LANES) {
     const PnpScratch MS(lds0 + T);
-    cand = (MS.ld(MP_MASK) != 0.0) || (MS.ld(MP_MASK + 1) != 0.0) || (MS.ld(MP_MASK + 2) != 0.0);
+    const unsigned long long b = (unsigned long long)(long long)MS.ld(MP_MASK) | (unsigned long long)(long long)MS.ld(MP_MASK + 1) | (unsigned long long)(long long)MS.ld(MP_MASK + 2);
+    cnt = __popcll(b);
   }
-  unsigned em = __builtin_amdgcn_readfirstlane((unsigned)__ballot(cand));
-  for (int k = 0; em != 0u; k++) {                                  // uniform
+  unsigned em = __builtin_amdgcn_readfirstlane((unsigned)__ballot(cnt != 0));
+  if (em == 0u) return;                                             // uniform: the usual case away from the table
+  int total = 0;
+  for (unsigned mm = em; mm != 0u; mm &= mm - 1u) total += __builtin_amdgcn_readlane(cnt, __builtin_ctz(mm));
+  int before = 0;
+  while (em != 0u) {                                                // uniform
     const int e = __builtin_ctz(em); em &= em - 1u;
-    if (k % nwaves == wave) mesh_env(Pm, poly, lds0, e, ws);
+    const int c = __builtin_amdgcn_readlane(cnt, e);
+    const int owner = ((2 * before + c) * nwaves) / (2 * total);   // by the share's midpoint: no wave is systematically the heaviest
+    before += c;
+    if (owner == wave) mesh_env(Pm, poly, lds0, e);
   }
 }
 

@@ -13,17 +13,19 @@ import torch
 from mycobotgym_amd import MyCobotVecEnv, _abi
 
 NAMES = ["load", "controller", "sincos", "rne", "actuation", "crb->M", "rows: weld / rest", "g0", "newton: other (setup, line search)", "euler: factor M+hB, solve, integrate",
-         "cube wave: merging the staged arm-mesh contacts", "cube wave: side scan, zero fill", "coupled solve", "cube wave: waiting at S1b", "post (obs/reward/reset/store)",
+         "cube wave: mesh phase", "cube wave: list scan, zero fill", "coupled solve", "cube wave: waiting at S1b", "post (obs/reward/reset/store)",
          "newton: build H", "newton: factor H", "newton: solve", "newton: active-set check", "euler: forces/rhs",
          "rows: arm axes in link6 frame", "rows: connects + coupling", "rows: limits",
-         "M / RNE waves: own share (CRB / bias)", "M / RNE waves: four arm meshes each", "M / RNE waves: waiting at S1b", "M / RNE waves: S1b -> S2",
+         "M / RNE waves: own share (CRB / bias)", "M / RNE waves: arm meshes' broad phase", "(unused)", "M / RNE waves: waiting at S2",
          "M / RNE waves: waiting for q (S1)", "M / RNE waves: S2 -> S4",
-         "cube wave: waiting for q (S1)", "cube wave: collision (rest: per-contact solver numbers)", "cube wave: solve + finish", "cube wave: waiting at S2",
+         "cube wave: waiting for q (S1)", "cube wave: collision (rest)", "cube wave: solve + finish", "cube wave: waiting at S4",
          "robot wave: waiting at S2",
          "collision: cube frame, pair numbers", "collision: arm chain + arm meshes on table / ground", "collision: pad frames, ground plane",
-         "collision: table - pads", "collision: table - cube, pads - cube", "collision: gripper base / finger links - cube",
+         "collision: table - pads", "collision: table - cube, pads - cube", "collision: park the mesh phase's slots",
          "coop: env data, twist columns", "coop: rows", "coop: H0, g0", "coop: residuals, active set", "coop: assembly (LDS window)",
-         "coop: gradient + LDL", "coop: solves + transpose", "coop: consistency check", "coop: line search", "coop: hand back", "coop: idle at S5"]
+         "coop: gradient + LDL", "coop: solves + transpose", "coop: consistency check", "coop: line search", "coop: hand back", "coop: idle at S5",
+         "cube wave: waiting at S1c", "cube wave: flags + solver numbers", "cube wave: waiting at S2", "M / RNE waves: waiting at S1b", "M / RNE waves: mesh phase",
+         "M / RNE waves: waiting at S1c", "M / RNE waves: solver numbers"]
 COUNTS = ["robot sub-steps", "robot Newton iterations", "robot line searches", "cube Newton iterations", "cube line searches",
           "coupled solves", "coupled Newton iterations", "coupled line searches", "wave-max contacts (per collision pass)",
           "coop active rows (sum over iterations)", "coop line-search evaluations", "coop solves whose carried active set was confirmed at once", "coop solves at the 50-iteration cap", "coop solves that started from a carried active set",
@@ -31,12 +33,13 @@ COUNTS = ["robot sub-steps", "robot Newton iterations", "robot line searches", "
           "wrong rows: missing from the carried set", "wrong rows: surplus in the carried set",
           "pair solves whose final set = the set of the last sub-step", "... = the set of two sub-steps ago", "... = the set of two sub-steps ago and not the last one's"]
 fresh = "--fresh-actions" in sys.argv
+mocap = "--pnp-mocap" in sys.argv
 grasp = "--grasp" in sys.argv           # PickAndPlace joint with every env holding the cube (scripted grasp state)
 L = _abi.load()
 n = 8192
 pnpik = "--pnp-ik" in sys.argv         # PickAndPlace, IK controller, random policy only
 pnpj = "--pnp-joint" in sys.argv       # PickAndPlace, joint controller, cube resting
-for obj, ctrl, k in (((True, "joint", 20),) if grasp else ((True, "IK", 20),) if pnpik else ((True, "joint", 100),) if pnpj else ((False, "joint", 200), (False, "IK", 50), (True, "joint", 100), (True, "IK", 20))):
+for obj, ctrl, k in (((True, "mocap", 40),) if mocap else ((True, "joint", 20),) if grasp else ((True, "IK", 20),) if pnpik else ((True, "joint", 100),) if pnpj else ((False, "joint", 200), (False, "IK", 50), (True, "joint", 100), (True, "IK", 20))):
     envs = MyCobotVecEnv(n, has_object=obj, controller_type=ctrl, reward_type="dense", max_episode_steps=10 ** 9 if grasp else 50)
     envs.reset(seed=0)
     a = torch.rand(n, envs.action_dim, device="cuda") * 2 - 1
