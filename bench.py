@@ -171,6 +171,23 @@ def roofline(case, n, kernel_ms):
     return out
 
 
+def _rehearsal_engine(rank):
+    """Stand-in for MyCobotVecEnv under BENCH_REHEARSE_PLUMBING=1 (see main): same constructor / reset / set_state / step_async /
+    _buf / close surface on CPU tensors; a step sleeps (longer on higher ranks, so that the MAX over ranks is visible).  Not an engine."""
+    import torch
+
+    class Rehearsal:
+        def __init__(self, n, has_object=False, controller_type="joint", device=None, env_id_offset=0, **kw):
+            self.n, self.action_dim, self.env_id_offset = n, 7, env_id_offset
+            self._buf = {"ep_return": torch.full((n,), float(rank + 1), dtype=torch.float64), "ep_length": torch.full((n,), 50, dtype=torch.int32),
+                         "is_success": torch.zeros(n, dtype=torch.bool), "truncated": torch.ones(n, dtype=torch.bool)}
+        def reset(self, seed=None): pass
+        def set_state(self, **kw): pass
+        def step_async(self, a): time.sleep(1e-3 * (rank + 1))
+        def close(self): pass
+    return Rehearsal
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -201,23 +218,35 @@ def main():
     # BENCH_SHARE_GPU=1 (rehearsal on a one-GPU box only): ranks share device 0 and rendezvous over gloo, because RCCL refuses
     # two ranks on one device; the real multi-GPU run is one rank per GPU over RCCL ("nccl")
     share = os.environ.get("BENCH_SHARE_GPU") == "1"
+    # BENCH_REHEARSE_PLUMBING=1 (tests/test_bench_plumbing.py, CPU only): everything of this function EXCEPT the engine -- rank / world
+    # parsing, the --gpus check, shard offsets, barrier + synchronise brackets, the MAX-reduced wall time, the logging collective, JSON on
+    # rank 0 only -- over gloo, with a stand-in that sleeps instead of launching kernels.  Its line carries "rehearsal": true and no value:
+    # it measures nothing and exists so that the first real 8-GPU launch cannot fail on plumbing.
+    rehearse = os.environ.get("BENCH_REHEARSE_PLUMBING") == "1"
     if share:
         local_rank = 0
-    if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        if share:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    red_dev = "cpu" if share else None        # gloo reduces host tensors
     if args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if args.gpus > 1 and world == 1:
         raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
-    dev = torch.device("cuda", local_rank)
-    from mycobotgym_amd import MyCobotVecEnv
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            if share:
+                dist.init_process_group("gloo")
+            else:
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    red_dev = "cpu" if (share or rehearse) else None        # gloo reduces host tensors
+    dev = torch.device("cpu") if rehearse else torch.device("cuda", local_rank)
+    sync = (lambda: None) if rehearse else (lambda: torch.cuda.synchronize(dev))
     from mycobotgym_amd.sharding import reduce_episode_stats, shard
+    if rehearse:
+        MyCobotVecEnv = _rehearsal_engine(rank)
+    else:
+        from mycobotgym_amd import MyCobotVecEnv
 
     n = args.envs_per_gpu
     K, W = args.steps, args.warmup
@@ -243,23 +272,24 @@ def main():
             pool = act.unsqueeze(0).repeat(16, 1, 1).contiguous()
         for t in range(warmup):
             envs.step_async(pool[t % 16])
-        torch.cuda.synchronize(dev)
+        sync()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize(dev)
+        sync()
         # HIP events on the launch stream (mcg_step enqueues on torch's current stream, so torch events see it)
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        if not rehearse:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
-        ev0.record()
+        if not rehearse: ev0.record()
         for t in range(steps):
             envs.step_async(pool[t % 16])
-        ev1.record()
-        torch.cuda.synchronize(dev)
+        if not rehearse: ev1.record()
+        sync()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize(dev)
+        sync()
         dt = time.perf_counter() - t0
-        kernel_ms = ev0.elapsed_time(ev1) / steps      # average launch-to-launch duration over the timed region
+        kernel_ms = (dt * 1e3 if rehearse else ev0.elapsed_time(ev1)) / steps      # average launch-to-launch duration over the timed region
         if world > 1:
             tt = torch.tensor([dt], dtype=torch.float64, device=red_dev or dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -276,7 +306,7 @@ def main():
         v = total_envs * steps / dt
         return {"case": case, "workload": describe(case, n, lockstep), "env_steps_per_sec": v, "ms_per_step": dt / steps * 1e3,
                 "steps": steps, "warmup": warmup, "physics_substeps_per_sec": v * sub,
-                "roofline": roofline(case, n, kernel_ms) if rank == 0 else None, "episode_stats_last_step": stats}
+                "roofline": roofline(case, n, kernel_ms) if (rank == 0 and not rehearse) else None, "episode_stats_last_step": stats}
 
     def api_step_cost(case, steps):
         """The packaged Gymnasium-style step() (fresh copies of every output, info dict) against the raw launch: what a caller of
@@ -310,7 +340,10 @@ def main():
         "physics_substeps_per_sec": main_e["physics_substeps_per_sec"],
         "roofline": main_e["roofline"], "episode_stats_last_step": main_e["episode_stats_last_step"],
     }
-    if world == 1 and not args.no_secondary and case == "reach-joint" and not args.lockstep:
+    if rehearse:
+        out.update(value=None, rehearsal=True, data="none: plumbing rehearsal without the engine (BENCH_REHEARSE_PLUMBING=1)", roofline=None,
+                   rehearsal_detail={"rank0_env_offset": env_offset, "total_envs": total_envs, "max_over_ranks_wall_s": main_e["ms_per_step"] * K / 1e3})
+    if world == 1 and not args.no_secondary and case == "reach-joint" and not args.lockstep and not rehearse:
         # bounded so that the default run still finishes within a few minutes (the grasp case runs ~10 ms per step)
         k2, w2 = max(min(K, 200) // 2, 20), max(min(W, 100) // 2, 5)
         out["lockstep"] = {k: v for k, v in entry(case, K, W, True).items() if k != "roofline"}
@@ -320,7 +353,7 @@ def main():
         out["secondary"] = [entry(c, k2 if c != "pnp-joint-grasp" else min(k2, 40), warm_of(c), False) for c in DEFAULT_SECONDARY]
         out["api_step_cost"] = api_step_cost(case, 200)
     if rank == 0:
-        if not args.no_cpu_baseline and world == 1 and task == "reach":
+        if not args.no_cpu_baseline and world == 1 and task == "reach" and not rehearse:
             out["cpu_baseline"] = cpu_baseline(controller)
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -281,7 +281,12 @@ MCG_DEV void pyramid_row(const CubeRows& R, int r, const real* mu, real* j) {
 // it rides on (mcg_model.mesh_box: centre, half extents).  All three tests are CONSERVATIVE -- the box contains the polytope, a subset of
 // the separating axes is tried -- so a pair they reject is separated; a pair they pass goes to the exact narrow phase (mcg_mesh.hpp),
 // which decides.  Returns the pair's candidate bits: 1 ground, 2 table, 4 cube.
-MCG_DEV int mesh_broad(ModelPtr Pm, int m, const real* R, const real* p, const real* tp, const real* th, bool statics, bool cube, const real* cpos, real crad) {
+// CUBE_BOX: the caller knows the cube's attitude (rows of Rc = world <- cube, half sizes hc): the cube's three face axes and the box's three
+// instead of the cube's bounding sphere (a held cube sits 2 mm from both finger links: the sphere passed 2.0 pairs per grasping
+// environment to the narrow phase, the six axes pass 0.5)
+template <bool CUBE_BOX = false>
+MCG_DEV int mesh_broad(ModelPtr Pm, int m, const real* R, const real* p, const real* tp, const real* th, bool statics, bool cube, const real* cpos, real crad,
+                       const real* Rc = nullptr, const real* hc = nullptr) {
   ModelPtr H = launder(Pm);
   real bx[6]; ldc<6>(H->mesh_box[m], bx);
   real c[3], e[3];                                                      // the box's centre; its half extents along the world axes
@@ -293,12 +298,22 @@ MCG_DEV int mesh_broad(ModelPtr Pm, int m, const real* R, const real* p, const r
   const bool ground = c[2] - e[2] < 0;                                  // ground: the box's lowest point
   bool table = true;                                                    // table: its three face axes, then the box's own three
   _Pragma("unroll") for (int r = 0; r < 3; r++) table = table && !(fabs(c[r] - tp[r]) > th[r] + e[r]);
-  bool near = true;                                                     // the cube's bounding sphere against the box, in the box's frame
+  bool near = true;                                                     // the cube against the box
+  const real t[3] = {cpos[0] - c[0], cpos[1] - c[1], cpos[2] - c[2]};
   _Pragma("unroll") for (int k = 0; k < 3; k++) {
     const real rel = R[k]*(c[0] - tp[0]) + R[3 + k]*(c[1] - tp[1]) + R[6 + k]*(c[2] - tp[2]);
     const real rad = fabs(R[k])*th[0] + fabs(R[3 + k])*th[1] + fabs(R[6 + k])*th[2];
     table = table && !(fabs(rel) > bx[3 + k] + rad);
-    near = near && !(fabs(R[k]*(cpos[0] - c[0]) + R[3 + k]*(cpos[1] - c[1]) + R[6 + k]*(cpos[2] - c[2])) > bx[3 + k] + crad);
+    const real tk = R[k]*t[0] + R[3 + k]*t[1] + R[6 + k]*t[2];           // along the box's axis k
+    if constexpr (CUBE_BOX) {
+      real rb = 0;
+      _Pragma("unroll") for (int a = 0; a < 3; a++) rb += hc[a] * fabs(R[k]*Rc[a] + R[3 + k]*Rc[3 + a] + R[6 + k]*Rc[6 + a]);
+      near = near && !(fabs(tk) > bx[3 + k] + rb);
+      const real ta = Rc[k]*t[0] + Rc[3 + k]*t[1] + Rc[6 + k]*t[2];    // along the cube's axis k
+      real ra = 0;
+      _Pragma("unroll") for (int a = 0; a < 3; a++) ra += bx[3 + a] * fabs(R[a]*Rc[k] + R[3 + a]*Rc[3 + k] + R[6 + a]*Rc[6 + k]);
+      near = near && !(fabs(ta) > hc[k] + ra);
+    } else near = near && !(fabs(tk) > bx[3 + k] + crad);
   }
   return sel(statics && ground, 1, 0) | sel(statics && table, 2, 0) | sel(cube && near, 4, 0);
 }
@@ -531,7 +546,7 @@ struct CubeSys {
       // M / RNE waves (arm_broad_stage) unless ARM
       auto broad = [&](int m, int body, const real* Rio, const real* pio, bool statics, bool cube) {
         if constexpr (MESHES) {
-          const int bb = mesh_broad(Pm, m, Rio, pio, tp, th, statics, cube, Cb.pos, crad);
+          const int bb = mesh_broad<true>(Pm, m, Rio, pio, tp, th, statics, cube, Cb.pos, crad, Rc, hc);
           mbits |= (long long)bb << (3 * m);
           return bb != 0;
         } else return false;

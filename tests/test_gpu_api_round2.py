@@ -308,6 +308,46 @@ def test_bad_state_guard(torch_cuda, has_object):
     envs.close()
 
 
+def test_bad_state_in_the_middle_of_an_env_step(torch_cuda):
+    """mj_checkAcc inside a LATER sub-step of an env-step (the PickAndPlace kernels checked the first sub-step
+    only).  A cube in the air beside the table falling at 1e8 m/s passes mj_checkPos / mj_checkVel, touches nothing in sub-step 0 and is
+    2e5 m below the ground plane in sub-step 1: its contact acceleration exceeds 1e10, MuJoCo [RECALL] resets mjData there and carries
+    on from qpos0.  The engine sees the cube's acceleration when the NEXT sub-step starts (the verdict rides on the flags the waves
+    exchange anyway) and resets the cube there and the robot one exchange later: one / two sub-steps of the remaining eighteen behind
+    the oracle, both from rest -- so the env-step's end state agrees to the little that one sub-step at rest moves (asserted), the
+    counters report the resets, and the neighbours are untouched."""
+    torch = torch_cuda
+    from tests.common import make_pair, sync_oracle_to
+    n = 64
+    envs, ora = make_pair(n, has_object=True, controller_type="joint", reward_type="dense", seed=8)
+    envs.reset(seed=8); ora.reset(seed=8)
+    a = np.zeros((n, 7), np.float32)
+    sync_oracle_to(envs, ora)
+    envs.counters(clear=True)
+    bad = [5, 33]
+    so = ora.get_state()
+    for i in bad:
+        so["qpos"][i, 12:15] = [0.5, 0.0, 1.0]; so["qvel"][i, 14] = -1e8
+    so["qpos_lag"] = so["qpos"].copy()
+    ora.set_state(**so)
+    sync_oracle_to(envs, ora)
+    obs, rew, term, trunc, info = envs.step(torch.as_tensor(a))
+    o = ora.step(a)
+    err = np.abs(obs["observation"].cpu().numpy() - o["obs"]).max(axis=1)
+    st, s2 = envs.get_state(), ora.get_state()
+    qerr = np.abs(st["qpos"].cpu().numpy().T - s2["qpos"]).max(axis=1)
+    c = envs.counters()
+    print(f"\nbad acceleration in sub-step 1 of an env-step: obs error of the two reset envs {err[bad]}, of the others {np.delete(err, bad).max():.2e}; "
+          f"qpos error of the reset envs {qerr[bad]}; counters {c}")
+    assert all(int(ora.data(i).get("warning_badstate", (1,), np.int32)[0]) >= 1 for i in bad)
+    assert c["bad_state_resets"] >= 2
+    assert all(torch.isfinite(v.double()).all() for v in st.values())
+    assert np.delete(err, bad).max() < 1e-8                       # the neighbours never notice
+    assert err[bad].max() < 5e-3 and qerr[bad].max() < 5e-3       # the reset envs: the oracle's state up to the one / two sub-steps of lag (at rest)
+    assert np.abs(st["qpos"].cpu().numpy()[14, bad] - 0.21).max() < 0.02                     # (the cube is back at its model pose on the table, not 2e6 m down)
+    envs.close()
+
+
 # ------------------------------------------------------------------------------------------------- RCCL, one rank
 def test_rccl_single_rank_reduction(torch_cuda, tmp_path):
     """The logging collective through RCCL itself (backend "nccl"), world size 1 on this box's one GPU: the call the 8-GPU run makes

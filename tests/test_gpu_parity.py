@@ -75,28 +75,33 @@ def test_every_substep_of_a_100_step_rollout(torch_cuda):
 
 @pytest.mark.parametrize("controller", ["joint", "IK"])
 def test_env_steps_from_identical_state(torch_cuda, controller):
-    """100 env-steps, state re-synchronised before each: the per-step error distribution."""
-    from tests.common import make_pair, sync_oracle_to, step_errors
+    """100 env-steps, state re-synchronised before each: the per-step error distribution.  The IK controller's 100 sub-steps of stiff
+    servos amplify a last-bit difference chaotically: its quantiles are held to the oracle's OWN sensitivity -- a
+    twin oracle started 1e-14 away -- not to an absolute number."""
+    from tests.common import make_pair, make_oracle, sync_oracle_to, step_errors, twin_errors, assert_within_oracle_sensitivity
     n = 256
     envs, ora = make_pair(n, controller_type=controller, reward_type="dense", seed=1)
+    twin = make_oracle(n, controller_type=controller, reward_type="dense", seed=1) if controller == "IK" else None
     envs.reset(seed=1); ora.reset(seed=1)
-    rng = np.random.default_rng(42)
-    errs = []
+    if twin: twin.reset(seed=1)
+    rng = np.random.default_rng(42); prng = np.random.default_rng(7)
+    errs, terrs = [], []
     mismatched_flags = 0
     for t in range(100):
         sync_oracle_to(envs, ora)
+        state = ora.get_state()
         a = rng.uniform(-1, 1, (n, envs.action_dim)).astype(np.float32)
         e, flags_equal, o = step_errors(envs, ora, a)
         mismatched_flags += (not flags_equal)
         errs.append(e)
+        if twin: terrs.append(twin_errors(twin, state, a, o, prng))
+    if twin: assert_within_oracle_sensitivity(errs, terrs, "[Reach IK env-step]")
     errs = np.concatenate(errs)
     q50, q99, mx = np.median(errs), np.quantile(errs, 0.99), errs.max()
     print(f"\n[{controller}] one env-step from identical state, {errs.size} samples: median {q50:.2e} p99 {q99:.2e} max {mx:.2e}")
     assert mismatched_flags == 0
     if controller == "joint":       # measured: median 3.5e-16, p99 2.0e-13, max 8.6e-11
         assert q50 < 1e-13 and q99 < 2e-11 and mx < 1e-8
-    else:                           # measured: median 2.7e-12, p99 1.6e-5, max 8e-3 (chaotic amplification over 100 sub-steps;
-        assert q50 < 3e-10 and q99 < 1e-3      # the quantiles are tied to the oracle's own sensitivity in test_gpu_fullsize_parity.py)
     envs.close()
 
 

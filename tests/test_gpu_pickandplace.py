@@ -257,6 +257,23 @@ def test_whole_env_step_from_random_policy_states(torch_cuda):
           f"arm-mesh contact, {e[~isarm].max():.2e} over {int((~isarm).sum())} without")
     assert e.max() < 1e-9                                          # measured 5e-12 / 7e-14 here, 3e-11 / 2e-12 over 256 envs (tools/state_vs_oracle.py)
     envs.close()
+    # ... and the same states under the reference's DEFAULT controller (IK: 100 sub-steps in one launch), judged on the arm-contact subset
+    # by the oracle's own sensitivity there (a twin oracle started 1e-14 away): chaotic states, no absolute number
+    from tests.common import make_oracle, twin_errors, assert_within_oracle_sensitivity
+    kw = dict(has_object=True, controller_type="IK", reward_type="dense", seed=0, max_episode_steps=10 ** 9)
+    envs, ora = make_pair(n, **kw)
+    twin = make_oracle(n, **kw)
+    envs.reset(seed=0); ora.reset(seed=0); twin.reset(seed=0)
+    ora.set_state(**ost)
+    envs.set_state(qpos=sel["qpos"], qvel=sel["qvel"], ctrl=sel["ctrl"], warm=sel["warm"], qpos_lag=sel["qpos_lag"], goal=sel["goal"],
+                   elapsed=torch.zeros(n, dtype=torch.int32), episode=sel["episode"])
+    state = ora.get_state()
+    a = np.random.default_rng(2).uniform(-0.3, 0.3, (n, 7)).astype(np.float32)
+    e, flags_equal, o = step_errors(envs, ora, a)
+    te = twin_errors(twin, state, a, o, np.random.default_rng(5))
+    assert_within_oracle_sensitivity([e[isarm]], [te[isarm]], "[PickAndPlace IK env-step, environments with an arm-mesh contact]")
+    assert_within_oracle_sensitivity([e[~isarm]], [te[~isarm]], "[PickAndPlace IK env-step, environments without]")
+    envs.close()
 
 
 def _finger_mesh_poses(count=128, seed=2, meshes=("right_finger_link", "left_finger_link")):
