@@ -1020,15 +1020,20 @@ MCG_DEV void coop_phase_body(ModelPtr P, LdsPtr lds0, unsigned m, int w, int mod
       const int j1 = grab();
       if (j1 >= npair) break;
       const int e1 = kth(rank_of(j1)), n1 = ncon_of(e1);
-      if (10 + 6 * n1 > 2 * PNP_LANES) { coop_solve_single((unsigned long long)P, (unsigned)(uintptr_t)lds0, e1, w, n1); continue; }      // more than nine contacts
-      int e2 = e1, n2 = n1, big = -1, nbig = 0; bool have2 = false;
-      const int j2 = grab();
-      if (j2 < npair) {
-        const int ec = kth(rank_of(j2)), nc = ncon_of(ec);
-        if (10 + 6 * nc <= 2 * PNP_LANES) { e2 = ec; n2 = nc; have2 = true; } else { big = ec; nbig = nc; }
+      // a list of more than nine contacts (rows beyond two sets) goes through the 32-lane solve -- INLINED here (one call site): these waves
+      // hold nothing across the phase, and an out-of-line call saves and restores ~220 dwords a lane (round 4: with every mesh colliding such
+      // lists are common under the mocap controller, and the calls were 370 MB of HBM writes per launch, 48x the algorithmic bytes)
+      int e2 = e1, n2 = n1, big = -1, nbig = 0; bool have2 = false, pair = true;
+      if (10 + 6 * n1 > 2 * PNP_LANES) { big = e1; nbig = n1; pair = false; }
+      else {
+        const int j2 = grab();
+        if (j2 < npair) {
+          const int ec = kth(rank_of(j2)), nc = ncon_of(ec);
+          if (10 + 6 * nc <= 2 * PNP_LANES) { e2 = ec; n2 = nc; have2 = true; } else { big = ec; nbig = nc; }
+        }
       }
-      coop_solve_pair<2>(P, lds0, ws, e1, e2, n1, n2, have2, CK);
-      if (big >= 0) coop_solve_single((unsigned long long)P, (unsigned)(uintptr_t)lds0, big, w, nbig);
+      if (pair) coop_solve_pair<2>(P, lds0, ws, e1, e2, n1, n2, have2, CK);
+      if (big >= 0) coop_solve<COOP_SETS>(P, lds0, big, ws, nbig, CK);
     }
   }
   coop_flush_clocks(CK);
