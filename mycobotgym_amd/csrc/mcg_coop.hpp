@@ -1,4 +1,4 @@
-// mcg_coop.hpp -- the coupled robot + cube solve of PickAndPlace, ONE ENVIRONMENT PER WAVE.
+// mcg_coop.hpp -- the coupled robot + cube solve of PickAndPlace, one environment per 32 lanes (two per wave on the 64-lane waves).
 //
 // Replaces, for an environment in which a contact reaches the robot (finger pad / finger link on the cube, pad or arm mesh on the
 // table / the ground), MuJoCo's mj_fwdConstraint over the 18 dofs (P9; call sites /root/reference/mycobotgym/envs/mycobot.py:170,193;
@@ -959,7 +959,7 @@ MCG_DEV void coop_solve_pair(ModelPtr Pm, LdsPtr lds0, LdsPtr wsw, int eA, int e
 // the common shape (two environments of up to nine contacts) is INLINED into the kernel's cube-wave and M / RNE-wave branches, which hold
 // next to nothing across the phase (the cube wave its cube, the others nothing).  The robot wave -- whose live state would be spilled
 // around an inlined copy, and whose contact-free pipeline an inlined copy slowed in round 2 -- called an out-of-line instance until the
-// pair solve; it no longer takes part (six environments per round of the workgroup instead of four).  The rare shape (more than nine
+// pair solve; since then it takes only a rank-fixed share (every COOP_ROBOT_EVERY-th flagged environment, and none below that many).  The rare shape (more than nine
 // contacts) and the one-environment-per-wave routing (MCG_COOP_PAIR=0: the first implementation, kept as a cross-check of the second)
 // are out of line.
 static __device__ __noinline__ void coop_solve_single(unsigned long long model_bits, unsigned lds_base, int e_, int wave, int ncon_) {
@@ -984,7 +984,7 @@ static __device__ __noinline__ void coop_solve_single(unsigned long long model_b
 // run must reproduce bit for bit -- so the robot wave's share is fixed by rank: of the flagged environments, in lane order, every
 // seventh is the robot wave's (a 32-lane solve takes about as long as a pair's), the others are handed out in pairs.  (Who is paired
 // with whom does race; a half's arithmetic never sees the other half's numbers.)
-constexpr int COOP_ROBOT_EVERY = 7;
+constexpr int COOP_ROBOT_EVERY = 13;     // (round 4: 7 -> 13.  With twice the flagged environments the robot wave had a share in every fifth sub-step, and each of its out-of-line calls is scratch traffic; it now joins only when the other three waves would need a third round)
 template <bool PAIRS = true>      // PAIRS = false: the robot wave's instance (modes 0 and 2 only) -- without the inlined pair solve its out-of-line
                                   // frame saves a handful of registers per call instead of ~50 dwords a lane
 MCG_DEV void coop_phase_body(ModelPtr P, LdsPtr lds0, unsigned m, int w, int mode) {

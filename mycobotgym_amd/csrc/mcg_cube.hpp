@@ -40,7 +40,6 @@ constexpr int NMESH = 14;
 enum { PAIR_TABLE_CUBE = 0, PAIR_PADR_CUBE = 1, PAIR_PADL_CUBE = 2, PAIR_TABLE_PADR = 3, PAIR_TABLE_PADL = 4, PAIR_STATIC_MESH0 = 5,
        PAIR_MESH0_CUBE = PAIR_STATIC_MESH0 + NMESH, NPAIR = PAIR_MESH0_CUBE + NMESH,
        PAR_TABLE_MESH = 5, PAR_MESH_CUBE = 6 };                  // rows of mcg_model.contact_par of the two mesh classes
-constexpr int ALONE_MAX_LIST = 8;   // list positions the cube wave's own solve may use (12 row slots each in the first 96 of the row area)
 MCG_DEV bool pair_has_cube(int type) { return type < PAIR_TABLE_PADR || type >= PAIR_MESH0_CUBE; }
 MCG_DEV bool pair_mesh_static(int type) { return type >= PAIR_STATIC_MESH0 && type < PAIR_MESH0_CUBE; }
 MCG_DEV bool pair_mesh_cube(int type) { return type >= PAIR_MESH0_CUBE; }
@@ -675,30 +674,30 @@ struct CubeSys {
   // line-search data.  When the mask is consistent -- the usual case -- x is the minimiser and B's forces are final.
   // zeros in the line-search rows and masks of the list positions this lane does not fill (see prepare()).  `skip`: the lane's column
   // of the row area is not this solve's to touch (four-wave kernel: the robot wave parks the coupled solve's inputs there).
-  MCG_DEV void clean_rows(bool skip = false, bool limited = false) const {
+  MCG_DEV void clean_rows(bool skip = false) const {
     for (int c = 0; __any(c < ncon); c++) {
-      if (c >= ncon && !skip && !(limited && c >= ALONE_MAX_LIST)) {
+      if (c >= ncon && !skip) {
         _Pragma("unroll") for (int k = 0; k < 12; k++) S.st(LDS_ROW + c * 12 + k, 0.0);
         S.st(LDS_ACT + c, 0.0);
       }
     }
   }
   // `skip`: this lane's env goes through the cooperative coupled solve instead; it walks the loops with an empty list and
-  // stores nothing (its result is discarded).  `limited`: the lane's column holds parked inputs above list position ALONE_MAX_LIST.
+  // stores nothing (its result is discarded).
   // A wave that holds static geom - robot contacts somewhere (rare; wave-uniform) runs the OFF = true instance: each lane's loops then
   // cover only the stretch of its list that holds the cube's contacts, positions c0 .. c0 + ncon - 1 (the robot's entries in front of
   // it -- arm meshes, pads on the ground -- would otherwise make the whole wave walk lists three times as long), and entries inside the
   // stretch that are not the cube's get D = 0.  The rows and masks in LDS are indexed by the position within the stretch.
-  MCG_DEV void solve_alone(bool skip = false, bool limited = false) {
+  MCG_DEV void solve_alone(bool skip = false) {
     const int ncon_all = ncon;
     if (__any(stat_on && !skip)) {
       c0 = sel(cube_hi >= 0, cube_lo, 0);
       ncon = sel(skip || cube_hi < 0, 0, cube_hi - cube_lo + 1);
-      clean_rows(skip, limited);
+      clean_rows(skip);
       solve_alone_impl<true>();
     } else {
       ncon = sel(skip, 0, ncon_all);
-      clean_rows(skip, limited);
+      clean_rows(skip);
       solve_alone_impl<false>();
     }
     ncon = ncon_all;

@@ -235,12 +235,20 @@ __global__ __launch_bounds__(SPLIT ? 192 : 64) void step_reach_kernel(Cfg C, Vie
       euler2quat(e, qr); mat2quat(X.mat, cur); mulquat(qr, cur, tquat);
     }
     const real grip = C.grip_center + (real)act_last * C.grip_range;
+    // (three-wave kernels: the target lives in LDS across the 5 x 20 sub-steps -- eight doubles that were otherwise spilled to scratch
+    // and reloaded around every control step)
+    if constexpr (SPLIT) { for (int k = 0; k < 3; k++) MS.st(LDS_IKT + k, tpos[k]); for (int k = 0; k < 4; k++) MS.st(LDS_IKT + 3 + k, tquat[k]); MS.st(LDS_IKT + 7, grip); }
     for (int c = 0; c < C.control_steps; c++) {
       if (c > 0) { if constexpr (SPLIT) for (int k = 0; k < 6; k++) E.qlag6[k] = MS.ld(LDS_QLAG + k); eef_forward(P, E.qlag6, X, true); }
       real dq[6];
-      ik_delta(X, tpos, tquat, dq);
+      if constexpr (SPLIT) {
+        real tp_[3], tq_[4];
+        for (int k = 0; k < 3; k++) tp_[k] = MS.ld(LDS_IKT + k);
+        for (int k = 0; k < 4; k++) tq_[k] = MS.ld(LDS_IKT + 3 + k);
+        ik_delta(X, tp_, tq_, dq);
+      } else ik_delta(X, tpos, tquat, dq);
       for (int k = 0; k < 6; k++) E.R.ctrl[k] += dq[k];
-      E.R.ctrl[6] = grip;
+      E.R.ctrl[6] = SPLIT ? MS.ld(LDS_IKT + 7) : grip;
       if (c == 0) for (int k = 0; k < 7; k++) E.R.ctrl[k] = sel(bad0, 0.0, E.R.ctrl[k]);      // mj_resetData inside the first mj_step, after data.ctrl was written
       MCG_TICK(ST_CTRL);
       for (int s = 0; s < C.frame_skip; s++) hadbad |= robot_substep<LaneScratch, NoCoupling, NoWeld, Split>(P, E.R, E.qlag6, MS);
@@ -571,7 +579,7 @@ MCG_DEV void cube_wave(const CubeWaveArgs& C, const View& V, ModelPtr P, const r
       MCG_TICK2(ST_X_NUMBERS);
       __syncthreads();                                              // S2 (the robot side's "M and bias ready")
       MCG_TICK2(ST_X_S2);
-      CS.solve_alone(kind == 2, false);                             // flagged lanes walk an empty list, store nothing
+      CS.solve_alone(kind == 2);                                    // flagged lanes walk an empty list, store nothing
       if (!__any(kind == 2)) { CS.finish(qlag7); Cb = CS.Cb; for (int k = 0; k < 3; k++) MS.st(MP_CUBE + k, Cb.pos[k]); }
       MCG_TICK2(ST_W2_CUBE);
     }
@@ -1015,9 +1023,7 @@ int mcg_create(const mcg_config* c, const mcg_model* model, const double* polyto
     e->num_cu = (hipGetDeviceProperties(&prop, device) == hipSuccess) ? prop.multiProcessorCount : 256;
     const char* ns = getenv("MCG_NO_SPLIT");
     e->no_split = ns && ns[0] == '1';
-    // Opt-in (measured): an environment whose robot touches only static geoms gets a 12-dof cooperative solve and its
-    // cube stays with the cube wave.  The solve is half the price, but the cube wave then walks those lanes' longer lists in its own
-    // lane-parallel solve: no net gain at 8192 environments under a random policy (PickAndPlace-IK 11.7 against 11.3 ms per step).
+    // MCG_COOP_PAIR=0: the cooperative phase's first implementation (one environment per wave), kept as a cross-check of the pair solve
     const char* cp = getenv("MCG_COOP_PAIR");
     C.coop_pair = !(cp && cp[0] == '0');
   }

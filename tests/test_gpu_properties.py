@@ -300,6 +300,33 @@ def test_ragged_env_counts_with_multi_wave_kernels(torch_cuda, has_object, n):
     envs.close()
 
 
+def test_ragged_workgroup_with_flagged_lanes_equals_the_full_one(torch_cuda):
+    """in a ragged last workgroup (n % 32 != 0) the surplus lanes shadow the last environment; they must not be handed
+    out to the cooperative solves, counted, or stored.  Scripted-grasp states (EVERY lane flagged, more than seven per workgroup): an
+    engine of 40 environments must reproduce, bit for bit, the first 40 of an engine of 64 over whole env-steps, and its coupled
+    env-sub-step counter must count 40 lanes per sub-step, not 64."""
+    torch = torch_cuda
+    from mycobotgym_amd import MyCobotVecEnv
+    from mycobotgym_amd.scenarios import grasp_state
+    st = grasp_state(64, seed=0)
+    act = torch.as_tensor(st.pop("action"), device="cuda")
+    outs = []
+    for n in (64, 40):
+        envs = MyCobotVecEnv(n, has_object=True, controller_type="joint", reward_type="dense", seed=3, max_episode_steps=10 ** 9)
+        envs.reset(seed=3)
+        envs.set_state(**{k: (torch.as_tensor(v)[..., :n] if torch.as_tensor(v).ndim and torch.as_tensor(v).shape[-1] == 64 else v) for k, v in st.items()})
+        envs.counters(clear=True)
+        for t in range(6): obs, *_ = envs.step(act[:n])
+        s = envs.get_state()
+        outs.append((obs["observation"].clone(), s["qpos"].clone(), s["qvel"].clone(), envs.counters()))
+        envs.close()
+    (o64, q64, v64, c64), (o40, q40, v40, c40) = outs
+    assert torch.equal(o64[:40], o40) and torch.equal(q64[:, :40], q40) and torch.equal(v64[:, :40], v40)
+    print(f"\nragged workgroup: counters of 64 envs {c64}, of 40 envs {c40}")
+    # 90 % of the env-sub-steps are coupled here: 24 shadow lanes counted along would push the 40-env count (4318 measured) past its ceiling
+    assert 0.8 * 40 * 6 * 20 < c40["coupled_env_substeps"] <= 40 * 6 * 20 and c64["coupled_env_substeps"] <= 64 * 6 * 20
+
+
 def test_long_random_rollouts_stay_finite(torch_cuda):
     """Every task / controller / fetch combination, 2048 envs, 150 random env-steps (three episodes, auto-resets, pad contacts
     in the fetch PickAndPlace starts): nothing may go non-finite, hang or trip the bad-state guard into a reset storm."""

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Development helper: time a bench.py workload and, when MCG_LIB is a -DMCG_STAGE_CLOCKS build, print the cooperative-solve counters.
 
-    [MCG_COOP12=0] [MCG_LIB=ab/clocks.so] python tools/coop_probe.py pnp-IK [steps] [warmup]
+    [MCG_COOP_PAIR=0] [MCG_LIB=ab/clocks.so] python tools/coop_probe.py pnp-IK [steps] [warmup]
 """
 import ctypes as C, os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
@@ -49,7 +49,7 @@ for t in range(steps):
     t0 = time.perf_counter(); envs.step_async(pool[t % 16]); torch.cuda.synchronize(); per.append((time.perf_counter() - t0) * 1e3)
 stop = True; th.join()
 print('   smi samples (sclk, power):', samples[:3], '...', samples[-6:])
-print(f"{case} coop12={os.environ.get('MCG_COOP12', '1')} lib={os.path.basename(os.environ.get('MCG_LIB', 'plain'))}: "
+print(f"{case} coop_pair={os.environ.get('MCG_COOP_PAIR', '1')} lib={os.path.basename(os.environ.get('MCG_LIB', 'plain'))}: "
       f"mean {sum(per) / len(per):.3f} ms/step; first {per[0]:.2f} min {min(per):.2f} max {max(per):.2f}; every 5th: " + " ".join(f"{x:.1f}" for x in per[::5]))
 if has_clk:
     import re
