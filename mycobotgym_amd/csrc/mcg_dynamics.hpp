@@ -42,7 +42,7 @@ enum { ST_LOAD = 0, ST_CTRL, ST_TRIG, ST_RNE, ST_ACT, ST_CRB, ST_ROWS, ST_G0, ST
        ST_COUPLED, ST_CUBE_FIN, ST_POST, ST_N_BUILD, ST_N_FACTOR, ST_N_SOLVE, ST_N_CHECK, ST_E_RHS, ST_R_AX5, ST_R_CONNECT, ST_R_LIMITS, ST_C_MASK, ST_C_ASSEMBLE, ST_C_SCHUR, ST_C_SOLVE, ST_C_CHECK, ST_C_LS, ST_W2_WAIT1, ST_W2_COLLIDE, ST_W2_CUBE, ST_W2_WAIT2, ST_W1_WAIT, ST_A_ENTRY, ST_A_G, ST_A_TWIST, ST_A_LOOP, ST_A_MAP, ST_A_STORE,
        ST_CO_SETUP, ST_CO_ROWS, ST_CO_H0, ST_CO_RESID, ST_CO_ASM, ST_CO_FACTOR, ST_CO_SOLVE, ST_CO_CHECK, ST_CO_LS, ST_CO_OUT, ST_CO_IDLE,
        ST_X_S1C, ST_X_NUMBERS, ST_X_S2, ST_S_S1B, ST_S_MESH, ST_S_S1C, ST_S_NUMBERS, ST_COUNT,
-       CN_SUBSTEP = 0, CN_NEWTON_IT, CN_LINESEARCH, CN_CUBE_IT, CN_CUBE_LS, CN_COUPLED, CN_COUPLED_IT, CN_COUPLED_LS, CN_CONTACTS, CN_COOP_ROWS, CN_COOP_LSEVAL, CN_COOP_LONG, CN_COOP_CAP, CN_COOP_12, CN_G_FAILED, CN_G_LIM, CN_G_STAT, CN_G_CUBE, CN_G_MISSING, CN_G_EXTRA, CN_G_EQ1, CN_G_EQ2, CN_G_EQ2N1, CN_COUNT };
+       CN_SUBSTEP = 0, CN_NEWTON_IT, CN_LINESEARCH, CN_CUBE_IT, CN_CUBE_LS, CN_COUPLED, CN_COUPLED_IT, CN_COUPLED_LS, CN_CONTACTS, CN_COOP_ROWS, CN_COOP_LSEVAL, CN_COOP_LONG, CN_COOP_CAP, CN_COOP_12, CN_G_FAILED, CN_G_LIM, CN_G_STAT, CN_G_CUBE, CN_G_MISSING, CN_G_EXTRA, CN_G_EQ1, CN_G_EQ2, CN_G_EQ2N1, CN_MP_PAIRS, CN_MP_HITS, CN_MP_FACE, CN_MP_EXIT_B, CN_MP_EXIT_P, CN_MP_EXIT_E, CN_MP_KIND_E, CN_MP_KIND_P, CN_MP_CUBE, CN_COUNT };
 #ifdef MCG_STAGE_CLOCKS
 __device__ unsigned long long g_stage_clocks[ST_COUNT + CN_COUNT];      // stage clocks, then event counts (summed over waves)
 __device__ unsigned long long g_tick_last[4096 * 4];

@@ -23,7 +23,7 @@
 
 namespace mcg {
 
-constexpr real MESH_TIE = 1e-12, MESH_EDGE_MIN_SIN = 1e-6;
+constexpr real MESH_TIE = 1e-12, MESH_EDGE_MIN_SIN = 1e-6, MESH_FACE_MARGIN = 1e-9;
 
 // ---- cross-lane helpers, 64 lanes
 MCG_DEV real mesh_rdlane(real v, int l) {
@@ -99,19 +99,12 @@ MCG_DEV bool mesh_ground(const MeshTab& T, int L, const real* R, const real* p, 
 // the cube): the normal points from the mesh to the box; else from the box to the mesh (the static table is geom1).
 MCG_DEV bool mesh_box(const MeshTab& T, int L, const real* Rm, const real* pm, const real* Rb, const real* pb, const real* h, bool flip,
                       real* pos, real* nrm, real& dist) {
-  // ---- the tables of the B and P families and the first chunk of E: all loads in flight before anything is used
+  // ---- the vertex table (B family): all loads in flight before anything is used
   real vx[MESH_VCH], vy[MESH_VCH], vz[MESH_VCH]; int kv[MESH_VCH];
   _Pragma("unroll") for (int cch = 0; cch < MESH_VCH; cch++) {
     kv[cch] = sel(64 * cch + L < T.vp, 64 * cch + L, L);
     vx[cch] = T.v[kv[cch]]; vy[cch] = T.v[T.vp + kv[cch]]; vz[cch] = T.v[2 * T.vp + kv[cch]];
   }
-  real fn[MESH_FCH][4]; int kf[MESH_FCH];
-  _Pragma("unroll") for (int cch = 0; cch < MESH_FCH; cch++) {
-    kf[cch] = sel(64 * cch + L < T.fp, 64 * cch + L, L);
-    _Pragma("unroll") for (int q = 0; q < 4; q++) fn[cch][q] = T.f[q * T.fp + kf[cch]];
-  }
-  real eA[12];
-  _Pragma("unroll") for (int q = 0; q < 12; q++) eA[q] = T.e[q * T.ep + L];
   MCG_FENCE();
   real c[3], b[3][3];                                               // the box in the mesh frame: centre, axes (rows)
   { const real rel[3] = {pb[0] - pm[0], pb[1] - pm[1], pb[2] - pm[2]};
@@ -135,7 +128,41 @@ MCG_DEV bool mesh_box(const MeshTab& T, int L, const real* Rm, const real* pm, c
     const bool t0 = sp > sB; sB = sel(t0, sp, sB); cB = sel(t0, 2 * j, cB);
     const bool t1 = sn > sB; sB = sel(t1, sn, sB); cB = sel(t1, 2 * j + 1, cB);
   }
-  if (sB > 0) return false;                                         // (uniform: every lane holds the same numbers)
+  if (sB > 0) { MCG_COUNTW(CN_MP_EXIT_B, 1); return false; }        // (uniform: every lane holds the same numbers)
+  // the deepest vertex along the winning box axis: the lowest index among the vertices that realise the extreme
+  const int jB = cB >> 1; const bool negB = (cB & 1) != 0;
+  int vB;
+  { const real ext = sel(negB, sel3(jB, wmn[0], wmn[1], wmn[2]), sel3(jB, wmx[0], wmx[1], wmx[2]));
+    const real mine = sel(negB, sel3(jB, mn[0], mn[1], mn[2]), sel3(jB, mx[0], mx[1], mx[2]));
+    const int kmine = sel(negB, sel3(jB, kn[0], kn[1], kn[2]), sel3(jB, kx[0], kx[1], kx[2]));
+    vB = wave_min_int(sel(mine == ext, kmine, 0x7fffffff)); }
+  const real pB[3] = {T.v[vB], T.v[T.vp + vB], T.v[2 * T.vp + vB]};
+  // ---- the shortcut of a contact in the middle of a box face.  With d = -sB the depth along box axis j and g_i = h_i - |b_i.(p* - c)|
+  // the clearances of the deepest vertex p* to the box's faces along the other two axes: every facet of the Minkowski difference with
+  // unit normal n lies at h_box(n) + h_poly(-n) >= h_box(n) - n.(p* - c) >= sum_i |n_i| (h_i - |x_i|) >= |n_j| d + (|n_i1| + |n_i2|) min(g)
+  // from the origin, which is >= d (|n|_1 >= 1) once both clearances are: no face normal of the polytope and no edge axis can be the
+  // axis of least penetration, and none can separate.  The exhaustive rule (the oracle's) then returns the B axis too -- ties go to
+  // B -- so the P and E families, two thirds of a touching pair's instructions, are skipped for an arm link lying on the table away from
+  // its rim.  (Not taken at d <= 1e-12, where the exhaustive rule's rounding decides whether the pair touches at all.)
+  bool faceB;
+  { real g = INFINITY;
+    _Pragma("unroll") for (int i = 0; i < 3; i++) {
+      const real xi = dot3(b[i], pB) - dot3(c, b[i]);
+      g = sel(i == jB, g, fmin(g, h[i] - fabs(xi)));
+    }
+    faceB = -sB > 1e-12 && g >= -sB + MESH_FACE_MARGIN; }
+  real s = sB; int kind = 0;
+  real sE = -INFINITY; int cE = 0, lnE = 0, cP = 0;
+  real nEl[3] = {0, 0, 0};
+  if (!faceB) {                                                     // uniform
+  real fn[MESH_FCH][4]; int kf[MESH_FCH];
+  _Pragma("unroll") for (int cch = 0; cch < MESH_FCH; cch++) {
+    kf[cch] = sel(64 * cch + L < T.fp, 64 * cch + L, L);
+    _Pragma("unroll") for (int q = 0; q < 4; q++) fn[cch][q] = T.f[q * T.fp + kf[cch]];
+  }
+  real eA[12];
+  _Pragma("unroll") for (int q = 0; q < 12; q++) eA[q] = T.e[q * T.ep + L];
+  MCG_FENCE();
   // ---- P: the polytope's face normals
   real sPl = -INFINITY; int cPl = 0x7fffffff;
   _Pragma("unroll") for (int cch = 0; cch < MESH_FCH; cch++) {
@@ -144,12 +171,12 @@ MCG_DEV bool mesh_box(const MeshTab& T, int L, const real* Rm, const real* pm, c
     const bool up = s > sPl || (s == sPl && kf[cch] < cPl);         // (padding faces: d = 1e30, never the largest; a repeated chunk: same value, higher index)
     sPl = sel(up, s, sPl); cPl = sel(up, kf[cch], cPl);
   }
-  real sP; int cP, lnP;
+  real sP; int lnP;
   wave_argmax(sPl, cPl, sP, cP, lnP);
-  if (sP > 0) return false;
+  if (sP > 0) { MCG_COUNTW(CN_MP_EXIT_P, 1); return false; }
   // ---- E: e_k x b_j inside the normal cone of edge k; the next chunk's loads are in flight while one is evaluated (two buffers, the loop
   // unrolled by two: no run-time index into a private array)
-  real sEl = -INFINITY, nEl[3] = {0, 0, 0}; int cEl = 0x7fffffff;
+  real sEl = -INFINITY; int cEl = 0x7fffffff;
   auto edges = [&](const real* e12, int k) {
     _Pragma("unroll") for (int j = 0; j < 3; j++) {
       constexpr int I1[3] = {1, 2, 0}, I2[3] = {2, 0, 1};
@@ -185,13 +212,13 @@ MCG_DEV bool mesh_box(const MeshTab& T, int L, const real* Rm, const real* pm, c
       edges(eB, k0 + 64 + L);
     }
   }
-  real sE; int cE, lnE;
   wave_argmax(sEl, cEl, sE, cE, lnE);
-  if (sE > 0) return false;
+  if (sE > 0) { MCG_COUNTW(CN_MP_EXIT_E, 1); return false; }
   // ---- the axis of least penetration (families in the order B, E, P; a later one must be larger by more than MESH_TIE) and its contact
-  real s = sB; int kind = 0;
   if (sE > s + MESH_TIE) { s = sE; kind = 1; }
   if (sP > s + MESH_TIE) { s = sP; kind = 2; }
+  MCG_COUNTW(CN_MP_KIND_E, kind == 1); MCG_COUNTW(CN_MP_KIND_P, kind == 2);
+  } else MCG_COUNTW(CN_MP_FACE, 1);
   real n[3], q[3];
   if (kind == 1) {                                                  // uniform branches
     _Pragma("unroll") for (int r = 0; r < 3; r++) n[r] = mesh_rdlane(nEl[r], lnE);
@@ -216,15 +243,9 @@ MCG_DEV bool mesh_box(const MeshTab& T, int L, const real* Rm, const real* pm, c
     const real g0 = sel(dot3(b[0], n) > 0, 1.0, -1.0) * h[0], g1 = sel(dot3(b[1], n) > 0, 1.0, -1.0) * h[1], g2 = sel(dot3(b[2], n) > 0, 1.0, -1.0) * h[2];
     _Pragma("unroll") for (int r = 0; r < 3; r++) q[r] = (c[r] - g0*b[0][r] - g1*b[1][r] - g2*b[2][r]) - 0.5*s*n[r];      // the box's deepest corner, half a depth forward
   } else {
-    const int j = cB >> 1; const bool neg = (cB & 1) != 0;
-    // the deepest vertex along n: the lowest index among the vertices that realise the extreme
-    const real ext = sel(neg, sel3(j, wmn[0], wmn[1], wmn[2]), sel3(j, wmx[0], wmx[1], wmx[2]));
-    const real mine = sel(neg, sel3(j, mn[0], mn[1], mn[2]), sel3(j, mx[0], mx[1], mx[2]));
-    const int kmine = sel(neg, sel3(j, kn[0], kn[1], kn[2]), sel3(j, kx[0], kx[1], kx[2]));
-    const int vB = wave_min_int(sel(mine == ext, kmine, 0x7fffffff));
-    const real sg = neg ? -1.0 : 1.0;
-    _Pragma("unroll") for (int r = 0; r < 3; r++) n[r] = sg * sel3(j, b[0][r], b[1][r], b[2][r]);
-    q[0] = T.v[vB] + 0.5*s*n[0]; q[1] = T.v[T.vp + vB] + 0.5*s*n[1]; q[2] = T.v[2 * T.vp + vB] + 0.5*s*n[2];           // half a depth back
+    const real sg = negB ? -1.0 : 1.0;
+    _Pragma("unroll") for (int r = 0; r < 3; r++) n[r] = sg * sel3(jB, b[0][r], b[1][r], b[2][r]);
+    q[0] = pB[0] + 0.5*s*n[0]; q[1] = pB[1] + 0.5*s*n[1]; q[2] = pB[2] + 0.5*s*n[2];                                    // the deepest vertex, half a depth back
   }
   _Pragma("unroll") for (int r = 0; r < 3; r++) {
     pos[r] = pm[r] + Rm[3*r]*q[0] + Rm[3*r+1]*q[1] + Rm[3*r+2]*q[2];
@@ -261,6 +282,7 @@ MCG_DEV void mesh_env(ModelPtr Pm, const real* __restrict__ poly, LdsPtr lds0, i
     _Pragma("unroll") for (int k = 0; k < 3; k++) pm[k] = ME.ld(MP_FRAME + body * 12 + 9 + k);
     const MeshTab T = mesh_tab(poly, m);
     real pos[3], nrm[3], dist = 1.0; bool hit;
+    MCG_COUNTW(CN_MP_PAIRS, 1); MCG_COUNTW(CN_MP_CUBE, o == 2);
     if (o == 0) hit = mesh_ground(T, L, Rm, pm, pos, nrm, dist);
     else {
       const bool cube = o == 2;
@@ -270,6 +292,7 @@ MCG_DEV void mesh_env(ModelPtr Pm, const real* __restrict__ poly, LdsPtr lds0, i
       hit = mesh_box(T, L, Rm, pm, Rb, pb, hb, cube, pos, nrm, dist);
     }
     if (hit) {                                                      // uniform
+      MCG_COUNTW(CN_MP_HITS, 1);
       if (ncon < MAXCON) {
         const int bse = LDS_CON + ncon * CON_STRIDE;
         const int type = (o == 2 ? PAIR_MESH0_CUBE : PAIR_STATIC_MESH0) + m;

@@ -31,7 +31,9 @@ COUNTS = ["robot sub-steps", "robot Newton iterations", "robot line searches", "
           "coop active rows (sum over iterations)", "coop line-search evaluations", "coop solves whose carried active set was confirmed at once", "coop solves at the 50-iteration cap", "coop solves that started from a carried active set",
           "pair solves whose carried set was wrong", "wrong rows: joint limits", "wrong rows: static geom - robot contacts", "wrong rows: contacts of the cube",
           "wrong rows: missing from the carried set", "wrong rows: surplus in the carried set",
-          "pair solves whose final set = the set of the last sub-step", "... = the set of two sub-steps ago", "... = the set of two sub-steps ago and not the last one's"]
+          "pair solves whose final set = the set of the last sub-step", "... = the set of two sub-steps ago", "... = the set of two sub-steps ago and not the last one's",
+          "mesh pairs in the narrow phase", "mesh pairs that touch", "... decided by the face shortcut", "mesh pairs separated by a box axis", "... by a polytope face", "... by an edge axis",
+          "contacts on an edge axis", "contacts on a polytope face", "mesh pairs against the cube"]
 fresh = "--fresh-actions" in sys.argv
 mocap = "--pnp-mocap" in sys.argv
 grasp = "--grasp" in sys.argv           # PickAndPlace joint with every env holding the cube (scripted grasp state)
