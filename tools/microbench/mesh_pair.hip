@@ -1,8 +1,9 @@
 // Micro-benchmark: what does ONE polytope-box pair of the mesh narrow phase (csrc/mcg_mesh.hpp: mesh_box) cost a wave that is alone on its
 // SIMD, as in the PickAndPlace kernels?  One 64-lane workgroup per CU, the default polytope block, a box placed so that the pair touches
 // (the full path: B, P and E families, contact) or far away (separated by a box axis).  gfx950.
-// Measured (round 4, profiles/r04x/mesh_pair.log): 10.2 k clocks per touching pair -- ~1 600 executed instructions of which 660 are FP64,
-// 6 clocks each -- and 2.3 k for a pair that a box axis separates; stopping early: B 2.2 k, P +1.5 k, E +5.0 k, contact +1.6 k.
+// Measured (round 4): the exhaustive search 10.2 k clocks per touching pair (profiles/r04x/mesh_pair.log; ~1 600 executed instructions of
+// which 660 are FP64, 6 clocks each; stopping early: B 2.2 k, P +1.5 k, E +5.0 k, contact +1.6 k), 2.3 k for a pair that a box axis
+// separates; with the face bound (profiles/r04y/mesh_pair.log) a contact in the middle of a box face 3.5 k.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++20 -Iinclude -Imycobotgym_amd/csrc tools/microbench/mesh_pair.hip -o /tmp/mesh_pair && /tmp/mesh_pair
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -51,7 +52,7 @@ int main() {
   double* d_poly; hipMalloc(&d_poly, sizeof(kDefaultPolytopes)); hipMemcpy(d_poly, kDefaultPolytopes, sizeof(kDefaultPolytopes), hipMemcpyHostToDevice);
   unsigned long long* d_out; hipMalloc(&d_out, nwg * 8); double* d_sink; hipMalloc(&d_sink, nwg * 64 * 8); int* d_hits; hipMalloc(&d_hits, nwg * 4);
   double* d_pose; hipMalloc(&d_pose, 64 * NMESH * 27 * 8);
-  for (int variant = 0; variant < 3; variant++) {            // 0: touching (box face under the polytope's lowest vertex), 1: a box of the cube's size in touch, 2: far away
+  for (int variant = 0; variant < 4; variant++) {            // 0: touching in the middle of the table-sized box's face, 1: a cube-sized box, 2: far away, 3: touching 1 mm from the rim
     std::vector<double> P(64 * NMESH * 27); unsigned s = 12345u;
     for (int w = 0; w < 64; w++) for (int m = 0; m < NMESH; m++) {
       double* q = &P[(size_t)(w * NMESH + m) * 27];
@@ -67,7 +68,7 @@ int main() {
       }
       const double hx = variant == 1 ? 0.02 : 0.4, hz = variant == 1 ? 0.02 : 0.1;
       q[24] = hx; q[25] = hx; q[26] = hz;
-      q[21] = lx + (variant == 1 ? 0.013 : 0.0); q[22] = ly + (variant == 1 ? 0.011 : 0.0);
+      q[21] = lx + (variant == 1 ? 0.013 : variant == 3 ? hx - 0.001 : 0.0); q[22] = ly + (variant == 1 ? 0.011 : 0.0);
       q[23] = lo - hz + (variant == 2 ? -0.5 : 0.002);                                 // 2 mm deep, or half a metre below
     }
     hipMemcpy(d_pose, P.data(), P.size() * 8, hipMemcpyHostToDevice);
@@ -79,7 +80,7 @@ int main() {
     hipMemcpy(o.data(), d_out, nwg * 8, hipMemcpyDeviceToHost); hipMemcpy(hh.data(), d_hits, nwg * 4, hipMemcpyDeviceToHost);
     double sum = 0; long nh = 0; for (int w = 0; w < nwg; w++) { sum += (double)o[w]; nh += hh[w]; }
     printf("%-48s %8.0f clocks per pair (%d workgroups x %d pairs, %.1f %% touch)\n",
-           variant == 0 ? "table-sized box, 2 mm under the lowest vertex:" : variant == 1 ? "cube-sized box, 2 mm under the lowest vertex:" : "box far below (separated by a box axis):",
+           variant == 0 ? "table-sized box, 2 mm under the lowest vertex:" : variant == 1 ? "cube-sized box, 2 mm under the lowest vertex:" : variant == 2 ? "box far below (separated by a box axis):" : "table-sized box, the vertex 1 mm from its rim:",
            sum / nwg / iters, nwg, iters, 100.0 * nh / ((double)nwg * iters));
   }
   return 0;
