@@ -573,26 +573,15 @@ struct CubeSys {
       const bool nearstat = dtab < 0.17 * 0.17 || p[2] < 0.17;
       padlive = reach || nearstat;
       if (__any(padlive)) {
-        // one of the gripper's six small parts: its bounding sphere (mcg_body.hull_rad: the farthest polytope vertex from the body's
-        // origin) against the table top's height and the cube's sphere first -- with the gripper in the air (a resting cube, most of an
-        // episode) no lane of the wave passes, and the box tests of all six parts are skipped (round 4: they cost every sub-step 4 k clocks)
-        auto part = [&](int m, int body, real rad, const real* Rp, const real* pp) {
-          const real dx = pp[0] - Cb.pos[0], dy = pp[1] - Cb.pos[1], dz = pp[2] - Cb.pos[2];
-          const bool nc = reach && dx*dx + dy*dy + dz*dz < (rad + crad) * (rad + crad);
-          const bool ns = nearstat && pp[2] - rad < tp[2] + th[2];
-          bool any = false;
-          if (__any(nc || ns)) any = broad(m, body, Rp, pp, ns, nc);      // wave-uniform
-          park_frame(S, body, Rp, pp, any);
-        };
         static_for<2>([&](auto Sd) {
           constexpr int sd = Sd; constexpr int g = 6 + 2 * sd, f = 7 + 2 * sd;
           real ps[3];
           _Pragma("unroll") for (int k = 0; k < 9; k++) Rs[sd][k] = R[k];
           _Pragma("unroll") for (int k = 0; k < 3; k++) ps[k] = p[k];
           real r[3]; ldc<3>(Q->body[g].r, r); joint(g, 1, AXS[g], r, qr[g], Rs[sd], ps);
-          part(8 + 2 * sd, g, Q->body[g].hull_rad, Rs[sd], ps);                                  // gear link
+          park_frame(S, g, Rs[sd], ps, broad(8 + 2 * sd, g, Rs[sd], ps, nearstat, reach));      // gear link
           ldc<3>(Q->body[f].r, r); joint(f, 1, AXS[f], r, qr[f], Rs[sd], ps);
-          part(9 + 2 * sd, f, Q->body[f].hull_rad, Rs[sd], ps);                                  // finger link
+          park_frame(S, f, Rs[sd], ps, broad(9 + 2 * sd, f, Rs[sd], ps, nearstat, reach));      // finger link
           real pb[6]; ldc<6>(Q->pad_box[sd], pb);
           _Pragma("unroll") for (int k = 0; k < 3; k++) { pc[sd][k] = ps[k] + Rs[sd][3*k]*pb[0] + Rs[sd][3*k+1]*pb[1] + Rs[sd][3*k+2]*pb[2]; ph[sd][k] = pb[3 + k]; }
           // the hinge link of this side (its joint hangs on link6)
@@ -600,7 +589,7 @@ struct CubeSys {
           _Pragma("unroll") for (int k = 0; k < 9; k++) Rh[k] = R[k];
           _Pragma("unroll") for (int k = 0; k < 3; k++) phg[k] = p[k];
           ldc<3>(Q->body[10 + sd].r, r); joint(10 + sd, 1, AXS[10 + sd], r, qr[10 + sd], Rh, phg);
-          part(12 + sd, 10 + sd, Q->body[10 + sd].hull_rad, Rh, phg);
+          park_frame(S, 10 + sd, Rh, phg, broad(12 + sd, 10 + sd, Rh, phg, nearstat, reach));
         });
       }
     }
