@@ -358,7 +358,7 @@ constexpr int LDS_HEQ = NB * (NB + 1) / 2;            // H_eq = M + J^T D J over
 constexpr int LDS_SLOTS = 2 * (NB * (NB + 1) / 2);
 // two-wave variant (SplitA / helper_substep): factor of M + hB, its reciprocal pivots, and q published for the helper wave
 constexpr int LDS_FAC = LDS_SLOTS, LDS_FDINV = LDS_FAC + NB * (NB + 1) / 2, LDS_QB = LDS_FDINV + NB, LDS_QDB = LDS_QB + NB;
-constexpr int LDS_FS = LDS_QDB + NB, LDS_WARM = LDS_FS + NB, LDS_QLAG = LDS_WARM + NB, LDS_IKT = LDS_QLAG + 6, LDS_SLOTS_SPLIT = LDS_IKT + 8;      // LDS_WARM: qacc_warmstart parked between sub-steps; LDS_QLAG: q of the last forward pass; LDS_IKT: the IK controller's target pose and gripper command, parked across the sub-steps
+constexpr int LDS_FS = LDS_QDB + NB, LDS_WARM = LDS_FS + NB, LDS_QLAG = LDS_WARM + NB, LDS_IKT = LDS_QLAG + 6, LDS_SLOTS_SPLIT = LDS_IKT + 8;      // LDS_WARM: qacc_warmstart parked between sub-steps; LDS_QLAG: q of the last forward pass; LDS_IKT: the IK controller's six ctrl increments of a control step, handed from the RNE wave to the main wave (two slots spare)
 // The lane's LDS column.  The pointer carries the LDS address space explicitly: passed through structs as a generic
 // pointer the accesses degrade to flat_load/flat_store with 64-bit address arithmetic instead of ds_read/ds_write
 // with immediate offsets.

@@ -203,9 +203,47 @@ __global__ __launch_bounds__(SPLIT ? 192 : 64) void step_reach_kernel(Cfg C, Vie
   if (i >= C.n) return;                          // the same lanes leave in both waves: barriers stay matched
   if constexpr (SPLIT) {
     if (threadIdx.x >= 64) {                     // helper wave: M and the Euler factor; RNE wave: passive - bias forces
-      const int total = (CONTROLLER == MCG_CTRL_IK ? C.control_steps : 1) * C.frame_skip;
-      if (threadIdx.x < 128) { for (int s = 0; s < total; s++) helper_substep(P, MS); }
-      else { for (int s = 0; s < total; s++) rne_substep(P, MS); }
+      if constexpr (CONTROLLER == MCG_CTRL_IK) {
+        // The IK controller (S2 / S3: mycobot.py:134-170, utils.py:499-556) runs on the RNE wave: the main wave carries the robot's whole
+        // state through the sub-step loop, and the controller's Jacobians and 6 x 6 solve on top of it were that kernel's scratch frame
+        // (612 B a lane; the joint kernel's is 12).  Per control step: C1 -- the lagged q of the last sub-step is in LDS -- the RNE wave
+        // solves and leaves the six increments in the LDS_IKT slots -- C2 -- the main wave adds them to its ctrl.  The target pose is
+        // formed once from the first pose and stays in the RNE wave's registers; the helper wave only passes the two barriers.
+        if (threadIdx.x < 128) {
+          for (int c = 0; c < C.control_steps; c++) { __syncthreads(); __syncthreads(); for (int s = 0; s < C.frame_skip; s++) helper_substep(P, MS); }
+        } else {
+          float act[8];
+          _Pragma("unroll") for (int k = 0; k < 8; k++) {
+            const float x = (k < C.act_dim) ? actions[(size_t)i * C.act_dim + (k < C.act_dim ? k : 0)] : 0.f;
+            act[k] = fminf(fmaxf(x, -1.f), 1.f);
+          }
+          real tpos[3], tquat[4];
+          for (int c = 0; c < C.control_steps; c++) {
+            __syncthreads();                                        // C1
+            real ql[6]; EefPose X;
+            for (int k = 0; k < 6; k++) ql[k] = MS.ld(LDS_QLAG + k);
+            eef_forward(P, ql, X, true);
+            if (c == 0) {
+              for (int k = 0; k < 3; k++) tpos[k] = X.pos[k] + (real)(act[k] * 0.2f);      // f32 product, as numpy computes it
+              if (C.fetch) { tquat[0] = 0; tquat[1] = -0.707; tquat[2] = 0; tquat[3] = 0.707; }
+              else {
+                real e[3], qr[4], cur[4];
+                for (int k = 0; k < 3; k++) e[k] = (real)(act[3 + k] * 0.5f);
+                euler2quat(e, qr); mat2quat(X.mat, cur); mulquat(qr, cur, tquat);
+              }
+            }
+            real dq[6];
+            ik_delta(X, tpos, tquat, dq);
+            for (int k = 0; k < 6; k++) MS.st(LDS_IKT + k, dq[k]);
+            __syncthreads();                                        // C2
+            for (int s = 0; s < C.frame_skip; s++) rne_substep(P, MS);
+          }
+        }
+      } else {
+        const int total = C.frame_skip;
+        if (threadIdx.x < 128) { for (int s = 0; s < total; s++) helper_substep(P, MS); }
+        else { for (int s = 0; s < total; s++) rne_substep(P, MS); }
+      }
       return;
     }
   }
@@ -223,7 +261,18 @@ __global__ __launch_bounds__(SPLIT ? 192 : 64) void step_reach_kernel(Cfg C, Vie
   }
   const float act_last = C.act_dim == 8 ? act[7] : (C.act_dim == 7 ? act[6] : act[3]);     // the gripper command
 
-  if constexpr (CONTROLLER == MCG_CTRL_IK) {
+  if constexpr (CONTROLLER == MCG_CTRL_IK && SPLIT) {
+    const real grip = C.grip_center + (real)act_last * C.grip_range;
+    for (int c = 0; c < C.control_steps; c++) {
+      __syncthreads();                                              // C1: the lagged q is in LDS (from load_robot, or the last sub-step)
+      __syncthreads();                                              // C2: the RNE wave's increments are
+      for (int k = 0; k < 6; k++) E.R.ctrl[k] += MS.ld(LDS_IKT + k);
+      E.R.ctrl[6] = grip;
+      if (c == 0) for (int k = 0; k < 7; k++) E.R.ctrl[k] = sel(bad0, 0.0, E.R.ctrl[k]);      // mj_resetData inside the first mj_step, after data.ctrl was written
+      MCG_TICK(ST_CTRL);
+      for (int s = 0; s < C.frame_skip; s++) hadbad |= robot_substep<LaneScratch, NoCoupling, NoWeld, Split>(P, E.R, E.qlag6, MS);
+    }
+  } else if constexpr (CONTROLLER == MCG_CTRL_IK) {
     EefPose X;
     eef_forward(P, E.qlag6, X, true);
     real tpos[3], tquat[4];
@@ -235,20 +284,12 @@ __global__ __launch_bounds__(SPLIT ? 192 : 64) void step_reach_kernel(Cfg C, Vie
       euler2quat(e, qr); mat2quat(X.mat, cur); mulquat(qr, cur, tquat);
     }
     const real grip = C.grip_center + (real)act_last * C.grip_range;
-    // (three-wave kernels: the target lives in LDS across the 5 x 20 sub-steps -- eight doubles that were otherwise spilled to scratch
-    // and reloaded around every control step)
-    if constexpr (SPLIT) { for (int k = 0; k < 3; k++) MS.st(LDS_IKT + k, tpos[k]); for (int k = 0; k < 4; k++) MS.st(LDS_IKT + 3 + k, tquat[k]); MS.st(LDS_IKT + 7, grip); }
     for (int c = 0; c < C.control_steps; c++) {
-      if (c > 0) { if constexpr (SPLIT) for (int k = 0; k < 6; k++) E.qlag6[k] = MS.ld(LDS_QLAG + k); eef_forward(P, E.qlag6, X, true); }
+      if (c > 0) eef_forward(P, E.qlag6, X, true);
       real dq[6];
-      if constexpr (SPLIT) {
-        real tp_[3], tq_[4];
-        for (int k = 0; k < 3; k++) tp_[k] = MS.ld(LDS_IKT + k);
-        for (int k = 0; k < 4; k++) tq_[k] = MS.ld(LDS_IKT + 3 + k);
-        ik_delta(X, tp_, tq_, dq);
-      } else ik_delta(X, tpos, tquat, dq);
+      ik_delta(X, tpos, tquat, dq);
       for (int k = 0; k < 6; k++) E.R.ctrl[k] += dq[k];
-      E.R.ctrl[6] = SPLIT ? MS.ld(LDS_IKT + 7) : grip;
+      E.R.ctrl[6] = grip;
       if (c == 0) for (int k = 0; k < 7; k++) E.R.ctrl[k] = sel(bad0, 0.0, E.R.ctrl[k]);      // mj_resetData inside the first mj_step, after data.ctrl was written
       MCG_TICK(ST_CTRL);
       for (int s = 0; s < C.frame_skip; s++) hadbad |= robot_substep<LaneScratch, NoCoupling, NoWeld, Split>(P, E.R, E.qlag6, MS);
