@@ -11,7 +11,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 import numpy as np
 import torch
 import bench
-from mycobotgym_amd import MyCobotVecEnv
+from mycobotgym_amd import MyCobotVecEnv, _abi
 
 case = sys.argv[1] if len(sys.argv) > 1 else "pnp-IK"
 warm = int(sys.argv[2]) if len(sys.argv) > 2 else 100
@@ -24,18 +24,18 @@ g = torch.Generator(device="cuda"); g.manual_seed(1234)
 envs.set_state(elapsed=torch.randint(0, 50, (n,), device="cuda", generator=g, dtype=torch.int32))
 pool = torch.rand(16, n, envs.action_dim, device="cuda", generator=g) * 2 - 1
 for t in range(warm): envs.step_async(pool[t % 16])
-hist_n = np.zeros(13, int); hist_rows = np.zeros(8, int); hist_wg = np.zeros(33, int); flagged_tot = 0; types = np.zeros(32, int)
+hist_n = np.zeros(_abi.MAXCON + 1, int); hist_rows = np.zeros(8, int); hist_wg = np.zeros(33, int); flagged_tot = 0; types = np.zeros(5 + 2 * _abi.NMESH, int)
 for s in range(samples):
     for t in range(3): envs.step_async(pool[(s * 3 + t) % 16])
     kc = {k: v.cpu().numpy() for k, v in envs.debug_contacts().items()}
     cnt, typ = kc["count"], kc["type"]
-    valid = np.arange(12)[None, :] < cnt[:, None]
+    valid = np.arange(_abi.MAXCON)[None, :] < cnt[:, None]
     robot = valid & (typ != 0)                       # PAIR_TABLE_CUBE = 0 is the only pair that does not reach the robot
     flagged = robot.any(1)
     flagged_tot += flagged.sum()
     for c in cnt[flagged]: hist_n[c] += 1
-    # rows if packed tightly: 6 per condim-4 contact, 4 per condim-3 (arm mesh on the table: types 5..12)
-    cd3 = valid & (typ >= 5) & (typ < 13)
+    # rows if packed tightly: 6 per condim-4 contact, 4 per condim-3 (a mesh on the table / the ground: types 5 .. 5 + NMESH - 1)
+    cd3 = valid & (typ >= 5) & (typ < 5 + _abi.NMESH)
     rows = (6 * valid.sum(1) - 2 * cd3.sum(1))[flagged]
     for r in rows: hist_rows[min(r // 16, 7)] += 1
     for w in flagged.reshape(-1, 32).sum(1): hist_wg[w] += 1
